@@ -1,0 +1,287 @@
+// lane_math.h -- per-lane (one 64-char word) bit-sliced arithmetic of the fused split-mask kernel.
+//
+// One lane of a wavefront owns one 64-bit word of every feature plane: bit i of a plane = the feature of char
+// (word_base + i).  Everything in this header is pure integer math on that word plus a few carry bits, so it compiles
+// for the device (hipcc) and for the host (the CPU model under oracle/ that is used to debug the algorithm; the
+// product never runs it).
+//
+// Reference semantics restated here (all citations are to the reference tree):
+//   * base features + context columns .......... latok/core/src/latok/latok.c:87-134
+//   * C_SPLIT / C_MASK / C_SYM rule tables ..... latok/core/default_tokenizer.py:39-110
+//   * gen_block_mask queue semantics ........... latok/core/src/latok/latok.c:217-245
+//   * splits = raw*mask + sym; splits[0]=1 ..... latok/core/default_tokenizer.py:121-132
+#ifndef LATOK_LANE_MATH_H
+#define LATOK_LANE_MATH_H
+#include <stdint.h>
+
+#include "split_code.h"
+
+#if defined(__HIPCC__)
+#define LATOK_HD __host__ __device__ inline
+#else
+#define LATOK_HD static inline
+#endif
+
+typedef unsigned long long lk_u64;
+
+LATOK_HD int lk_popc(lk_u64 x) { return __builtin_popcountll(x); }
+LATOK_HD int lk_ctz(lk_u64 x) { return __builtin_ctzll(x); }  // x != 0
+LATOK_HD lk_u64 lk_rev(lk_u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse64(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 8x8 bit-matrix transpose: input byte r (bits 8r..8r+7) = row r; output byte c holds column c (bit r = row r).
+// ---------------------------------------------------------------------------------------------------------------
+LATOK_HD lk_u64 lk_transpose8(lk_u64 x) {
+    lk_u64 t;
+    t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;  x ^= t ^ (t << 7);
+    t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull; x ^= t ^ (t << 14);
+    t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull; x ^= t ^ (t << 28);
+    return x;
+}
+
+// 64 code bytes (d[k] = chars 4k..4k+3, little endian) -> 8 planes; plane[b] bit i = bit b of char i's code.
+LATOK_HD void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
+    lk_u64 y[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) y[g] = lk_transpose8((lk_u64)d[2 * g] | ((lk_u64)d[2 * g + 1] << 32));
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        lk_u64 p = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) p |= ((y[g] >> (8 * b)) & 0xFFull) << (8 * g);
+        plane[b] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Features of one word, decoded from the split-code planes (split_code.h).
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_feat {
+    lk_u64 S, Y, L, U, AN, A, T, AT, CO, SL, PE;
+};
+
+LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
+    lk_feat f;
+    f.S = p[LK_BIT_SPACE];
+    f.Y = p[LK_BIT_SYMBOL];
+    f.L = p[LK_BIT_LOWER];
+    f.U = p[LK_BIT_UPPER];
+    f.AN = p[LK_BIT_ALNUM];
+    f.A = p[5] & ~f.Y;              // bit5 = ALPHA when SYMBOL=0
+    f.T = p[5] & f.Y & ~p[7];       // sub 1 (# $ ^) or 3 ('@')
+    f.AT = p[5] & p[6];             // sub 3
+    f.CO = p[7] & ~p[6] & ~p[5];    // sub 4
+    f.SL = p[7] & p[5];             // sub 5
+    f.PE = p[7] & p[6];             // sub 6
+    return f;
+}
+
+// neighbour characters outside the word: codes of char (base-1), (base+64), (base+65); 0 when they do not exist
+struct lk_halo {
+    uint32_t prev, next0, next1;
+};
+
+LATOK_HD lk_u64 lk_code_bit(uint32_t code, int feature /* index into lk_feat order */) {
+    lk_u64 p[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) p[b] = (code >> b) & 1u;
+    lk_feat f = lk_decode(p);
+    const lk_u64* a = &f.S;
+    return a[feature] & 1ull;
+}
+
+// outputs of the purely local rules for one word
+struct lk_local {
+    lk_u64 t_space, t_sym, t_prevsym, t_camel_next, t_camel_prev;  // the five C_SPLIT terms (for 0..5 values)
+    lk_u64 raw;    // OR of the five terms  (C_SPLIT != 0)
+    lk_u64 start;  // C_MASK term: URL / e-mail / twitter starts
+    lk_u64 sym;    // C_SYM term: SYMBOL & NEXT_SPACE
+    lk_u64 S;      // space plane (block delimiters)
+};
+
+// B  = string-start bits of this word; Bn = bits 0..1 = string-start bits of the next two chars after the word.
+// Edge conventions (latok.c:69-73,114-134): at a string start PREV_SPACE=1 and the other PREV_* are 0; at a string
+// end NEXT_SPACE=1 and the other NEXT_* are 0; AFTER_NEXT_* are 0 for the last two chars.
+LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
+    lk_u64 pc[8], n0[8], n1[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        pc[b] = (h.prev >> b) & 1u;
+        n0[b] = (h.next0 >> b) & 1u;
+        n1[b] = (h.next1 >> b) & 1u;
+    }
+    const lk_feat fp = lk_decode(pc), f0 = lk_decode(n0), f1 = lk_decode(n1);
+
+    const lk_u64 E = (B >> 1) | ((Bn & 1ull) << 63);               // last char of a string
+    const lk_u64 E2 = E | (B >> 2) | ((Bn & 3ull) << 62);          // last or second-to-last char
+    const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
+
+#define LK_PREV(X) ((((f.X) << 1) | (fp.X & 1ull)) & nB)
+#define LK_NEXT(X) ((((f.X) >> 1) | ((f0.X & 1ull) << 63)) & nE)
+#define LK_ANEXT(X) ((((f.X) >> 2) | ((f0.X & 1ull) << 62) | ((f1.X & 1ull) << 63)) & nE2)
+    const lk_u64 prevS = ((f.S << 1) | (fp.S & 1ull)) | B;
+    const lk_u64 nextS = ((f.S >> 1) | ((f0.S & 1ull) << 63)) | E;
+    const lk_u64 prevY = LK_PREV(Y), prevL = LK_PREV(L), prevAN = LK_PREV(AN), prevA = LK_PREV(A);
+    const lk_u64 nextL = LK_NEXT(L), nextA = LK_NEXT(A), nextAN = LK_NEXT(AN), nextAT = LK_NEXT(AT),
+                 nextSL = LK_NEXT(SL);
+    const lk_u64 anA = LK_ANEXT(A), anSL = LK_ANEXT(SL);
+#undef LK_PREV
+#undef LK_NEXT
+#undef LK_ANEXT
+
+    lk_local r;
+    r.S = f.S;
+    r.t_space = f.S;                  // [SPACE]
+    r.t_sym = f.Y;                    // [SYMBOL]
+    r.t_prevsym = prevY;              // [PREV_SYMBOL]
+    r.t_camel_next = f.U & nextL;     // [UPPER, NEXT_LOWER]
+    r.t_camel_prev = f.U & prevL;     // [UPPER, PREV_LOWER]
+    r.raw = r.t_space | r.t_sym | r.t_prevsym | r.t_camel_next | r.t_camel_prev;
+    r.start = (f.T & prevS & nextA)                 // [TWITTER, PREV_SPACE, NEXT_ALPHA]
+              | (f.PE & prevS & nextAT & anA)       // [CHAR_PERIOD, PREV_SPACE, NEXT_AT, AFTER_NEXT_ALPHA]
+              | (f.AT & prevAN & nextAN)            // [CHAR_AT, PREV_ALPHA_NUM, NEXT_ALPHA_NUM]
+              | (f.CO & nextSL & anSL & prevA);     // [CHAR_COLON, NEXT_SLASH, AFTER_NEXT_SLASH, PREV_ALPHA]
+    r.sym = f.Y & nextS;              // [SYMBOL, NEXT_SPACE]
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Block mask, forward half: which block-closing events zero their block.
+//
+// Events inside a word, in position order; at one position: (1) B: the previous string ends (a virtual space that
+// closes its last block, latok.c:240-244) and the pending-start queue q resets; (2) St: q++ ; (3) S: the space closes
+// the block before it.  A closing event with q > 0 zeroes its block and consumes one start (latok.c:227-236).
+// The word is first simulated with q_in = 0; `idle` are the closings (up to and including the first B) that found
+// q == 0: a non-zero q_in = r is consumed by exactly the first r of them, so Z(r) = Z(0) | first_r(idle) and
+// q_out(r) = hasB ? q0 : q0 + max(r - popc(idle), 0).
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_fwd {
+    lk_u64 zs, zb;     // zeroing closings with q_in = 0: spaces / string-ends (bit at the *next* string's start)
+    lk_u64 idle;       // idle closings before-or-at the first B (bit at first B position = that B closing)
+    lk_u64 firstB;     // lowest B bit (0 if none)
+    int q0;            // q_out with q_in = 0
+    int n_idle;        // popc(idle)
+    int head_starts;   // starts strictly before the first closing event of the word
+    int has_closing;   // (S | B) != 0
+};
+
+LATOK_HD lk_fwd lk_forward(lk_u64 St, lk_u64 S, lk_u64 B) {
+    lk_fwd r;
+    const lk_u64 closing = S | B;
+    const lk_u64 Pf = ~closing;
+    r.firstB = B & (~B + 1ull);
+    r.has_closing = closing != 0;
+    const lk_u64 first_closing = closing & (~closing + 1ull);
+    r.head_starts = lk_popc(first_closing ? (St & (first_closing - 1ull)) : St);
+
+    // fast path: a start's carry ripples (binary add) through the non-closing positions above it and lands on the
+    // first closing.  Valid iff no two starts share a block, checked by counting (a merged ripple loses a start).
+    const lk_u64 gen = St << 1;
+    const int g63 = (int)(St >> 63);
+    const lk_u64 sum = Pf + gen;
+    const int cout = sum < Pf;
+    const lk_u64 reached = (sum ^ Pf) & closing;
+    if (lk_popc(St) == lk_popc(reached) + cout + g63) {
+        r.zb = reached & B;
+        r.zs = reached & ~B;
+        const lk_u64 below = r.firstB ? (r.firstB - 1ull) : ~0ull;
+        r.idle = ((S & ~B & below) | r.firstB) & ~reached;
+        r.q0 = cout + g63;
+    } else {
+        // exact sequential simulation (a block with >= 2 starts: latok's "spill-over" case)
+        lk_u64 zs = 0, zb = 0, idle = 0, M = St | closing;
+        int q = 0, seenB = 0;
+        while (M) {
+            const lk_u64 bit = M & (~M + 1ull);
+            M ^= bit;
+            if (B & bit) {
+                if (q > 0) zb |= bit; else if (!seenB) idle |= bit;
+                q = 0;
+                seenB = 1;
+            }
+            if (St & bit) ++q;
+            if (S & bit) {
+                if (q > 0) { zs |= bit; --q; } else if (!seenB) idle |= bit;
+            }
+        }
+        r.zs = zs; r.zb = zb; r.idle = idle; r.q0 = q;
+    }
+    r.n_idle = lk_popc(r.idle);
+    return r;
+}
+
+// q transfer function of a word / tile: f(q) = max(q + a, b).  a == LK_NEG_INF encodes "constant b" (a string start
+// inside resets the queue).  Composition (first f1 then f2) stays in the family.
+#define LK_NEG_INF (-(1 << 29))
+struct lk_qfn {
+    int a, b;
+};
+LATOK_HD lk_qfn lk_qfn_of(const lk_fwd& w) {
+    lk_qfn f;
+    f.a = w.firstB ? LK_NEG_INF : (w.q0 - w.n_idle);
+    f.b = w.q0;
+    return f;
+}
+LATOK_HD lk_qfn lk_qfn_then(lk_qfn f1, lk_qfn f2) {
+    lk_qfn f;
+    int a = f1.a + f2.a;
+    f.a = a < LK_NEG_INF ? LK_NEG_INF : a;
+    int c = f1.b + f2.a;
+    f.b = c > f2.b ? c : f2.b;
+    return f;
+}
+LATOK_HD int lk_qfn_apply(lk_qfn f, int q) {
+    int c = q + f.a;
+    return c > f.b ? c : f.b;
+}
+
+// add the closings consumed by r extra pending starts (r > 0): the first r idle closings
+LATOK_HD void lk_apply_extra(lk_fwd& w, int r) {
+    lk_u64 idle = w.idle, take = 0;
+    while (r > 0 && idle) {
+        const lk_u64 bit = idle & (~idle + 1ull);
+        idle ^= bit;
+        take |= bit;
+        --r;
+    }
+    w.zb |= take & w.firstB;
+    w.zs |= take & ~w.firstB;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Block mask, backward half: every zeroing closing at position i clears the run of non-delimiter chars below it
+// (down to, and including, a string's first char).  Done as one binary add on the bit-reversed word; the carry that
+// leaves the word at the bottom continues in the previous word.
+//   gen_top : bit 63 generator = the NEXT word's closing at its position 0 zeroes (Zall_next & 1)
+//   cin     : a fill that started in a later word arrives at position 63
+// returns the cleared positions (B positions may be included: the caller ORs B back, splits[0] = 1).
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_bwd {
+    lk_u64 xr, gr;  // reversed propagate mask / generators
+    int g, p;       // carry-out with cin = 0; word is all-propagate
+};
+LATOK_HD lk_bwd lk_backward_prepare(lk_u64 zall, lk_u64 S, lk_u64 B, int gen_top) {
+    lk_bwd r;
+    const lk_u64 G = (zall >> 1) | ((lk_u64)(gen_top & 1) << 63);
+    r.xr = lk_rev(~(S | B));
+    r.gr = lk_rev(G);
+    const lk_u64 sum = r.xr + r.gr;
+    r.g = sum < r.xr;
+    r.p = r.xr == ~0ull;
+    return r;
+}
+LATOK_HD lk_u64 lk_backward_fill(const lk_bwd& w, int cin, lk_u64 S) {
+    const lk_u64 sum = w.xr + w.gr + (lk_u64)(cin & 1);
+    return lk_rev(sum ^ w.xr) & ~S;
+}
+
+#endif

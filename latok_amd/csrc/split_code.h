@@ -1,0 +1,23 @@
+// split_code.h -- the 8-bit per-character "split code" that the fused kernel bit-slices.
+//
+// The reference derives 12 base features per character from a Unicode flag word
+// (reference latok/core/src/latok/latok.c:87-98).  Only 17 distinct feature combinations exist over all code points,
+// and the split rules (reference latok/core/default_tokenizer.py:39-102) never look at NUM except through ALPHA_NUM,
+// which leaves 16 behaviours.  They are encoded in one byte so that the planes the rules need most are single bits:
+//
+//   bit0 SPACE   bit1 SYMBOL   bit2 LOWER   bit3 UPPER   bit4 ALPHA_NUM
+//   bit5 ALPHA                      (when SYMBOL = 0; ALPHA implies ALPHA_NUM, and SYMBOL excludes both)
+//   bit5..7 = sub-type of a SYMBOL  (when SYMBOL = 1):  0 plain, 1 twitter-only (# $ ^), 3 '@' (twitter + at),
+//                                                       4 ':', 5 '/', 6 '.'
+//
+// tools/gen_unicode_tables.py emits kClassCode[] with exactly this layout; lane_math.h:lk_decode() undoes it.
+#ifndef LATOK_SPLIT_CODE_H
+#define LATOK_SPLIT_CODE_H
+
+#define LK_BIT_SPACE 0
+#define LK_BIT_SYMBOL 1
+#define LK_BIT_LOWER 2
+#define LK_BIT_UPPER 3
+#define LK_BIT_ALNUM 4
+
+#endif

@@ -1,0 +1,193 @@
+// fused_model.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// A CPU model of the HIP pipeline in latok_amd/csrc/split_kernels.hip: same tiling (4096-char tiles, 64 "lanes" of
+// one 64-bit word each), same per-lane math (it includes the product's lane_math.h and unicode_tables.inc), same
+// four stages (tile index / tiles / summary scan / fix-up), with the wavefront written as a plain loop over 64
+// lanes.  It exists to debug the *algorithm* against the reference-shaped oracle (latok_oracle.c) in a container
+// without a GPU, and doubles as the multi-core "fused" CPU number.  The product never links or loads it.
+//
+//   g++ -O2 -shared -fPIC -I../latok_amd/csrc fused_model.cpp -o libfused_model.so
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "lane_math.h"
+#include "unicode_tables.inc"
+
+namespace {
+
+constexpr int kTile = 4096;
+constexpr int kLanes = 64;
+
+struct TileSummary {
+    int a, b;          // q transfer function of the tile
+    int head_starts;   // starts before the first closing event of the tile
+    int has_closing;
+};
+
+inline uint32_t classify(uint32_t cp) {
+    uint32_t hi = cp >> LATOK_TBL_SHIFT;
+    if (hi > LATOK_TBL_STAGE1_LEN - 1) hi = LATOK_TBL_STAGE1_LEN - 1;
+    uint32_t blk = kStage1[hi];
+    return kClassCode[kStage2[(blk << LATOK_TBL_SHIFT) | (cp & ((1u << LATOK_TBL_SHIFT) - 1))]];
+}
+
+struct Model {
+    const uint32_t* cps;
+    const int64_t* row_off;
+    int64_t n_str, total, n_tiles;
+    std::vector<int64_t> tile_first;
+    std::vector<TileSummary> summ;
+    uint8_t* values;   // may be null
+    uint64_t* bits;    // may be null
+    int64_t n_fix = 0;
+
+    uint32_t code_at(int64_t p) const { return (p >= 0 && p < total) ? classify(cps[p]) : 0u; }
+
+    // stage 0: tile_first[t] = first string index s with row_off[s] >= t*kTile
+    void build_tile_index() {
+        tile_first.assign((size_t)n_tiles, n_str);
+        int64_t prev_tile = -1;
+        for (int64_t s = 0; s <= n_str; ++s) {
+            int64_t tl = row_off[s] / kTile;
+            for (int64_t w = prev_tile + 1; w <= tl && w < n_tiles; ++w) tile_first[(size_t)w] = s;
+            if (tl > prev_tile) prev_tile = tl;
+        }
+    }
+
+    void process_tile(int64_t t, int q_in, int tail_zero, bool write_summary) {
+        const int64_t t0 = t * kTile;
+        // string-start bits for chars t0 .. t0+4096+63
+        lk_u64 Bw[kLanes + 1];
+        memset(Bw, 0, sizeof(Bw));
+        for (int64_t s = tile_first[(size_t)t]; s <= n_str; ++s) {
+            int64_t rel = row_off[s] - t0;
+            if (rel >= kTile + 64) break;
+            Bw[rel >> 6] |= 1ull << (rel & 63);
+        }
+        lk_local loc[kLanes];
+        lk_fwd fw[kLanes];
+        lk_u64 Bl[kLanes];
+        for (int j = 0; j < kLanes; ++j) {
+            const int64_t base = t0 + 64 * j;
+            uint32_t d[16];
+            for (int k = 0; k < 16; ++k) {
+                uint32_t v = 0;
+                for (int b = 0; b < 4; ++b) v |= code_at(base + 4 * k + b) << (8 * b);
+                d[k] = v;
+            }
+            lk_u64 plane[8];
+            lk_bitslice64(d, plane);
+            lk_feat f = lk_decode(plane);
+            lk_halo h;
+            h.prev = code_at(base - 1);
+            h.next0 = code_at(base + 64);
+            h.next1 = code_at(base + 65);
+            Bl[j] = Bw[j];
+            loc[j] = lk_rules(f, h, Bw[j], Bw[j + 1] & 3ull);
+            fw[j] = lk_forward(loc[j].start, loc[j].S, Bw[j]);
+        }
+        // "wave" exclusive scan of the q transfer functions
+        lk_qfn acc;
+        acc.a = 0; acc.b = 0;  // identity on q >= 0
+        int head = 0, seen_closing = 0;
+        for (int j = 0; j < kLanes; ++j) {
+            const int r = lk_qfn_apply(acc, q_in);
+            if (!seen_closing) {
+                head += fw[j].has_closing ? fw[j].head_starts : lk_popc(loc[j].start);
+                seen_closing = fw[j].has_closing;
+            }
+            acc = lk_qfn_then(acc, lk_qfn_of(fw[j]));
+            if (r > 0) lk_apply_extra(fw[j], r);
+        }
+        if (write_summary) {
+            TileSummary& s = summ[(size_t)t];
+            s.a = acc.a; s.b = acc.b; s.head_starts = head; s.has_closing = seen_closing;
+        }
+        // backward fill, carry travels from lane 63 down to lane 0
+        // tail_zero < 0: provisional decision = "a start is still pending at the tile end" (its closing event,
+        // wherever it is, will zero the open block)
+        int cin = tail_zero >= 0 ? tail_zero : (lk_qfn_apply(acc, q_in) > 0);
+        for (int j = kLanes - 1; j >= 0; --j) {
+            const lk_u64 zall = fw[j].zs | fw[j].zb;
+            const int gen_top = (j < kLanes - 1) ? (int)((fw[j + 1].zs | fw[j + 1].zb) & 1ull) : 0;
+            lk_bwd bw = lk_backward_prepare(zall, loc[j].S, Bl[j], gen_top);
+            const lk_u64 cleared = lk_backward_fill(bw, cin, loc[j].S);
+            cin = bw.g | (bw.p & cin);
+            const int64_t base = t0 + 64 * j;
+            if (base >= total) continue;
+            const lk_u64 valid = (total - base >= 64) ? ~0ull : ((1ull << (total - base)) - 1ull);
+            const lk_u64 keep = ~cleared;
+            const lk_u64 out = (((loc[j].raw & keep) | loc[j].sym | Bl[j])) & valid;
+            if (bits) bits[base >> 6] = out;
+            if (values) {
+                for (int i = 0; i < 64 && base + i < total; ++i) {
+                    const lk_u64 m = 1ull << i;
+                    int v = (int)!!(loc[j].t_space & m) + !!(loc[j].t_sym & m) + !!(loc[j].t_prevsym & m) +
+                            !!(loc[j].t_camel_next & m) + !!(loc[j].t_camel_prev & m);
+                    v = (keep & m) ? v : 0;
+                    v += !!(loc[j].sym & m);
+                    if (Bl[j] & m) v = 1;
+                    values[base + i] = (uint8_t)v;
+                }
+            }
+        }
+    }
+
+    void run() {
+        if (n_tiles == 0) return;
+        build_tile_index();
+        summ.resize((size_t)n_tiles);
+        // stage 1: every tile with q_in = 0 and the provisional tail decision (pending start at the tile end)
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            process_tile(t, 0, -1, true);
+        }
+        // stage 2: forward scan of q, backward scan of "starts before the next closing"
+        // (q is 64-bit here: a tile only ever sees min(q, 2^20), it has at most 4096 closings to feed)
+        auto apply64 = [](const TileSummary& f, long long q) -> long long {
+            if (f.a <= LK_NEG_INF / 2) return f.b;
+            return std::max<long long>(q + f.a, f.b);
+        };
+        std::vector<long long> q_in((size_t)n_tiles);
+        std::vector<int> tz((size_t)n_tiles);
+        long long q = 0;
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            q_in[(size_t)t] = q;
+            q = apply64(summ[(size_t)t], q);
+        }
+        long long H = 0;  // starts after the end of tile t before the first closing event
+        for (int64_t t = n_tiles - 1; t >= 0; --t) {
+            const long long q_end = apply64(summ[(size_t)t], q_in[(size_t)t]);
+            tz[(size_t)t] = (q_end + H) > 0;
+            H = summ[(size_t)t].head_starts + (summ[(size_t)t].has_closing ? 0 : H);
+        }
+        // stage 3: recompute the tiles whose assumptions were wrong
+        for (int64_t t = 0; t < n_tiles; ++t) {
+            const int tz0 = summ[(size_t)t].b > 0;
+            if (q_in[(size_t)t] != 0 || tz[(size_t)t] != tz0) {
+                process_tile(t, (int)std::min<long long>(q_in[(size_t)t], 1 << 20), tz[(size_t)t], false);
+                ++n_fix;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int fused_split_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, uint8_t* values_out,
+                                 uint64_t* bits_out, int64_t* n_fix_out) {
+    if (n_str < 0) return -1;
+    Model m;
+    m.cps = cps;
+    m.row_off = row_off;
+    m.n_str = n_str;
+    m.total = n_str > 0 ? row_off[n_str] : 0;
+    m.n_tiles = (m.total + kTile - 1) / kTile;
+    m.values = values_out;
+    m.bits = bits_out;
+    m.run();
+    if (n_fix_out) *n_fix_out = m.n_fix;
+    return 0;
+}

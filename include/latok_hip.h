@@ -1,0 +1,128 @@
+/* latok_hip.h -- C ABI of liblatok_hip.so: latok's character-feature-matrix + split-mask path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference binds this path through the CPython extension module `latok.latok`
+ * (reference setup.py:10-18, method table latok/core/src/latok/latok.c:373-378) whose three functions are called by
+ * latok/core/default_tokenizer.py:36,123-129,146 and latok/core/latok_utils.py:7,15,24.  Each entry point below names
+ * the reference interface it replaces.  Plain pointers and sizes only: no Python.h, no NumPy C-API, no torch types.
+ *
+ * Conventions
+ *   - every function returns LATOK_OK (0) or a negative LATOK_ERR_*; latok_last_error() gives the message
+ *     (the reference raises ValueError for bad arguments: latok.c:40-50,151-171,292-312; the Python mirror maps
+ *     LATOK_ERR_INVALID -> ValueError and everything else -> RuntimeError).
+ *   - the caller owns every buffer (the reference returns freshly allocated NumPy arrays: latok.c:59,174,357).
+ *   - `flags & LATOK_DEVICE_PTRS`: all data pointers are device pointers, the call is asynchronous on `stream`
+ *     (a hipStream_t, NULL = the library's own stream) and returns as soon as the work is enqueued.  Otherwise they
+ *     are host pointers: the library stages through its own device buffers and the call is synchronous.
+ *   - a batch is CSR: `cps` = packed UTF-32 code points of all strings, `row_off[n_str + 1]` = start of each string
+ *     (row_off[0] == 0, non-decreasing).  Device `cps` pointers must be 16-byte aligned.
+ *   - `total_chars` = row_off[n_str]; the caller normally knows it.  Pass -1 to let the library read it (in device
+ *     mode that costs one blocking 8-byte device->host copy).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
+ */
+#ifndef LATOK_HIP_H
+#define LATOK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LATOK_OK 0
+#define LATOK_ERR_INVALID (-1)  /* bad argument / shape (reference: ValueError) */
+#define LATOK_ERR_HIP (-2)      /* HIP runtime error, or no device */
+#define LATOK_ERR_NOT_INIT (-3) /* latok_init() has not been called */
+#define LATOK_ERR_NOMEM (-4)
+
+#define LATOK_DEVICE_PTRS 1
+
+#define LATOK_FEATURE_COUNT 25 /* reference latok/core/offsets.py:49 */
+#define LATOK_TILE_CHARS 4096  /* chars per wavefront tile (64 lanes x 64-bit words) */
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------------ */
+int latok_device_count(void);          /* number of HIP devices, 0 when none (never fails) */
+int latok_init(int device);            /* bind this process to `device`, upload the Unicode tables, create the stream */
+int latok_shutdown(void);
+const char* latok_last_error(void);    /* message of the last failure on this thread */
+const char* latok_version(void);
+
+/* Grow the library-owned workspace (tile index, tile summaries, host-mode staging) for batches of up to
+ * `max_chars` code points / `max_strings` strings, so that later calls allocate nothing. */
+int latok_reserve(int64_t max_chars, int64_t max_strings);
+
+/* ---- the fused hot path ------------------------------------------------------------------------------------------
+ * Replaces, for a whole batch at once, the reference call chain of default_tokenizer.py:146-148:
+ *   _gen_parse_matrix (latok.c:31-138) -> gen_split_mask (default_tokenizer.py:113-134: 3x _combine_matrix_rows
+ *   latok.c:275-370 + gen_block_mask latok.c:140-258) -> nonzero-ness of the result.
+ * mask_bits_out: uint64[ceil(total_chars / 64)], bit (i & 63) of word (i >> 6) = 1 iff packed char i is a token
+ * boundary (splits[i] != 0).  Every string's first char is a boundary (default_tokenizer.py:132); empty strings
+ * contribute nothing (the reference raises IndexError for '' -- documented deviation of batch mode). */
+int latok_split_mask_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                           uint64_t* mask_bits_out, int flags, void* stream);
+
+/* Same pipeline, but writes the reference's split VALUES (0..5, the int8 vector returned by gen_split_mask,
+ * default_tokenizer.py:121-134) as uint8[total_chars].  Parity/debug form: 1 byte per char instead of 1 bit. */
+int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                             uint8_t* values_out, int flags, void* stream);
+
+/* Boundary offsets (replaces np.nonzero(splits)[0], default_tokenizer.py:148) for every string of the batch:
+ * counts_out[n_str] = number of boundaries of each string; offsets_out[0..sum(counts)) = the offsets of string 0,
+ * then string 1, ... each relative to its own string start (int64, ascending, first one always 0).
+ * offsets_cap = capacity of offsets_out in elements; *n_offsets_out = total number written (host pointer, always).
+ * Returns LATOK_ERR_INVALID if offsets_cap is too small (n_offsets_out still holds the needed size).
+ * Synchronous in both pointer modes (the total is returned to the host). */
+int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                              int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
+                              int flags, void* stream);
+
+/* ---- the reference's three native functions, one string at a time (compat surface) ---------------------------- */
+/* _gen_parse_matrix (latok.c:31-138): n code points -> int8[n][25], C-contiguous. */
+int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream);
+
+/* _combine_matrix_rows (latok.c:275-370): m is a 2-D byte matrix addressed m[r*stride_r + c*stride_c] with `rows`
+ * rows and `cols` columns; idx is int8, idx_ndim 2 (irows x icols, "sum of products", -1 skipped) or 1 (icols row
+ * ids, "sum").  out = int8[cols].  uint8 wrap-around arithmetic like the reference.  The matrix is copied densely
+ * (rows x cols) before upload when given as host pointers; in device mode strides are honoured as given. */
+int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64_t stride_r, int64_t stride_c,
+                              const int8_t* idx, int idx_ndim, int irows, int icols, int8_t* out, int flags,
+                              void* stream);
+
+/* _gen_block_mask (latok.c:140-258): a1 ("starts") and a2 ("spaces") are int8[n], non-zero = set. out = int8[n]. */
+int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out, int flags, void* stream);
+
+/* ---- device memory / stream helpers (so hosts need no other GPU runtime binding) ------------------------------ */
+void* latok_dev_alloc(size_t bytes);   /* NULL on failure */
+int latok_dev_free(void* p);
+int latok_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int latok_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int latok_memset_dev(void* dst_dev, int value, size_t bytes);
+int latok_sync(void);                  /* wait for the library stream */
+int latok_device_props(int* n_cu, int64_t* hbm_bytes, char* name_out, int name_cap);
+
+/* ---- synthetic corpora (counter-based, identical on host and device) ------------------------------ */
+#define LATOK_CORPUS_ASCII 0
+#define LATOK_CORPUS_UNICODE 1
+/* row_off_out[n_str + 1] (host): lengths uniform in [len_lo, len_hi] for string ids sid0 .. sid0+n_str-1 */
+int latok_corpus_offsets(uint64_t seed, uint64_t sid0, int64_t n_str, int64_t len_lo, int64_t len_hi,
+                         int64_t* row_off_out);
+/* fill code points; host form (pure CPU, no device needed) and device form (one thread per string) */
+int latok_corpus_fill_host(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
+                           uint32_t* cps_out);
+int latok_corpus_fill_device(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off_dev,
+                             uint32_t* cps_out_dev, void* stream);
+/* total UTF-8 encoded size of n code points (device pointers when LATOK_DEVICE_PTRS); result to a host int64 */
+int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int flags);
+
+/* ---- measurement ----------------------------------------------------------------------------------------------- */
+/* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
+ * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
+ * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (split_tiles), measured with its own
+ * event pair per launch; n_fix_tiles_out = tiles re-done by the fix-up stage in the last pass.  Any may be NULL. */
+int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                           uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
+                           int64_t* n_fix_tiles_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""Whole-batch entry points over the fused HIP kernel (additive to the reference surface).
+
+A batch is CSR: ``cps`` = packed UTF-32 code points of all strings, ``row_off[n+1]`` = start of each string.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack(texts):
+    """list[str] -> (cps uint32[total], row_off int64[n+1])."""
+    lens = np.fromiter((len(t) for t in texts), dtype=np.int64, count=len(texts))
+    row_off = np.zeros(len(texts) + 1, np.int64)
+    np.cumsum(lens, out=row_off[1:])
+    blob = "".join(texts).encode("utf-32-le", "surrogatepass")
+    cps = np.frombuffer(blob, dtype="<u4").astype(np.uint32, copy=False)
+    return np.ascontiguousarray(cps), row_off
+
+
+def _csr(cps, row_off):
+    cps = np.ascontiguousarray(cps, dtype=np.uint32)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+    if row_off.ndim != 1 or row_off.size < 1:
+        raise ValueError("row_off must be a 1-D array of n_str + 1 offsets")
+    if cps.ndim != 1 or (row_off.size > 1 and cps.size < int(row_off[-1])):
+        raise ValueError("cps is shorter than row_off[-1]")
+    return cps, row_off
+
+
+def split_mask_batch(cps, row_off) -> np.ndarray:
+    """Boundary bitmask uint64[ceil(total/64)]: bit i = packed char i starts a token."""
+    cps, row_off = _csr(cps, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    bits = np.zeros((total + 63) // 64, np.uint64)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_mask_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(bits), 0, None))
+    return bits
+
+
+def split_values_batch(cps, row_off) -> np.ndarray:
+    """The reference's split values (0..5) for every packed char, uint8[total]."""
+    cps, row_off = _csr(cps, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    vals = np.zeros(total, np.uint8)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_values_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(vals), 0, None))
+    return vals
+
+
+def split_offsets_csr(cps, row_off):
+    """(counts int64[n], offsets int64[sum(counts)]): per-string boundary offsets, concatenated."""
+    cps, row_off = _csr(cps, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    offsets = np.empty(max(total, 1), np.int64)  # a string has at most len boundaries
+    n_off = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_offsets_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(offsets),
+                                             offsets.size, C.byref(n_off), 0, None))
+    return counts, offsets[:n_off.value].copy()
+
+
+def split_offsets_batch(texts):
+    """list[str] -> list of int64 arrays = np.nonzero(split mask)[0] of every string ('' -> empty array)."""
+    if len(texts) == 0:
+        return []
+    cps, row_off = pack(texts)
+    counts, offsets = split_offsets_csr(cps, row_off)
+    return np.split(offsets, np.cumsum(counts)[:-1])
+
+
+def spans_from_offsets(text, nz):
+    """Token strings of one text from its boundary offsets, as the reference's loop builds them
+    (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""
+    toks = []
+    if len(nz) > 0:
+        bounds = [int(x) for x in nz]
+        a, end = bounds[0], 0
+        for end in bounds[1:]:
+            tok = text[a:end].strip()
+            if tok:
+                toks.append(tok)
+            a = end
+        tok = text[end:].strip()
+        if tok:
+            toks.append(tok)
+    return toks
+
+
+def tokenize_batch(texts):
+    """list[str] -> list[list[str]], each as list(tokenize(text)) of the reference (default_tokenizer.py:137-160);
+    an empty string yields [] instead of the reference's IndexError."""
+    return [spans_from_offsets(t, nz) for t, nz in zip(texts, split_offsets_batch(texts))]

@@ -1,0 +1,103 @@
+"""Default LaTok tokenizer -- mirror of reference latok/core/default_tokenizer.py (same public names).
+
+``tokenize`` / ``featurize`` get their boundary offsets from the fused HIP kernel (one string = a batch of one);
+``gen_split_mask`` stays the generic, user-editable recipe over the three native functions exactly as in the reference
+(default_tokenizer.py:113-134), so customised combo matrices keep working through the compat kernels.
+"""
+import numpy as np
+
+from . import offsets as oft
+from .latok_utils import LaToken, build_combo_matrix, gen_block_mask
+from ..latok import _combine_matrix_rows, _gen_parse_matrix
+from .. import batch as _batch
+
+
+def build_split_combo_matrix():
+    """Split on whitespace, on a symbol, after a symbol, and at camelCase humps (an upper-case letter next to a
+    lower-case one, either side).  Reference default_tokenizer.py:39-55."""
+    return build_combo_matrix([
+        [oft.SPACE_IDX],
+        [oft.SYMBOL_IDX],
+        [oft.PREV_SYMBOL_IDX],
+        [oft.UPPER_IDX, oft.NEXT_LOWER_IDX],
+        [oft.UPPER_IDX, oft.PREV_LOWER_IDX],
+    ])
+
+
+def build_mask_combo_matrix():
+    """Starts of spans that must not be split: twitter specials (``#tag``, ``@user``, ``.@user`` after a space),
+    e-mail addresses (``@`` between alphanumerics) and URLs (``:`` after a letter, before ``//``).
+    Reference default_tokenizer.py:58-91."""
+    return build_combo_matrix([
+        [oft.TWITTER_IDX, oft.PREV_SPACE_IDX, oft.NEXT_ALPHA_IDX],
+        [oft.CHAR_PERIOD_IDX, oft.PREV_SPACE_IDX, oft.NEXT_AT_IDX, oft.AFTER_NEXT_ALPHA_IDX],
+        [oft.CHAR_AT_IDX, oft.PREV_ALPHA_NUM_IDX, oft.NEXT_ALPHA_NUM_IDX],
+        [oft.CHAR_COLON_IDX, oft.NEXT_SLASH_IDX, oft.AFTER_NEXT_SLASH_IDX, oft.PREV_ALPHA_IDX],
+    ])
+
+
+def build_symbol_combo_matrix():
+    """A symbol followed by whitespace (a symbol that ends a token).  Reference default_tokenizer.py:94-102."""
+    return build_combo_matrix([
+        [oft.SYMBOL_IDX, oft.NEXT_SPACE_IDX],
+    ])
+
+
+# rule tables used by gen_split_mask (reference default_tokenizer.py:108-110)
+C_SPLIT = build_split_combo_matrix()
+C_MASK = build_mask_combo_matrix()
+C_SYM = build_symbol_combo_matrix()
+
+
+def gen_split_mask(m: np.ndarray):
+    """Split-mask vector of a feature matrix: non-zero entries mark the characters at which to split
+    (reference default_tokenizer.py:113-134)."""
+    mt = m.T  # features as rows
+    splits = _combine_matrix_rows(mt, C_SPLIT) * gen_block_mask(_combine_matrix_rows(mt, C_MASK), mt[oft.SPACE_IDX])
+    splits += _combine_matrix_rows(mt, C_SYM)
+    splits[0] = 1  # start of string is always a boundary; IndexError on an empty matrix, like the reference
+    return splits
+
+
+def _boundaries(text: str) -> np.ndarray:
+    """np.nonzero(gen_split_mask(_gen_parse_matrix(text)))[0] (reference default_tokenizer.py:146-148), computed by
+    the fused kernel."""
+    if len(text) == 0:
+        # the reference fails at ``splits[0] = 1`` on an empty array (default_tokenizer.py:132)
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    return _batch.split_offsets_batch([text])[0]
+
+
+def _spans(text: str, non_zero):
+    """(start, end) pairs exactly as the reference's loop walks them (default_tokenizer.py:149-158)."""
+    str_idx, end_idx = int(non_zero[0]), 0
+    for end_idx in non_zero[1:]:
+        end_idx = int(end_idx)
+        yield str_idx, end_idx
+        str_idx = end_idx
+    yield end_idx, len(text)
+
+
+def tokenize(text: str):
+    """Yield the tokens of ``text`` (reference default_tokenizer.py:137-160)."""
+    non_zero = _boundaries(text)
+    if len(non_zero) > 0:
+        for a, b in _spans(text, non_zero):
+            token = text[a:b].strip()
+            if token:
+                yield token
+    else:
+        yield ''
+
+
+def featurize(text: str):
+    """Yield the tokens of ``text`` as ``LaToken`` with their summed feature vectors
+    (reference default_tokenizer.py:163-191).  The reference indexes matrix rows with ``np.arange(..., dtype=np.int8)``
+    and therefore breaks past character 127; rows are summed here for any position."""
+    non_zero = _boundaries(text)
+    m = _gen_parse_matrix(text)
+    if len(non_zero) > 0:
+        for a, b in _spans(text, non_zero):
+            token = text[a:b].strip()
+            if token:
+                yield LaToken(token, a, b, m[a:b].sum(axis=0, dtype=np.int64).astype(np.int8))

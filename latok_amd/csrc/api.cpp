@@ -1,0 +1,537 @@
+// api.cpp -- host side of liblatok_hip.so: the C ABI declared in include/latok_hip.h.
+//
+// Thin by design: argument checks, workspace management, H2D/D2H staging for host-pointer calls, and the launch
+// sequence of the four-stage pipeline (tile index -> tiles -> summary scan -> fix-up).  No compute happens on the
+// host and there is no CPU fallback: without a HIP device every compute entry point fails.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/latok_hip.h"
+#include "corpus_gen.h"
+#include "kernels.h"
+#include "unicode_tables.inc"
+
+static_assert(LATOK_TBL_SHIFT == latok::kTblShift, "table shift");
+static_assert(LATOK_TBL_STAGE1_LEN == latok::kStage1Len, "stage-1 length");
+static_assert(LATOK_TBL_NBLOCKS * (1 << LATOK_TBL_SHIFT) == latok::kStage2Len, "stage-2 length");
+static_assert(LATOK_TILE_CHARS == latok::kTile, "tile size");
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail(LATOK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return LATOK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(LATOK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return LATOK_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Ctx {
+    bool inited = false;
+    int device = -1, n_cu = 0;
+    hipStream_t stream = nullptr;
+    // tables
+    DevBuf t1, t2code, t2cls, cw;
+    // pipeline workspace (sized by tiles)
+    DevBuf tile_first, summ, tile_q, fix_list, fix_q, fix_tz, fix_count;
+    // staging for host-pointer calls and for the offsets API
+    DevBuf h_cps, h_row, h_out, bits, counts, bases, scalar, h_aux;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+} g;
+
+int ensure_workspace(int64_t n_tiles) {
+    const size_t t = (size_t)(n_tiles > 0 ? n_tiles : 1);
+    int rc;
+    if ((rc = g.tile_first.ensure(t * 8))) return rc;
+    if ((rc = g.summ.ensure(t * 16))) return rc;
+    if ((rc = g.tile_q.ensure(t * 4))) return rc;
+    if ((rc = g.fix_list.ensure(t * 8))) return rc;
+    if ((rc = g.fix_q.ensure(t * 4))) return rc;
+    if ((rc = g.fix_tz.ensure(t * 4))) return rc;
+    if ((rc = g.fix_count.ensure(8))) return rc;
+    return LATOK_OK;
+}
+
+int need_init() {
+    if (!g.inited) return fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called (no CPU fallback exists)");
+    return LATOK_OK;
+}
+
+// enqueue the four-stage pipeline on device-resident data
+int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
+                 uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
+                 hipEvent_t tiles_end = nullptr) {
+    if (total <= 0 || n_str <= 0) return LATOK_OK;
+    const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
+    int rc = ensure_workspace(n_tiles);
+    if (rc) return rc;
+    latok::SplitParams P;
+    P.cps = d_cps;
+    P.row_off = d_row;
+    P.n_str = n_str;
+    P.total = total;
+    P.n_tiles = n_tiles;
+    P.tile_first = (const int64_t*)g.tile_first.p;
+    P.t1 = (const uint8_t*)g.t1.p;
+    P.t2 = (const uint8_t*)g.t2code.p;
+    P.bits_out = d_bits;
+    P.values_out = d_values;
+    P.summ = (int4*)g.summ.p;
+    P.tile_q = (int*)g.tile_q.p;
+    P.fix_list = (int64_t*)g.fix_list.p;
+    P.fix_q = (int*)g.fix_q.p;
+    P.fix_tz = (int*)g.fix_tz.p;
+    P.fix_count = (int64_t*)g.fix_count.p;
+    HIP_TRY(latok::launch_tile_index(d_row, n_str, n_tiles, (int64_t*)g.tile_first.p, P.fix_count, st));
+    if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
+    HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
+    if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));
+    HIP_TRY(latok::launch_scan_summaries(P, st));
+    HIP_TRY(latok::launch_fix_tiles(P, mode, g.n_cu, st));
+    return LATOK_OK;
+}
+
+int check_csr_host(const int64_t* row_off, int64_t n_str, int64_t* total_io) {
+    if (n_str < 0) return fail(LATOK_ERR_INVALID, "n_str must be >= 0");
+    if (n_str == 0) { *total_io = 0; return LATOK_OK; }
+    if (!row_off) return fail(LATOK_ERR_INVALID, "row_off is NULL");
+    if (row_off[0] != 0) return fail(LATOK_ERR_INVALID, "row_off[0] must be 0");
+    for (int64_t s = 0; s < n_str; ++s)
+        if (row_off[s + 1] < row_off[s]) return fail(LATOK_ERR_INVALID, "row_off must be non-decreasing");
+    if (*total_io >= 0 && *total_io != row_off[n_str])
+        return fail(LATOK_ERR_INVALID, "total_chars does not match row_off[n_str]");
+    *total_io = row_off[n_str];
+    return LATOK_OK;
+}
+
+int resolve_total_device(const int64_t* d_row, int64_t n_str, int64_t* total_io, hipStream_t st) {
+    if (n_str < 0) return fail(LATOK_ERR_INVALID, "n_str must be >= 0");
+    if (n_str == 0) { *total_io = 0; return LATOK_OK; }
+    if (*total_io < 0) {
+        HIP_TRY(hipMemcpyAsync(total_io, d_row + n_str, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LATOK_OK;
+}
+
+int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, void* out, int mode,
+                 int flags, void* stream) {
+    int rc = need_init();
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    if (flags & LATOK_DEVICE_PTRS) {
+        if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
+        if (total == 0) return LATOK_OK;
+        if (!cps || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+        if (((uintptr_t)cps & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+        return run_pipeline(cps, row_off, n_str, total, mode == latok::kModeBits ? (uint64_t*)out : nullptr,
+                            mode == latok::kModeValues ? (uint8_t*)out : nullptr, mode, st);
+    }
+    if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
+    if (total == 0) return LATOK_OK;
+    if (!cps || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    const size_t out_bytes = mode == latok::kModeBits ? (size_t)((total + 63) / 64) * 8 : (size_t)total;
+    if ((rc = g.h_cps.ensure((size_t)total * 4))) return rc;
+    if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
+    if ((rc = g.h_out.ensure(out_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g.h_row.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+    rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.h_row.p, n_str, total,
+                      mode == latok::kModeBits ? (uint64_t*)g.h_out.p : nullptr,
+                      mode == latok::kModeValues ? (uint8_t*)g.h_out.p : nullptr, mode, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, g.h_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int latok_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* latok_last_error(void) { return g_err.c_str(); }
+const char* latok_version(void) { return "latok_hip 0.1 (gfx950)"; }
+
+int latok_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.inited) {
+        if (g.device == device) return LATOK_OK;
+        return fail(LATOK_ERR_INVALID, "already initialised on device %d (one process per GPU)", g.device);
+    }
+    int n = latok_device_count();
+    if (n <= 0) return fail(LATOK_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(LATOK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    g.n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
+
+    // tables: stage-1 (padded), stage-2 as split codes (fused path) and as class ids + class words (parse matrix)
+    std::vector<uint8_t> t1(latok::kStage1Pad, kStage1[LATOK_TBL_STAGE1_LEN - 1]);
+    memcpy(t1.data(), kStage1, LATOK_TBL_STAGE1_LEN);
+    std::vector<uint8_t> t2code(latok::kStage2Len);
+    for (int i = 0; i < latok::kStage2Len; ++i) t2code[i] = kClassCode[kStage2[i]];
+    int rc;
+    if ((rc = g.t1.ensure(t1.size()))) return rc;
+    if ((rc = g.t2code.ensure(t2code.size()))) return rc;
+    if ((rc = g.t2cls.ensure(sizeof(kStage2)))) return rc;
+    if ((rc = g.cw.ensure(sizeof(kClassWord)))) return rc;
+    if ((rc = g.scalar.ensure(64))) return rc;
+    HIP_TRY(hipMemcpy(g.t1.p, t1.data(), t1.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.t2code.p, t2code.data(), t2code.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.t2cls.p, kStage2, sizeof(kStage2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g.cw.p, kClassWord, sizeof(kClassWord), hipMemcpyHostToDevice));
+    g.device = device;
+    g.inited = true;
+    return LATOK_OK;
+}
+
+int latok_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.inited) return LATOK_OK;
+    (void)hipStreamSynchronize(g.stream);
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.tile_first, &g.summ, &g.tile_q, &g.fix_list, &g.fix_q,
+                      &g.fix_tz, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.counts, &g.bases, &g.scalar,
+                      &g.h_aux})
+        b->release();
+    for (auto& e : g.ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.inited = false;
+    g.device = -1;
+    return LATOK_OK;
+}
+
+int latok_reserve(int64_t max_chars, int64_t max_strings) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (max_chars < 0 || max_strings < 0) return fail(LATOK_ERR_INVALID, "negative size");
+    return ensure_workspace((max_chars + latok::kTile - 1) / latok::kTile);
+}
+
+int latok_split_mask_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                           uint64_t* mask_bits_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return split_common(cps, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
+}
+
+int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                             uint8_t* values_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return split_common(cps, row_off, n_str, total_chars, values_out, latok::kModeValues, flags, stream);
+}
+
+int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+                              int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
+                              int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (!n_offsets_out) return fail(LATOK_ERR_INVALID, "n_offsets_out is NULL");
+    *n_offsets_out = 0;
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    const uint32_t* d_cps = cps;
+    const int64_t* d_row = row_off;
+    if (dev) {
+        if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
+        if (total > 0 && ((uintptr_t)cps & 15) != 0)
+            return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    } else {
+        if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
+    }
+    if (n_str == 0) return LATOK_OK;
+    if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
+    if (!dev) {
+        if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
+        if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
+        if (total > 0) HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.h_row.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+        d_cps = (const uint32_t*)g.h_cps.p;
+        d_row = (const int64_t*)g.h_row.p;
+    }
+    const size_t words = (size_t)((total + 63) / 64);
+    if ((rc = g.bits.ensure(words * 8 + 8))) return rc;
+    if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
+    if ((rc = g.bases.ensure((size_t)n_str * 8))) return rc;
+    if ((rc = run_pipeline(d_cps, d_row, n_str, total, (uint64_t*)g.bits.p, nullptr, latok::kModeBits, st))) return rc;
+    int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
+    HIP_TRY(latok::launch_count_boundaries((const uint64_t*)g.bits.p, d_row, n_str, d_counts, st));
+    HIP_TRY(latok::launch_exclusive_scan(d_counts, n_str, (int64_t*)g.bases.p, (int64_t*)g.scalar.p, st));
+    int64_t n_off = 0;
+    HIP_TRY(hipMemcpyAsync(&n_off, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_offsets_out = n_off;
+    if (!dev) HIP_TRY(hipMemcpy(counts_out, g.counts.p, (size_t)n_str * 8, hipMemcpyDeviceToHost));
+    if (n_off > offsets_cap) return fail(LATOK_ERR_INVALID, "offsets_cap too small: need %lld", (long long)n_off);
+    if (n_off == 0) return LATOK_OK;
+    if (!offsets_out) return fail(LATOK_ERR_INVALID, "offsets_out is NULL");
+    int64_t* d_off = offsets_out;
+    if (!dev) {
+        if ((rc = g.h_out.ensure((size_t)n_off * 8))) return rc;
+        d_off = (int64_t*)g.h_out.p;
+    }
+    HIP_TRY(latok::launch_write_offsets((const uint64_t*)g.bits.p, d_row, n_str, (const int64_t*)g.bases.p, d_off, st));
+    if (!dev) HIP_TRY(hipMemcpyAsync(offsets_out, d_off, (size_t)n_off * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
+    if (n == 0) return LATOK_OK;
+    if (!cps || !matrix_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    const uint8_t* t1 = (const uint8_t*)g.t1.p;
+    const uint8_t* t2 = (const uint8_t*)g.t2cls.p;
+    const uint16_t* cw = (const uint16_t*)g.cw.p;
+    if (flags & LATOK_DEVICE_PTRS) {
+        HIP_TRY(latok::launch_parse_matrix(cps, n, t1, t2, cw, matrix_out, st));
+        return LATOK_OK;
+    }
+    if ((rc = g.h_cps.ensure((size_t)n * 4))) return rc;
+    if ((rc = g.h_out.ensure((size_t)n * LATOK_FEATURE_COUNT))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(latok::launch_parse_matrix((const uint32_t*)g.h_cps.p, n, t1, t2, cw, (int8_t*)g.h_out.p, st));
+    HIP_TRY(hipMemcpyAsync(matrix_out, g.h_out.p, (size_t)n * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64_t stride_r, int64_t stride_c,
+                              const int8_t* idx, int idx_ndim, int irows, int icols, int8_t* out, int flags,
+                              void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (idx_ndim != 1 && idx_ndim != 2) return fail(LATOK_ERR_INVALID, "must specify 2d numpy array args");
+    if (rows < 0 || cols < 0 || irows < 0 || icols < 0) return fail(LATOK_ERR_INVALID, "negative shape");
+    if (cols == 0) return LATOK_OK;
+    if (!m || !idx || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    const int n_idx = idx_ndim == 2 ? irows * icols : icols;
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    if (flags & LATOK_DEVICE_PTRS) {
+        HIP_TRY(latok::launch_combine_rows((const uint8_t*)m, stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out, st));
+        return LATOK_OK;
+    }
+    // host: gather the (possibly strided) matrix into a dense rows x cols copy, upload, run, download
+    std::vector<int8_t> dense((size_t)rows * (size_t)cols);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) dense[(size_t)(r * cols + c)] = m[r * stride_r + c * stride_c];
+    // the reference does not bounds-check idx (latok.c:324-327); we refuse out-of-range rows instead of reading wild
+    for (int i = 0; i < n_idx; ++i) {
+        const uint8_t r = (uint8_t)idx[i];
+        if (r != 255 && (int64_t)r >= rows) return fail(LATOK_ERR_INVALID, "idx value %d out of range for %lld rows", (int)r, (long long)rows);
+    }
+    if ((rc = g.h_cps.ensure(dense.size() + 16))) return rc;
+    if ((rc = g.h_aux.ensure((size_t)n_idx + 16))) return rc;
+    if ((rc = g.h_out.ensure((size_t)cols))) return rc;
+    if (!dense.empty()) HIP_TRY(hipMemcpyAsync(g.h_cps.p, dense.data(), dense.size(), hipMemcpyHostToDevice, st));
+    if (n_idx) HIP_TRY(hipMemcpyAsync(g.h_aux.p, idx, (size_t)n_idx, hipMemcpyHostToDevice, st));
+    HIP_TRY(latok::launch_combine_rows((const uint8_t*)g.h_cps.p, cols, 1, cols, (const int8_t*)g.h_aux.p, idx_ndim,
+                                       irows, icols, (int8_t*)g.h_out.p, st));
+    HIP_TRY(hipMemcpyAsync(out, g.h_out.p, (size_t)cols, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)a1; (void)a2; (void)n; (void)out; (void)flags; (void)stream;
+    int rc = need_init();
+    if (rc) return rc;
+    return fail(LATOK_ERR_INVALID, "latok_block_mask: not implemented yet");
+}
+
+void* latok_dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!g.inited) { fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called"); return nullptr; }
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { fail(LATOK_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int latok_dev_free(void* p) {
+    if (p) HIP_TRY(hipFree(p));
+    return LATOK_OK;
+}
+int latok_memcpy_h2d(void* d, const void* s, size_t n) {
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return LATOK_OK;
+}
+int latok_memcpy_d2h(void* d, const void* s, size_t n) {
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return LATOK_OK;
+}
+int latok_memset_dev(void* d, int v, size_t n) {
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(d, v, n, g.stream));
+    return LATOK_OK;
+}
+int latok_sync(void) {
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    return LATOK_OK;
+}
+int latok_device_props(int* n_cu, int64_t* hbm_bytes, char* name_out, int name_cap) {
+    int rc = need_init();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g.device));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (name_out && name_cap > 0) snprintf(name_out, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    return LATOK_OK;
+}
+
+int latok_corpus_offsets(uint64_t seed, uint64_t sid0, int64_t n_str, int64_t len_lo, int64_t len_hi,
+                         int64_t* row_off_out) {
+    if (n_str < 0 || len_lo < 0 || len_hi < len_lo || !row_off_out) return fail(LATOK_ERR_INVALID, "bad corpus shape");
+    int64_t acc = 0;
+    row_off_out[0] = 0;
+    for (int64_t s = 0; s < n_str; ++s) {
+        acc += latok_corpus_length(seed, sid0 + (uint64_t)s, len_lo, len_hi);
+        row_off_out[s + 1] = acc;
+    }
+    return LATOK_OK;
+}
+int latok_corpus_fill_host(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
+                           uint32_t* cps_out) {
+    if (n_str < 0 || !row_off || (!cps_out && n_str > 0 && row_off[n_str] > 0)) return fail(LATOK_ERR_INVALID, "bad corpus args");
+    for (int64_t s = 0; s < n_str; ++s)
+        latok_corpus_string(seed, model, sid0 + (uint64_t)s, cps_out + row_off[s], row_off[s + 1] - row_off[s]);
+    return LATOK_OK;
+}
+int latok_corpus_fill_device(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off_dev,
+                             uint32_t* cps_out_dev, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(latok::launch_corpus_fill(seed, model, sid0, n_str, row_off_dev, cps_out_dev,
+                                      stream ? (hipStream_t)stream : g.stream));
+    return LATOK_OK;
+}
+int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int flags) {
+    if (!bytes_out || n < 0) return fail(LATOK_ERR_INVALID, "bad args");
+    if (!(flags & LATOK_DEVICE_PTRS)) {
+        int64_t t = 0;
+        for (int64_t i = 0; i < n; ++i) t += latok_utf8_len(cps[i]);
+        *bytes_out = t;
+        return LATOK_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    HIP_TRY(latok::launch_utf8_bytes(cps, n, (unsigned long long*)g.scalar.p, g.stream));
+    unsigned long long t = 0;
+    HIP_TRY(hipMemcpyAsync(&t, g.scalar.p, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    *bytes_out = (int64_t)t;
+    return LATOK_OK;
+}
+
+int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total,
+                           uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
+                           int64_t* n_fix_tiles_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (iters <= 0 || warmup < 0) return fail(LATOK_ERR_INVALID, "iters must be > 0");
+    if (((uintptr_t)cps_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    hipStream_t st = g.stream;
+    if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+    // (1) whole pipeline, `iters` passes between one pair of events on the launch stream
+    HIP_TRY(hipEventRecord(g.ev[0], st));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+    HIP_TRY(hipEventRecord(g.ev[1], st));
+    HIP_TRY(hipEventSynchronize(g.ev[1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
+    if (ms_total_out) *ms_total_out = ms;
+    // (2) the dominant kernel alone: its own event pair around every launch (separate passes, not part of (1))
+    if (ms_tiles_out) {
+        float acc = 0.f;
+        for (int i = 0; i < iters; ++i) {
+            if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st, g.ev[2], g.ev[3])))
+                return rc;
+            HIP_TRY(hipEventSynchronize(g.ev[3]));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, g.ev[2], g.ev[3]));
+            acc += t;
+        }
+        *ms_tiles_out = acc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_fix_tiles_out) {
+        *n_fix_tiles_out = 0;
+        if (total > 0) HIP_TRY(hipMemcpy(n_fix_tiles_out, g.fix_count.p, 8, hipMemcpyDeviceToHost));
+    }
+    return LATOK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// aux_kernels.hip -- everything on the device that is NOT the fused hot path:
+//   * the reference's native functions one string at a time, as plain element-parallel kernels (compat surface):
+//       _gen_parse_matrix      reference latok/core/src/latok/latok.c:31-138
+//       _combine_matrix_rows   reference latok/core/src/latok/latok.c:275-370
+//   * boundary-offset compaction (np.nonzero, reference latok/core/default_tokenizer.py:148)
+//   * synthetic corpus fill and UTF-8 size reduction for the benchmark
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "corpus_gen.h"
+#include "kernels.h"
+
+namespace latok {
+
+// ---- _gen_parse_matrix ------------------------------------------------------------------------------------------
+// One thread per character; the 12 base features come from the class-word table (bit i = column i), the 13 context
+// columns are the neighbours' base bits with the reference's edge conventions (latok.c:69-73,114-134).
+__device__ __forceinline__ uint32_t base_word(const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw, uint32_t cp) {
+    const uint32_t hi = min(cp >> kTblShift, (uint32_t)(kStage1Len - 1));
+    return cw[t2cls[((uint32_t)t1[hi] << kTblShift) | (cp & ((1u << kTblShift) - 1u))]];
+}
+
+__global__ void k_parse_matrix(const uint32_t* __restrict__ cps, int64_t n, const uint8_t* __restrict__ t1,
+                               const uint8_t* __restrict__ t2cls, const uint16_t* __restrict__ cw,
+                               int8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = base_word(t1, t2cls, cw, cps[i]);
+    const uint32_t p = i > 0 ? base_word(t1, t2cls, cw, cps[i - 1]) : 0u;
+    const uint32_t x = i + 1 < n ? base_word(t1, t2cls, cw, cps[i + 1]) : 0u;
+    const uint32_t y = i + 2 < n ? base_word(t1, t2cls, cw, cps[i + 2]) : 0u;
+    int8_t* row = out + i * 25;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) row[c] = (int8_t)((w >> c) & 1u);
+    row[12] = (int8_t)((p >> 0) & 1u);                         // PREV_ALPHA
+    row[13] = (int8_t)((x >> 0) & 1u);                         // NEXT_ALPHA
+    row[14] = (int8_t)((p >> 1) & 1u);                         // PREV_ALPHA_NUM
+    row[15] = (int8_t)((x >> 1) & 1u);                         // NEXT_ALPHA_NUM
+    row[16] = (int8_t)((p >> 3) & 1u);                         // PREV_LOWER
+    row[17] = (int8_t)((x >> 3) & 1u);                         // NEXT_LOWER
+    row[18] = (int8_t)(i > 0 ? (p >> 5) & 1u : 1u);            // PREV_SPACE (string start counts as space)
+    row[19] = (int8_t)(i + 1 < n ? (x >> 5) & 1u : 1u);        // NEXT_SPACE (string end counts as space)
+    row[20] = (int8_t)((p >> 6) & 1u);                         // PREV_SYMBOL
+    row[21] = (int8_t)((x >> 8) & 1u);                         // NEXT_AT
+    row[22] = (int8_t)((x >> 10) & 1u);                        // NEXT_SLASH
+    row[23] = (int8_t)((y >> 0) & 1u);                         // AFTER_NEXT_ALPHA
+    row[24] = (int8_t)((y >> 10) & 1u);                        // AFTER_NEXT_SLASH
+}
+
+hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1, const uint8_t* t2cls,
+                               const uint16_t* cw, int8_t* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int threads = 256;
+    hipLaunchKernelGGL(k_parse_matrix, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, st, cps, n, t1,
+                       t2cls, cw, out);
+    return hipGetLastError();
+}
+
+// ---- _combine_matrix_rows -----------------------------------------------------------------------------------------
+// One thread per output element k.  uint8 wrap-around; 2-D idx: sum over idx rows of the product over idx columns,
+// -1 skipped; the running product is only re-initialised by column 0 (latok.c:328-333), so an idx row that starts
+// with -1 keeps multiplying the previous row's product -- kept.  1-D idx: plain sum (latok.c:342-354).
+__global__ void k_combine_rows(const uint8_t* __restrict__ m, int64_t stride_r, int64_t stride_c, int64_t cols,
+                               const int8_t* __restrict__ idx, int idx_ndim, int irows, int icols,
+                               int8_t* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cols) return;
+    uint8_t acc = 0, prod = 0;
+    if (idx_ndim == 2) {
+        for (int i = 0; i < irows; ++i) {
+            for (int j = 0; j < icols; ++j) {
+                const uint8_t r = (uint8_t)idx[i * icols + j];
+                if (r == 255) continue;
+                const uint8_t v = m[(int64_t)r * stride_r + k * stride_c];
+                prod = j == 0 ? v : (uint8_t)(prod * v);
+            }
+            acc = (uint8_t)(acc + prod);
+        }
+    } else {
+        for (int j = 0; j < icols; ++j) {
+            const uint8_t r = (uint8_t)idx[j];
+            if (r == 255) continue;
+            acc = (uint8_t)(acc + m[(int64_t)r * stride_r + k * stride_c]);
+        }
+    }
+    out[k] = (int8_t)acc;
+}
+
+hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
+                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st) {
+    if (cols <= 0) return hipSuccess;
+    const int threads = 256;
+    hipLaunchKernelGGL(k_combine_rows, dim3((unsigned)((cols + threads - 1) / threads)), dim3(threads), 0, st, m,
+                       stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out);
+    return hipGetLastError();
+}
+
+// ---- boundary offsets (np.nonzero per string) ---------------------------------------------------------------------
+// counts[s] = popcount of the mask bits in [row_off[s], row_off[s+1]); one thread per string (strings are short in the
+// batch configs; long documents are few).  Offsets are then scattered at the exclusive prefix sum of the counts.
+__device__ __forceinline__ uint64_t mask_word(const uint64_t* bits, int64_t w, int64_t lo, int64_t hi) {
+    // bits of word w restricted to char range [lo, hi)
+    uint64_t x = bits[w];
+    const int64_t base = w << 6;
+    if (lo > base) x &= ~0ull << (lo - base);
+    if (hi < base + 64) x &= (1ull << (hi - base)) - 1ull;
+    return x;
+}
+
+__global__ void k_count_boundaries(const uint64_t* __restrict__ bits, const int64_t* __restrict__ row_off,
+                                   int64_t n_str, int64_t* __restrict__ counts) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    const int64_t lo = row_off[s], hi = row_off[s + 1];
+    int64_t c = 0;
+    if (hi > lo)
+        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) c += __popcll(mask_word(bits, w, lo, hi));
+    counts[s] = c;
+}
+
+__global__ void k_write_offsets(const uint64_t* __restrict__ bits, const int64_t* __restrict__ row_off, int64_t n_str,
+                                const int64_t* __restrict__ out_base, int64_t* __restrict__ offsets) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    const int64_t lo = row_off[s], hi = row_off[s + 1];
+    int64_t k = out_base[s];
+    if (hi > lo)
+        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
+            uint64_t x = mask_word(bits, w, lo, hi);
+            while (x) {
+                const int b = __builtin_ctzll(x);
+                x &= x - 1;
+                offsets[k++] = (w << 6) + b - lo;
+            }
+        }
+}
+
+// single-block exclusive scan of int64 counts (chunk per thread + Hillis-Steele across threads)
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const int64_t* __restrict__ in, int64_t n,
+                                                         int64_t* __restrict__ out, int64_t* __restrict__ total) {
+    __shared__ long long s[1024];
+    const int tid = threadIdx.x;
+    const int64_t chunk = (n + 1023) / 1024;
+    const int64_t lo = min((int64_t)tid * chunk, n), hi = min(lo + chunk, n);
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += in[i];
+    s[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        long long o = 0;
+        if (tid >= d) o = s[tid - d];
+        __syncthreads();
+        s[tid] += o;
+        __syncthreads();
+    }
+    long long run = tid > 0 ? s[tid - 1] : 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (tid == 1023) *total = s[1023];
+}
+
+hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
+                                   hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_count_boundaries, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, row_off,
+                       n_str, counts);
+    return hipGetLastError();
+}
+hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, hipStream_t st) {
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, in, n, out, total);
+    return hipGetLastError();
+}
+hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
+                                int64_t* offsets, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, row_off, n_str,
+                       out_base, offsets);
+    return hipGetLastError();
+}
+
+// ---- synthetic corpus ------------------------------------------------------------------------------------------
+__global__ void k_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str,
+                              const int64_t* __restrict__ row_off, uint32_t* __restrict__ cps) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    const int64_t b = row_off[s];
+    latok_corpus_string(seed, model, sid0 + (uint64_t)s, cps + b, row_off[s + 1] - b);
+}
+
+hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
+                              uint32_t* cps, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_corpus_fill, dim3((unsigned)((n_str + 63) / 64)), dim3(64), 0, st, seed, model, sid0, n_str,
+                       row_off, cps);
+    return hipGetLastError();
+}
+
+__global__ void k_utf8_bytes(const uint32_t* __restrict__ cps, int64_t n, unsigned long long* __restrict__ total) {
+    long long local = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        local += latok_utf8_len(cps[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) local += __shfl_xor(local, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(total, (unsigned long long)local);
+}
+
+hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(total, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess || n <= 0) return e;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_utf8_bytes, dim3((unsigned)blocks), dim3(256), 0, st, cps, n, total);
+    return hipGetLastError();
+}
+
+}  // namespace latok

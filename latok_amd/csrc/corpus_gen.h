@@ -17,7 +17,10 @@
 #define LATOK_HD static inline
 #endif
 
-enum { LATOK_CORPUS_ASCII = 0, LATOK_CORPUS_UNICODE = 1 };
+#ifndef LATOK_CORPUS_ASCII
+#define LATOK_CORPUS_ASCII 0
+#define LATOK_CORPUS_UNICODE 1
+#endif
 
 LATOK_HD uint64_t latok_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;

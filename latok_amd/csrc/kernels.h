@@ -1,0 +1,64 @@
+// kernels.h -- constants, parameter blocks and launcher prototypes shared by the .hip kernel files and api.cpp.
+#ifndef LATOK_KERNELS_H
+#define LATOK_KERNELS_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace latok {
+
+// ---- geometry ------------------------------------------------------------------------------------------------
+constexpr int kTile = 4096;              // chars per tile = 64 lanes x 64-bit words (== LATOK_TILE_CHARS)
+constexpr int kTblShift = 7;             // stage-2 block = 128 code points
+constexpr int kStage1Len = 8705;         // 0x110000 >> 7, + 1 entry for cp >= 0x110000
+constexpr int kStage1Pad = 8720;         // padded to 16 B
+constexpr int kStage2Len = 255 * 128;    // 32640, multiple of 16
+constexpr int kTablesLdsBytes = kStage1Pad + kStage2Len;   // 41360
+constexpr int kStageBytes = 64 * 80;     // 64 rows of 64 code bytes + 16 B pad (conflict-free ds_read_b128)
+constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo + string-start words = 5664
+constexpr int kWavesPerBlockMain = 16;   // 1024 threads, one block per CU: 41360 + 16*5664 = 131984 B of LDS
+constexpr int kWavesPerBlockFix = 4;
+
+constexpr int kModeBits = 0;
+constexpr int kModeValues = 1;
+
+constexpr long long kNegInf64 = -(1ll << 60);
+
+struct SplitParams {
+    const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
+    const int64_t* row_off;     // [n_str + 1]
+    int64_t n_str, total, n_tiles;
+    const int64_t* tile_first;  // [n_tiles]
+    const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
+    const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
+    uint64_t* bits_out;         // kModeBits
+    uint8_t* values_out;        // kModeValues
+    int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing}
+    int* tile_q;                // [n_tiles] scratch of the scan
+    int64_t* fix_list;          // [n_tiles]
+    int* fix_q;                 // [n_tiles]
+    int* fix_tz;                // [n_tiles]
+    int64_t* fix_count;         // [1]
+};
+
+hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
+                             int64_t* fix_count, hipStream_t st);
+hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+hipError_t launch_scan_summaries(const SplitParams& P, hipStream_t st);
+hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+
+// aux_kernels.hip
+hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1, const uint8_t* t2cls,
+                               const uint16_t* cw, int8_t* out, hipStream_t st);
+hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
+                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
+hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
+                                   hipStream_t st);
+hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, hipStream_t st);
+hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
+                                int64_t* offsets, hipStream_t st);
+hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
+                              uint32_t* cps, hipStream_t st);
+hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);
+
+}  // namespace latok
+#endif

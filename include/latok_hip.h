@@ -117,7 +117,8 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
 /* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
  * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
  * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (split_tiles), measured with its own
- * event pair per launch; n_fix_tiles_out = tiles re-done by the fix-up stage in the last pass.  Any may be NULL. */
+ * event pair per launch in `iters` further passes; n_fix_tiles_out = tiles re-done by the fix-up stage in the last
+ * pass.  Any may be NULL (a NULL output skips its passes), so warm-up-only and kernel-only calls are possible. */
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
                            int64_t* n_fix_tiles_out);

@@ -84,7 +84,7 @@ int ensure_workspace(int64_t n_tiles) {
     int rc;
     if ((rc = g.tile_first.ensure(t * 8))) return rc;
     if ((rc = g.summ.ensure(t * 16))) return rc;
-    if ((rc = g.tile_q.ensure(t * 4))) return rc;
+    if ((rc = g.tile_q.ensure((t / 1024 + 2) * 32))) return rc;   // block aggregates of the summary scan
     if ((rc = g.fix_list.ensure(t * 8))) return rc;
     if ((rc = g.fix_q.ensure(t * 4))) return rc;
     if ((rc = g.fix_tz.ensure(t * 4))) return rc;
@@ -100,7 +100,8 @@ int need_init() {
 // enqueue the four-stage pipeline on device-resident data
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
-                 hipEvent_t tiles_end = nullptr) {
+                 hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
+                 const int* bm_flags = nullptr) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     int rc = ensure_workspace(n_tiles);
@@ -117,11 +118,14 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.summ = (int4*)g.summ.p;
-    P.tile_q = (int*)g.tile_q.p;
+    P.scan_agg = (unsigned char*)g.tile_q.p;
     P.fix_list = (int64_t*)g.fix_list.p;
     P.fix_q = (int*)g.fix_q.p;
     P.fix_tz = (int*)g.fix_tz.p;
     P.fix_count = (int64_t*)g.fix_count.p;
+    P.bm_a1 = bm_a1;
+    P.bm_a2 = bm_a2;
+    P.bm_flags = bm_flags;
     HIP_TRY(latok::launch_tile_index(d_row, n_str, n_tiles, (int64_t*)g.tile_first.p, P.fix_count, st));
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
     HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
@@ -392,10 +396,42 @@ int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64
 
 int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out, int flags, void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
-    (void)a1; (void)a2; (void)n; (void)out; (void)flags; (void)stream;
     int rc = need_init();
     if (rc) return rc;
-    return fail(LATOK_ERR_INVALID, "latok_block_mask: not implemented yet");
+    if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
+    if (n == 0) return LATOK_OK;
+    if (!a1 || !a2 || !out) return fail(LATOK_ERR_INVALID, "must specify two aligning 1d numpy array args");
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    // the block mask of ONE array pair is the batch pipeline over a single "string" [0, n) whose planes are a1 / a2
+    const int64_t row[2] = {0, n};
+    if ((rc = g.h_row.ensure(16))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.h_row.p, row, 16, hipMemcpyHostToDevice, st));
+    const int8_t *d1 = a1, *d2 = a2;
+    int8_t* dout = out;
+    if (dev) {
+        if ((((uintptr_t)a1 | (uintptr_t)a2 | (uintptr_t)out) & 3) != 0)
+            return fail(LATOK_ERR_INVALID, "device pointers must be 4-byte aligned");
+    } else {
+        if ((rc = g.h_cps.ensure((size_t)n + 16))) return rc;
+        if ((rc = g.h_aux.ensure((size_t)n + 16))) return rc;
+        if ((rc = g.h_out.ensure((size_t)n + 16))) return rc;
+        HIP_TRY(hipMemcpyAsync(g.h_cps.p, a1, (size_t)n, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.h_aux.p, a2, (size_t)n, hipMemcpyHostToDevice, st));
+        d1 = (const int8_t*)g.h_cps.p;
+        d2 = (const int8_t*)g.h_aux.p;
+        dout = (int8_t*)g.h_out.p;
+    }
+    int* d_flags = (int*)((char*)g.scalar.p + 16);
+    HIP_TRY(latok::launch_any_nonzero(d1, d2, n, d_flags, st));
+    if ((rc = run_pipeline(nullptr, (const int64_t*)g.h_row.p, 1, n, nullptr, (uint8_t*)dout, latok::kModeBlockMask, st,
+                           nullptr, nullptr, d1, d2, d_flags)))
+        return rc;
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LATOK_OK;
 }
 
 void* latok_dev_alloc(size_t bytes) {
@@ -498,21 +534,23 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = need_init();
     if (rc) return rc;
-    if (iters <= 0 || warmup < 0) return fail(LATOK_ERR_INVALID, "iters must be > 0");
+    if (iters < 0 || warmup < 0) return fail(LATOK_ERR_INVALID, "iters and warmup must be >= 0");
     if (((uintptr_t)cps_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
     hipStream_t st = g.stream;
     if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
     for (int i = 0; i < warmup; ++i)
         if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
     // (1) whole pipeline, `iters` passes between one pair of events on the launch stream
-    HIP_TRY(hipEventRecord(g.ev[0], st));
-    for (int i = 0; i < iters; ++i)
-        if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
-    HIP_TRY(hipEventRecord(g.ev[1], st));
-    HIP_TRY(hipEventSynchronize(g.ev[1]));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
-    if (ms_total_out) *ms_total_out = ms;
+    if (ms_total_out) {
+        HIP_TRY(hipEventRecord(g.ev[0], st));
+        for (int i = 0; i < iters; ++i)
+            if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+        HIP_TRY(hipEventRecord(g.ev[1], st));
+        HIP_TRY(hipEventSynchronize(g.ev[1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
+        *ms_total_out = ms;
+    }
     // (2) the dominant kernel alone: its own event pair around every launch (separate passes, not part of (1))
     if (ms_tiles_out) {
         float acc = 0.f;

@@ -20,6 +20,7 @@ constexpr int kWavesPerBlockFix = 4;
 
 constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;
+constexpr int kModeBlockMask = 2;        // compat _gen_block_mask: planes from caller byte arrays, byte mask out
 
 constexpr long long kNegInf64 = -(1ll << 60);
 
@@ -33,11 +34,15 @@ struct SplitParams {
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing}
-    int* tile_q;                // [n_tiles] scratch of the scan
+    unsigned char* scan_agg;    // [ceil(n_tiles/1024)] x 32 B block aggregates of the summary scan
     int64_t* fix_list;          // [n_tiles]
     int* fix_q;                 // [n_tiles]
     int* fix_tz;                // [n_tiles]
     int64_t* fix_count;         // [1]
+    // kModeBlockMask only
+    const int8_t* bm_a1;        // "starts" bytes [total]
+    const int8_t* bm_a2;        // "spaces" bytes [total]
+    const int* bm_flags;        // {any(a1), any(a2)}
 };
 
 hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
@@ -45,6 +50,7 @@ hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_ti
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_scan_summaries(const SplitParams& P, hipStream_t st);
 hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st);
 
 // aux_kernels.hip
 hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1, const uint8_t* t2cls,

@@ -181,16 +181,22 @@ LATOK_HD lk_fwd lk_forward(lk_u64 St, lk_u64 S, lk_u64 B) {
     r.firstB = B & (~B + 1ull);
     r.has_closing = closing != 0;
     const lk_u64 first_closing = closing & (~closing + 1ull);
-    r.head_starts = lk_popc(first_closing ? (St & (first_closing - 1ull)) : St);
+    // a start sitting ON a space is consumed by that very space (only possible through the generic
+    // _gen_block_mask surface; the tokenizer's own starts are never spaces)
+    r.head_starts = lk_popc(first_closing ? (St & (first_closing - 1ull)) : St) +
+                    (int)((St & S & ~B & first_closing) != 0);
 
     // fast path: a start's carry ripples (binary add) through the non-closing positions above it and lands on the
     // first closing.  Valid iff no two starts share a block, checked by counting (a merged ripple loses a start).
-    const lk_u64 gen = St << 1;
-    const int g63 = (int)(St >> 63);
+    // A start ON a space generates at its own position (its space consumes it); start+space+string-start on one
+    // char is left to the exact loop.
+    const lk_u64 on_space = St & S;
+    const lk_u64 gen = ((St & ~S) << 1) | on_space;
+    const int g63 = (int)((St & ~S) >> 63);
     const lk_u64 sum = Pf + gen;
     const int cout = sum < Pf;
     const lk_u64 reached = (sum ^ Pf) & closing;
-    if (lk_popc(St) == lk_popc(reached) + cout + g63) {
+    if ((on_space & B) == 0 && lk_popc(St) == lk_popc(reached) + cout + g63) {
         r.zb = reached & B;
         r.zs = reached & ~B;
         const lk_u64 below = r.firstB ? (r.firstB - 1ull) : ~0ull;

@@ -68,8 +68,9 @@ __device__ __forceinline__ int wave_sum(int v) {
 // (one thread per row_off entry, including the end sentinel row_off[n_str])
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_tile_index(const int64_t* __restrict__ row_off, int64_t n_str, int64_t n_tiles,
-                             int64_t* __restrict__ tile_first) {
+                             int64_t* __restrict__ tile_first, int64_t* __restrict__ fix_count) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) *fix_count = 0;   // consumed two launches later by the summary scan
     if (s > n_str) return;
     const int64_t cur = row_off[s] / kTile;
     const int64_t prev = s > 0 ? row_off[s - 1] / kTile : -1;
@@ -94,7 +95,9 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     const int64_t total = P.total;
 
     // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
-    if (t0 + kTile <= total) {
+    if (MODE == kModeBlockMask) {
+        // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
+    } else if (t0 + kTile <= total) {
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
         u32x4 v[16];
 #pragma unroll
@@ -118,7 +121,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
-    if (lane < 3) {
+    if (MODE != kModeBlockMask && lane < 3) {
         const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
         L.halo[lane] = (hp >= 0 && hp < total) ? (uint8_t)classify1(L.t1, L.t2, P.cps[hp]) : (uint8_t)0;
     }
@@ -140,23 +143,54 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     wave_lds_sync();
 
     // ---- phase 2: lane = one 64-char word ---------------------------------------------------------------------
-    uint32_t d[16];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4 q = *reinterpret_cast<const uint4*>(L.stage + stage_addr(64u * lane + 16u * k));
-        d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
-    }
-    lk_halo h;
-    h.prev = lane > 0 ? L.stage[stage_addr(64u * lane - 1u)] : L.halo[0];
-    h.next0 = lane < 63 ? L.stage[stage_addr(64u * lane + 64u)] : L.halo[1];
-    h.next1 = lane < 63 ? L.stage[stage_addr(64u * lane + 65u)] : L.halo[2];
     const lk_u64 B = L.bw[lane];
-    const lk_u64 Bn = L.bw[lane + 1] & 3ull;
-
-    lk_u64 plane[8];
-    lk_bitslice64(d, plane);
-    const lk_feat f = lk_decode(plane);
-    const lk_local loc = lk_rules(f, h, B, Bn);
+    const int64_t base = t0 + 64 * (int64_t)lane;
+    lk_local loc;
+    if (MODE == kModeBlockMask) {
+        // a1 -> start plane, a2 -> space plane; 64 bytes each, non-zero = set (PyArray_Nonzero, latok.c:178,198)
+        lk_u64 st = 0, sp = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t p = base + 4 * k;
+            uint32_t w1 = 0, w2 = 0;
+            if (p + 4 <= total) {
+                w1 = *reinterpret_cast<const uint32_t*>(P.bm_a1 + p);
+                w2 = *reinterpret_cast<const uint32_t*>(P.bm_a2 + p);
+            } else {
+                for (int b = 0; b < 4; ++b)
+                    if (p + b < total) {
+                        w1 |= (uint32_t)(uint8_t)P.bm_a1[p + b] << (8 * b);
+                        w2 |= (uint32_t)(uint8_t)P.bm_a2[p + b] << (8 * b);
+                    }
+            }
+            // byte != 0 -> one bit per byte -> 4-bit nibble
+            const uint32_t n1 = ((((w1 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w1) & 0x80808080u) >> 7;
+            const uint32_t n2 = ((((w2 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w2) & 0x80808080u) >> 7;
+            st |= (lk_u64)(((n1 * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+            sp |= (lk_u64)(((n2 * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+        }
+        loc.start = st;
+        loc.S = sp;
+        loc.raw = ~0ull;
+        loc.sym = 0;
+        loc.t_space = loc.t_sym = loc.t_prevsym = loc.t_camel_next = loc.t_camel_prev = 0;
+    } else {
+        uint32_t d[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 q = *reinterpret_cast<const uint4*>(L.stage + stage_addr(64u * lane + 16u * k));
+            d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+        }
+        lk_halo h;
+        h.prev = lane > 0 ? L.stage[stage_addr(64u * lane - 1u)] : L.halo[0];
+        h.next0 = lane < 63 ? L.stage[stage_addr(64u * lane + 64u)] : L.halo[1];
+        h.next1 = lane < 63 ? L.stage[stage_addr(64u * lane + 65u)] : L.halo[2];
+        const lk_u64 Bn = L.bw[lane + 1] & 3ull;
+        lk_u64 plane[8];
+        lk_bitslice64(d, plane);
+        const lk_feat f = lk_decode(plane);
+        loc = lk_rules(f, h, B, Bn);
+    }
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
 
     // forward: inclusive (max,+) scan of the per-word queue transfer functions over the 64 lanes
@@ -197,7 +231,6 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     const int cin = (int)((carries_in >> (63 - lane)) & 1ull);
     const lk_u64 cleared = lk_backward_fill(bw, cin, loc.S);
 
-    const int64_t base = t0 + 64 * (int64_t)lane;
     if (base < total) {
         const int64_t remain = total - base;
         const lk_u64 valid = remain >= 64 ? ~0ull : ((1ull << remain) - 1ull);
@@ -205,21 +238,32 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         if (MODE == kModeBits) {
             P.bits_out[base >> 6] = ((loc.raw & keep) | loc.sym | B) & valid;
         } else {
-            // split VALUES 0..5: (sum of the five C_SPLIT terms) * mask + C_SYM term; first char of a string = 1
+            // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
+            // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the
+            //   general path because "previous space" starts at 0, latok.c:224; zero only when there is no space at all)
             uint8_t* dst = P.values_out + base;
             const int n = remain >= 64 ? 64 : (int)remain;
 #pragma unroll 1
             for (int w = 0; w < 16; ++w) {
                 uint32_t packed = 0;
+                if (MODE == kModeBlockMask) {
+                    packed = ((uint32_t)((keep >> (4 * w)) & 0xFull) * 0x00204081u) & 0x01010101u;
+                    if (base == 0 && w == 0) {
+                        const int first = (P.bm_flags[0] != 0 && P.bm_flags[1] == 0) ? 0 : 1;
+                        packed = (packed & ~0xFFu) | (uint32_t)first;
+                    }
+                } else {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int i = 4 * w + b;
-                    int v = (int)((loc.t_space >> i) & 1) + (int)((loc.t_sym >> i) & 1) + (int)((loc.t_prevsym >> i) & 1) +
-                            (int)((loc.t_camel_next >> i) & 1) + (int)((loc.t_camel_prev >> i) & 1);
-                    v = ((keep >> i) & 1) ? v : 0;
-                    v += (int)((loc.sym >> i) & 1);
-                    if ((B >> i) & 1) v = 1;
-                    packed |= (uint32_t)v << (8 * b);
+                    for (int b = 0; b < 4; ++b) {
+                        const int i = 4 * w + b;
+                        int v = (int)((loc.t_space >> i) & 1) + (int)((loc.t_sym >> i) & 1) +
+                                (int)((loc.t_prevsym >> i) & 1) + (int)((loc.t_camel_next >> i) & 1) +
+                                (int)((loc.t_camel_prev >> i) & 1);
+                        v = ((keep >> i) & 1) ? v : 0;
+                        v += (int)((loc.sym >> i) & 1);
+                        if ((B >> i) & 1) v = 1;
+                        packed |= (uint32_t)v << (8 * b);
+                    }
                 }
                 if (4 * w + 4 <= n) {
                     *reinterpret_cast<uint32_t*>(dst + 4 * w) = packed;
@@ -246,7 +290,7 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
         if (n_items == 0) return;  // uniform: nothing to repair, skip the table load
     }
     // cooperative table load (global/L2 -> LDS), 16 B per thread per step
-    {
+    if (MODE != kModeBlockMask) {
         const uint4* s1 = reinterpret_cast<const uint4*>(P.t1);
         uint4* d1 = reinterpret_cast<uint4*>(lds);
         for (int i = threadIdx.x; i < kStage1Pad / 16; i += WPB * 64) d1[i] = s1[i];
@@ -319,65 +363,158 @@ __device__ __forceinline__ Hd64 hd_then(Hd64 x, Hd64 y) {
     return r;
 }
 
-constexpr int kScanThreads = 1024;
+constexpr int kScanThreads = 1024;   // tiles per scan block
+constexpr int kScanWaves = kScanThreads / 64;
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_summaries(const int4* __restrict__ summ, int64_t n_tiles,
-                                                                 int* __restrict__ tile_q,
-                                                                 int64_t* __restrict__ fix_list,
-                                                                 int* __restrict__ fix_q, int* __restrict__ fix_tz,
-                                                                 int64_t* __restrict__ fix_count) {
-    __shared__ Fn64 s_fn[kScanThreads];
-    __shared__ Hd64 s_hd[kScanThreads];
-    const int tid = threadIdx.x;
-    const int64_t chunk = (n_tiles + kScanThreads - 1) / kScanThreads;
-    const int64_t lo = min((int64_t)tid * chunk, n_tiles), hi = min(lo + chunk, n_tiles);
+__device__ __forceinline__ Fn64 fn_identity() { Fn64 f; f.a = 0; f.b = 0; return f; }   // identity on q >= 0
+__device__ __forceinline__ Hd64 hd_identity() { Hd64 h; h.h = 0; h.c = 0; return h; }
 
-    // pass 1: compose my chunk of tile functions (forward) and head descriptors (backward)
-    Fn64 F; F.a = 0; F.b = 0;
-    Hd64 H; H.h = 0; H.c = 0;
-    for (int64_t t = lo; t < hi; ++t) {
-        const int4 s = summ[t];
-        F = fn_then(F, fn_of(s));
-        Hd64 e; e.h = s.z; e.c = s.w;
-        H = hd_then(H, e);
+// Ordered block-wide scans over kScanThreads elements (one per thread).  Returns, for this thread, the composition of
+// all EARLIER elements (fn: exclusive prefix) and of all LATER elements (hd: exclusive suffix); *tot_* get the
+// composition of the whole block.  Wave-level shuffles + 16 wave aggregates in LDS.
+struct ScanLds {
+    Fn64 fn_w[kScanWaves];
+    Hd64 hd_w[kScanWaves];
+};
+__device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLds& L, Fn64* excl_fn, Hd64* excl_hd, Fn64* tot_fn,
+                                           Hd64* tot_hd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Fn64 fi = f;
+    Hd64 hi = h;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Fn64 o; o.a = __shfl_up(fi.a, d); o.b = __shfl_up(fi.b, d);
+        if (lane >= d) fi = fn_then(o, fi);
+        Hd64 oh; oh.h = __shfl_down(hi.h, d); oh.c = __shfl_down(hi.c, d);
+        if (lane + d < 64) hi = hd_then(hi, oh);
     }
-    s_fn[tid] = F;
-    s_hd[tid] = H;
+    __syncthreads();  // protects L against the previous use
+    if (lane == 63) L.fn_w[wave] = fi;
+    if (lane == 0) L.hd_w[wave] = hi;
     __syncthreads();
-    // inclusive scans across the 1024 chunks: prefix for the functions, suffix for the head descriptors
-    for (int dlt = 1; dlt < kScanThreads; dlt <<= 1) {
-        Fn64 o; Hd64 oh;
-        const bool hf = tid >= dlt, hb = tid + dlt < kScanThreads;
-        if (hf) o = s_fn[tid - dlt];
-        if (hb) oh = s_hd[tid + dlt];
-        __syncthreads();
-        if (hf) s_fn[tid] = fn_then(o, s_fn[tid]);
-        if (hb) s_hd[tid] = hd_then(s_hd[tid], oh);
-        __syncthreads();
+    Fn64 ef; ef.a = __shfl_up(fi.a, 1); ef.b = __shfl_up(fi.b, 1);
+    if (lane == 0) ef = fn_identity();
+    Hd64 eh; eh.h = __shfl_down(hi.h, 1); eh.c = __shfl_down(hi.c, 1);
+    if (lane == 63) eh = hd_identity();
+    Fn64 before = fn_identity(), all_f = fn_identity();
+    Hd64 after = hd_identity(), all_h = hd_identity();
+#pragma unroll
+    for (int w = 0; w < kScanWaves; ++w) {
+        if (w < wave) before = fn_then(before, L.fn_w[w]);
+        all_f = fn_then(all_f, L.fn_w[w]);
     }
-    long long q = tid > 0 ? fn_apply(s_fn[tid - 1], 0) : 0;                   // pending starts entering my chunk
-    long long h_next = tid + 1 < kScanThreads ? s_hd[tid + 1].h : 0;          // starts after my chunk before a closing
+#pragma unroll
+    for (int w = kScanWaves - 1; w >= 0; --w) {
+        if (w > wave) after = hd_then(L.hd_w[w], after);
+        all_h = hd_then(L.hd_w[w], all_h);
+    }
+    *excl_fn = fn_then(before, ef);
+    *excl_hd = hd_then(eh, after);
+    *tot_fn = all_f;
+    *tot_hd = all_h;
+}
 
-    // pass 2a (forward): pending starts entering every tile; a tile has <= 4096 closings, so clamping is exact
-    for (int64_t t = lo; t < hi; ++t) {
-        tile_q[t] = (int)(q < (1 << 20) ? q : (1 << 20));
-        q = fn_apply(fn_of(summ[t]), q);
-    }
-    // pass 2b (backward): tail decision per tile, and the list of tiles whose provisional assumptions were wrong
-    for (int64_t t = hi - 1; t >= lo; --t) {
+// stage 2a: one block per 1024 tiles -> block aggregates (transfer function of the block, head descriptor of the block)
+__global__ __launch_bounds__(kScanThreads) void k_scan_aggregate(const int4* __restrict__ summ, int64_t n_tiles,
+                                                                 Fn64* __restrict__ agg_fn, Hd64* __restrict__ agg_hd) {
+    __shared__ ScanLds L;
+    const int64_t t = (int64_t)blockIdx.x * kScanThreads + threadIdx.x;
+    Fn64 f = fn_identity();
+    Hd64 h = hd_identity();
+    if (t < n_tiles) {
         const int4 s = summ[t];
-        const int qin = tile_q[t];
-        const long long q_end = fn_apply(fn_of(s), qin);
-        const int tz = (q_end + h_next) > 0;
-        const int tz0 = s.y > 0;
-        if (qin != 0 || tz != tz0) {
-            const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long*>(fix_count), 1ull);
+        f = fn_of(s);
+        h.h = s.z; h.c = s.w;
+    }
+    Fn64 ef, tf; Hd64 eh, th;
+    block_scan(f, h, L, &ef, &eh, &tf, &th);
+    if (threadIdx.x == 0) { agg_fn[blockIdx.x] = tf; agg_hd[blockIdx.x] = th; }
+}
+
+// stage 2b: one block per 1024 tiles.  Every block first composes the aggregates of the blocks before it (pending
+// starts entering the block) and after it (starts before the next closing after the block), then resolves its own
+// tiles and appends the ones whose provisional assumptions were wrong to the fix list.
+__global__ __launch_bounds__(kScanThreads) void k_scan_resolve(const int4* __restrict__ summ, int64_t n_tiles,
+                                                               const Fn64* __restrict__ agg_fn,
+                                                               const Hd64* __restrict__ agg_hd, int n_blocks,
+                                                               int64_t* __restrict__ fix_list, int* __restrict__ fix_q,
+                                                               int* __restrict__ fix_tz, int64_t* __restrict__ fix_count) {
+    __shared__ ScanLds L;
+    const int b = blockIdx.x;
+    // (1) aggregates of the other blocks, contiguous range per thread, ordered
+    Fn64 pf = fn_identity();
+    Hd64 sh = hd_identity();
+    if (n_blocks > 1) {
+        const int per = (n_blocks + kScanThreads - 1) / kScanThreads;
+        const int lo = min((int)threadIdx.x * per, n_blocks), hi = min(lo + per, n_blocks);
+        Fn64 f = fn_identity();
+        Hd64 h = hd_identity();
+        for (int j = lo; j < hi; ++j) {
+            if (j < b) f = fn_then(f, agg_fn[j]);
+            if (j > b) h = hd_then(h, agg_hd[j]);
+        }
+        Fn64 ef; Hd64 eh;
+        block_scan(f, h, L, &ef, &eh, &pf, &sh);
+    }
+    const long long q_block_in = fn_apply(pf, 0);
+    Hd64 rest; rest.h = sh.h; rest.c = 1;   // what follows the block: sh.h starts before the next closing
+
+    // (2) my tile
+    const int64_t t = (int64_t)b * kScanThreads + threadIdx.x;
+    int4 s = make_int4(0, 0, 0, 0);
+    Fn64 f = fn_identity();
+    Hd64 h = hd_identity();
+    if (t < n_tiles) {
+        s = summ[t];
+        f = fn_of(s);
+        h.h = s.z; h.c = s.w;
+    }
+    Fn64 ef, tf; Hd64 eh, th;
+    block_scan(f, h, L, &ef, &eh, &tf, &th);
+    long long q_in = 0;
+    int tz = 0, need = 0;
+    if (t < n_tiles) {
+        q_in = fn_apply(ef, q_block_in);
+        const long long q_end = fn_apply(f, q_in);
+        const long long h_next = hd_then(eh, rest).h;
+        tz = (q_end + h_next) > 0;
+        need = q_in != 0 || tz != (s.y > 0);
+    }
+    // one atomic per wave (a single counter word saturates at a few dozen atomics per microsecond)
+    const lk_u64 m = __ballot(need);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(fix_count), (unsigned long long)lk_popc(m));
+        base = __shfl(base, 0);
+        if (need) {
+            const unsigned long long slot = base + (unsigned long long)lk_popc(m & ((1ull << lane) - 1ull));
             fix_list[slot] = t;
-            fix_q[slot] = qin;
+            fix_q[slot] = (int)(q_in < (1 << 20) ? q_in : (1 << 20));   // a tile has <= 4096 closings: clamp is exact
             fix_tz[slot] = tz;
         }
-        h_next = (long long)s.z + (s.w ? 0 : h_next);
     }
+}
+
+// flags[0] = any(a1 != 0), flags[1] = any(a2 != 0) (flags zeroed by the caller)
+__global__ void k_any_nonzero(const int8_t* __restrict__ a1, const int8_t* __restrict__ a2, int64_t n,
+                              int* __restrict__ flags) {
+    int f1 = 0, f2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        f1 |= a1[i] != 0;
+        f2 |= a2[i] != 0;
+    }
+    if (__any(f1) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+    if (__any(f2) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess || n <= 0) return e;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_any_nonzero, dim3((unsigned)blocks), dim3(256), 0, st, a1, a2, n, flags);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -393,12 +530,11 @@ static inline int blocks_for(int64_t n_items, int wpb, int n_cu, int max_blocks_
 
 hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
                              int64_t* fix_count, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(fix_count, 0, sizeof(int64_t), st);
-    if (e != hipSuccess) return e;
     const int64_t n = n_str + 1;
     const int threads = 256;
     const int64_t blocks = (n + threads - 1) / threads;
-    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)blocks), dim3(threads), 0, st, row_off, n_str, n_tiles, tile_first);
+    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)blocks), dim3(threads), 0, st, row_off, n_str, n_tiles, tile_first,
+                       fix_count);
     return hipGetLastError();
 }
 
@@ -407,26 +543,35 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
     if (mode == kModeBits)
         hipLaunchKernelGGL((k_split_tiles<kModeBits, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else
+    else if (mode == kModeValues)
         hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    else
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 
 hipError_t launch_scan_summaries(const SplitParams& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_summaries, dim3(1), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, P.tile_q,
-                       P.fix_list, P.fix_q, P.fix_tz, P.fix_count);
+    const int n_blocks = (int)((P.n_tiles + kScanThreads - 1) / kScanThreads);
+    Fn64* agg_fn = reinterpret_cast<Fn64*>(P.scan_agg);
+    Hd64* agg_hd = reinterpret_cast<Hd64*>(P.scan_agg + (size_t)n_blocks * sizeof(Fn64));
+    if (n_blocks > 1)
+        hipLaunchKernelGGL(k_scan_aggregate, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd);
+    hipLaunchKernelGGL(k_scan_resolve, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd,
+                       n_blocks, P.fix_list, P.fix_q, P.fix_tz, P.fix_count);
     return hipGetLastError();
 }
 
 hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
     constexpr int WPB = kWavesPerBlockFix;
     // the number of tiles to repair is only known on the device; a modest fixed grid loops over the list
-    int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
-    if (blocks > 128) blocks = 128;
+    int blocks = blocks_for(P.n_tiles / 8 + 1, WPB, n_cu, 2);
+    if (blocks > 2 * n_cu) blocks = 2 * n_cu;
     if (mode == kModeBits)
         hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else
+    else if (mode == kModeValues)
         hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    else
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 

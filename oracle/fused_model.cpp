@@ -42,9 +42,12 @@ struct Model {
     std::vector<TileSummary> summ;
     uint8_t* values;   // may be null
     uint64_t* bits;    // may be null
+    const int8_t* bm_a1 = nullptr;   // block-mask mode (compat _gen_block_mask): planes from byte arrays
+    const int8_t* bm_a2 = nullptr;
+    int8_t* bm_out = nullptr;
     int64_t n_fix = 0;
 
-    uint32_t code_at(int64_t p) const { return (p >= 0 && p < total) ? classify(cps[p]) : 0u; }
+    uint32_t code_at(int64_t p) const { return (cps && p >= 0 && p < total) ? classify(cps[p]) : 0u; }
 
     // stage 0: tile_first[t] = first string index s with row_off[s] >= t*kTile
     void build_tile_index() {
@@ -86,6 +89,15 @@ struct Model {
             h.next0 = code_at(base + 64);
             h.next1 = code_at(base + 65);
             Bl[j] = Bw[j];
+            if (bm_a1) {
+                lk_u64 st = 0, sp = 0;
+                for (int i = 0; i < 64 && base + i < total; ++i) {
+                    st |= (lk_u64)(bm_a1[base + i] != 0) << i;
+                    sp |= (lk_u64)(bm_a2[base + i] != 0) << i;
+                }
+                loc[j] = lk_local();
+                loc[j].start = st; loc[j].S = sp; loc[j].raw = ~0ull; loc[j].sym = 0;
+            } else
             loc[j] = lk_rules(f, h, Bw[j], Bw[j + 1] & 3ull);
             fw[j] = lk_forward(loc[j].start, loc[j].S, Bw[j]);
         }
@@ -122,6 +134,8 @@ struct Model {
             const lk_u64 keep = ~cleared;
             const lk_u64 out = (((loc[j].raw & keep) | loc[j].sym | Bl[j])) & valid;
             if (bits) bits[base >> 6] = out;
+            if (bm_out)
+                for (int i = 0; i < 64 && base + i < total; ++i) bm_out[base + i] = (int8_t)((keep >> i) & 1);
             if (values) {
                 for (int i = 0; i < 64 && base + i < total; ++i) {
                     const lk_u64 m = 1ull << i;
@@ -189,5 +203,25 @@ extern "C" int fused_split_batch(const uint32_t* cps, const int64_t* row_off, in
     m.bits = bits_out;
     m.run();
     if (n_fix_out) *n_fix_out = m.n_fix;
+    return 0;
+}
+
+// compat _gen_block_mask through the same pipeline (mirrors kModeBlockMask of the HIP kernel)
+extern "C" int fused_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out) {
+    if (n <= 0) return 0;
+    const int64_t row[2] = {0, n};
+    Model m;
+    m.cps = nullptr;
+    m.row_off = row;
+    m.n_str = 1;
+    m.total = n;
+    m.n_tiles = (n + kTile - 1) / kTile;
+    m.values = nullptr;
+    m.bits = nullptr;
+    m.bm_a1 = a1; m.bm_a2 = a2; m.bm_out = out;
+    m.run();
+    int any1 = 0, any2 = 0;
+    for (int64_t i = 0; i < n; ++i) { any1 |= a1[i] != 0; any2 |= a2[i] != 0; }
+    out[0] = (any1 && !any2) ? 0 : 1;   // reference quirk: element 0 (latok.c:224 vs :211-216)
     return 0;
 }

@@ -1,0 +1,76 @@
+"""N > 1 path of bench.py on CPU: world_size-2 gloo, the same helpers bench.py uses for sharding and for its only
+cross-rank traffic (max of wall time, sums of byte counts).  The data path itself has no collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import bench
+    import latok_oracle as orc
+    from latok_amd import _lib
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        n_per = 500
+        sid0, n = bench.shard_string_ids(n_per, rank)
+        lib = _lib.load()
+        model, seed, lo, hi, _, _ = bench.WORKLOADS["C2"]
+        row = np.zeros(n + 1, np.int64)
+        lib.latok_corpus_offsets(seed, sid0, n, lo, hi, row.ctypes.data)
+        cps = np.zeros(int(row[-1]), np.uint32)
+        lib.latok_corpus_fill_host(seed, model, sid0, n, row.ctypes.data, cps.ctypes.data)
+        vals, _ = orc.split_batch(cps, row, want_bits=False)
+        total_chars = bench.reduce_sum_int(dist, int(row[-1]))
+        total_bound = bench.reduce_sum_int(dist, int(np.count_nonzero(vals)))
+        slowest = bench.reduce_max_seconds(dist, 0.25 * (rank + 1))
+        dist.barrier()
+        q.put((rank, sid0, int(row[-1]), total_chars, total_bound, slowest, cps[:8].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_sharding_and_reductions(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, s0, c0, tot0, b0, slow0, head0), (r1, s1, c1, tot1, b1, slow1, head1) = res
+    assert (s0, s1) == (0, 500)                       # disjoint contiguous shards
+    assert tot0 == tot1 == c0 + c1                    # sum over ranks
+    assert b0 == b1 > 0
+    assert slow0 == slow1 == 0.5                      # max over ranks
+    assert head0 != head1                             # different strings on different ranks
+    # the union of the two shards is the single-process corpus of 1000 strings
+    sys.path.insert(0, ROOT)
+    import bench
+    from latok_amd import _lib
+    lib = _lib.load()
+    model, seed, lo, hi, _, _ = bench.WORKLOADS["C2"]
+    row = np.zeros(1001, np.int64)
+    lib.latok_corpus_offsets(seed, 0, 1000, lo, hi, row.ctypes.data)
+    assert int(row[-1]) == tot0 and int(row[500]) == c0

@@ -1,0 +1,76 @@
+"""The CPU model of the GPU pipeline (oracle/fused_model.cpp: same tiling, same lane math header, same four stages)
+against the reference-shaped oracle.  This is where the algorithm -- bit tricks, tile summaries, scan, fix-up,
+spill-over slow path -- is validated without a GPU.  CPU only."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ALPHABETS, ROOT, pack, random_strings
+
+
+@pytest.fixture(scope="module")
+def model():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fused"])
+    L = C.CDLL(os.path.join(ROOT, "oracle", "libfused_model.so"))
+    L.fused_split_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fused_block_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    return L
+
+
+def run_model(L, cps, row):
+    total = int(row[-1])
+    vals = np.zeros(total, np.uint8)
+    bits = np.zeros((total + 63) // 64, np.uint64)
+    nfix = C.c_int64(0)
+    assert L.fused_split_batch(cps.ctypes.data, row.ctypes.data, len(row) - 1, vals.ctypes.data, bits.ctypes.data,
+                               C.byref(nfix)) == 0
+    return vals, bits, nfix.value
+
+
+@pytest.mark.parametrize("kind,n,lo,hi", [
+    ("mixed", 400, 0, 40), ("starts", 60, 0, 300), ("mixed", 4, 3000, 20000), ("nospace_at", 3, 5000, 30000),
+    ("rare_space_at", 3, 5000, 30000), ("words", 200, 0, 200),
+])
+def test_model_matches_oracle(model, oracle, kind, n, lo, hi):
+    rng = random.Random(hash((kind, n)) & 0xFFFF)
+    fixed = 0
+    for _ in range(12):
+        cps, row = pack(random_strings(rng, rng.randint(1, n), lo, hi, ALPHABETS[kind]))
+        ov, ob = oracle.split_batch(cps, row)
+        mv, mb, nf = run_model(model, cps, row)
+        fixed += nf
+        assert np.array_equal(ov, mv) and np.array_equal(ob, mb)
+    if kind in ("nospace_at", "rare_space_at"):
+        assert fixed > 0, "the fix-up stage was never exercised"
+
+
+def test_model_all_code_points(model, oracle):
+    """The device table layout (unicode_tables.inc, two-stage + split codes) classifies every code point like the
+    oracle's run-length table: one string holding all of 0..0x10FFFF plus out-of-range values."""
+    cps = np.concatenate([np.arange(0x110000, dtype=np.uint32), np.array([0x110000, 0x7FFFFFFF, 0xFFFFFFFF], np.uint32)])
+    row = np.array([0, cps.size], np.int64)
+    ov, _ = oracle.split_batch(cps, row, want_bits=False)
+    mv, _, _ = run_model(model, cps, row)
+    assert np.array_equal(ov, mv)
+    # and with a letter between consecutive code points so every char's own class shows in its neighbours' context
+    inter = np.empty(2 * 0x110000, np.uint32)
+    inter[0::2] = np.arange(0x110000)
+    inter[1::2] = ord("a")
+    row = np.array([0, inter.size], np.int64)
+    assert np.array_equal(oracle.split_batch(inter, row, want_bits=False)[0], run_model(model, inter, row)[0])
+
+
+def test_model_block_mask(model, oracle):
+    rng = random.Random(17)
+    for _ in range(1500):
+        n = rng.choice([1, 2, 3, 7, 63, 64, 65, 200, 4096, 4097, 9000])
+        p1, p2 = rng.choice([0, .01, .1, .4]), rng.choice([0, .01, .1, .4])
+        a1 = np.array([rng.random() < p1 for _ in range(n)], np.int8)
+        a2 = np.array([rng.random() < p2 for _ in range(n)], np.int8)
+        out = np.zeros(n, np.int8)
+        model.fused_block_mask(a1.ctypes.data, a2.ctypes.data, n, out.ctypes.data)
+        assert np.array_equal(out, oracle.gen_block_mask(a1, a2)), (n, p1, p2)

@@ -136,3 +136,176 @@ def test_compat_native_functions(gpu, oracle):
         ext._gen_parse_matrix()
     with pytest.raises(ValueError):
         ext._combine_matrix_rows(np.zeros((2, 2), np.int8))
+
+
+def test_compat_block_mask(gpu, oracle):
+    """_gen_block_mask (reference latok.c:140-258) on arbitrary aligned arrays, incl. the probed SURVEY vectors,
+    coincident start/space positions, multi-tile lengths and the element-0 quirk."""
+    from latok_amd import latok as ext
+    cases = [
+        ([0, 0, 1, 0, 0, 0, 0], [0, 1, 0, 0, 1, 0, 0], [1, 1, 0, 0, 1, 1, 1]),
+        ([0, 0, 1, 1, 0, 0, 0, 0], [0, 1, 0, 0, 1, 0, 1, 0], [1, 1, 0, 0, 1, 0, 1, 1]),
+        ([0, 0, 0, 0, 0, 1, 0], [0, 1, 0, 0, 1, 0, 0], [1, 1, 1, 1, 1, 0, 0]),
+        ([0, 0, 1, 0], [0, 0, 0, 0], [0, 0, 0, 0]),
+    ]
+    for a1, a2, want in cases:
+        got = ext._gen_block_mask(np.array(a1, np.int8), np.array(a2, np.int8))
+        assert got.dtype == np.int8 and got.tolist() == want
+    rng = random.Random(3)
+    for n, p1, p2 in [(1, .5, .5), (2, .5, .5), (7, .3, .3), (64, .1, .2), (65, .1, .2), (1000, .02, .15),
+                      (4096, .01, .1), (4097, .01, .001), (20000, .001, .0), (20000, .0, .2), (30000, .3, .01),
+                      (50000, .002, .0005)]:
+        for _ in range(4):
+            a1 = np.array([rng.random() < p1 for _ in range(n)], np.int8) * rng.choice([1, 3, -1])
+            a2 = np.array([rng.random() < p2 for _ in range(n)], np.int8)
+            assert np.array_equal(ext._gen_block_mask(a1, a2), oracle.gen_block_mask(a1, a2)), (n, p1, p2)
+    with pytest.raises(ValueError):
+        ext._gen_block_mask(np.zeros(3, np.int8))
+    with pytest.raises(ValueError):
+        ext._gen_block_mask(np.zeros((2, 2), np.int8), np.zeros(4, np.int8))
+    with pytest.raises(ValueError):
+        ext._gen_block_mask(np.zeros(3, np.int8), np.zeros(4, np.int8))
+    assert ext._gen_block_mask(np.zeros(0, np.int8), np.zeros(0, np.int8)).shape == (0,)
+
+
+def test_gen_split_mask_recipe_and_tokenize(gpu, oracle):
+    """The user-editable recipe gen_split_mask(m) over the three compat kernels equals the fused kernel's values."""
+    from latok_amd.core import default_tokenizer as dt
+    from latok_amd import batch
+    rng = random.Random(21)
+    texts = [G1, "$#@^:a./", "camelCaseXMLParser", "foo@bar.com, .@user hi", "http://a@b X,y z", " ", "x"] + \
+        random_strings(rng, 40, 1, 200, ALPHABETS["mixed"]) + random_strings(rng, 10, 1, 400, ALPHABETS["words"])
+    for t in texts:
+        sp = dt.gen_split_mask(dt._gen_parse_matrix(t))
+        assert sp.dtype == np.int8
+        assert np.array_equal(sp, oracle.split_values(t)), t
+        assert list(dt.tokenize(t)) == oracle.tokenize(t)
+        feats = list(dt.featurize(t))
+        assert [f.text for f in feats] == oracle.tokenize(t)
+    with pytest.raises(IndexError):
+        list(dt.tokenize(""))
+    assert batch.tokenize_batch(["", "a b", G1]) == [[], ["a", "b"], oracle.tokenize(G1)]
+
+
+# ---- committed golden fixtures through the GPU path ------------------------------------------------------------------
+def _golden(name):
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _text_of(cps):
+    return np.array(cps, dtype="<u4").tobytes().decode("utf-32-le", "surrogatepass")
+
+
+def test_golden_fixtures_on_gpu(gpu):
+    """tests/golden was produced by the REAL reference (make_golden.py); no oracle involved here."""
+    import hashlib
+    from latok_amd import batch, latok as ext
+    from latok_amd.core import default_tokenizer as dt
+    g1 = _golden("g1_notebook.json")
+    assert ext._gen_parse_matrix(g1["text"]).tolist() == g1["matrix"]
+    assert dt.gen_split_mask(ext._gen_parse_matrix(g1["text"])).tolist() == g1["splits"]
+    items = _golden("ref_strings.json")["items"]
+    texts = [_text_of(it["cps"]) for it in items]
+    cps, row = batch.pack(texts)
+    vals = batch.split_values_batch(cps, row)
+    offs = batch.split_offsets_batch(texts)
+    toks = batch.tokenize_batch(texts)
+    for i, it in enumerate(items):
+        assert vals[row[i]:row[i + 1]].tolist() == it["splits"], texts[i]
+        assert offs[i].tolist() == it["offsets"]
+        assert toks[i] == [_text_of(t) for t in it["tokens"]]
+        m = ext._gen_parse_matrix(texts[i])
+        assert hashlib.sha256(np.ascontiguousarray(m).tobytes()).hexdigest() == it["matrix_sha256"]
+    c1 = _golden("c1_paragraph.json")
+    assert list(dt.tokenize(c1["text"])) == c1["tokens"]
+    assert batch.split_offsets_batch([c1["text"]])[0].tolist() == c1["offsets"]
+    nv = _golden("native_vectors.json")
+    for v in nv["block_mask"]:
+        assert ext._gen_block_mask(np.array(v["a1"], np.int8), np.array(v["a2"], np.int8)).tolist() == v["mask"]
+    for v in nv["combine"]:
+        assert ext._combine_matrix_rows(np.array(v["m"], np.int8), np.array(v["idx"], np.int8)).tolist() == v["out"]
+
+
+def _device_corpus(lib, seed, model, n_str, lo, hi, sid0=0, prefix=None):
+    """Generate a corpus on the device; optionally prepend one host-supplied string (shifts every tile boundary)."""
+    from latok_amd import _lib
+    row = np.zeros(n_str + 1, np.int64)
+    _lib.check(lib.latok_corpus_offsets(seed, sid0, n_str, lo, hi, row.ctypes.data))
+    total = int(row[-1])
+    d_row = lib.latok_dev_alloc(row.nbytes)
+    d_cps = lib.latok_dev_alloc(total * 4)
+    _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
+    _lib.check(lib.latok_corpus_fill_device(seed, model, sid0, n_str, d_row, d_cps, None))
+    cps = np.zeros(total, np.uint32)
+    _lib.check(lib.latok_memcpy_d2h(cps.ctypes.data, d_cps, cps.nbytes))
+    lib.latok_dev_free(d_row)
+    lib.latok_dev_free(d_cps)
+    if prefix is not None:
+        cps = np.concatenate([prefix, cps])
+        row = np.concatenate([[0], row + len(prefix)])
+    return cps, row
+
+
+def test_golden_corpus_hashes_device_generator_and_kernel(gpu):
+    """F7 end to end without the reference: device-generated corpus and GPU offsets hash like the reference's."""
+    import hashlib
+    from latok_amd import batch
+    for name, c in _golden("corpus_samples.json")["corpora"].items():
+        cps, row = _device_corpus(gpu, c["seed"], c["model"], c["n_str"], c["len_lo"], c["len_hi"])
+        assert hashlib.sha256(cps.astype("<u4").tobytes()).hexdigest() == c["sha256_cps_u32le"], name
+        counts, offs = batch.split_offsets_csr(cps, row)
+        assert int(counts.sum()) == c["n_boundaries"]
+        assert hashlib.sha256(offs.astype("<i8").tobytes()).hexdigest() == c["sha256_offsets_i64le"], name
+
+
+@pytest.mark.parametrize("workload", ["C2", "C3"])
+def test_full_size_properties(gpu, oracle, workload):
+    """BASELINE full sizes (1 M strings): size-independent properties + oracle parity on samples."""
+    import hashlib
+    from latok_amd import _lib, batch
+    seed, model, lo, hi = {"C2": (0x1A70C0DE, 0, 64, 192), "C3": (0x1A70C0DF, 1, 128, 384)}[workload]
+    n_str = 1_000_000
+    cps, row = _device_corpus(gpu, seed, model, n_str, lo, hi)
+    total = int(row[-1])
+    bits = batch.split_mask_batch(cps, row)
+    flags = bits_to_bool(bits, total)
+    # (1) every string start is a boundary; nothing beyond the last char
+    assert flags[row[:-1]].all()
+    # (2) idempotent / deterministic, and host-pointer path == device-pointer path
+    assert np.array_equal(bits, batch.split_mask_batch(cps, row))
+    counts, offs = batch.split_offsets_csr(cps, row)
+    assert int(counts.sum()) == int(flags.sum()) == offs.size
+    # (3) offsets are per-string ascending, start with 0, and re-create the bitmask
+    starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    assert (offs[starts] == 0).all()
+    glob = offs + np.repeat(row[:-1], counts)
+    assert (np.diff(glob) > 0).all()
+    rebuilt = np.zeros(total, bool)
+    rebuilt[glob] = True
+    assert np.array_equal(rebuilt, flags)
+    # (4) translation invariance: a string's boundaries do not depend on where it sits in the packed buffer
+    #     (prepending 1777 chars moves every tile / word boundary); compared through a checksum of checksums
+    pre = np.frombuffer(("x" * 1776 + " ").encode("utf-32-le"), dtype="<u4").astype(np.uint32)
+    cps2, row2 = _device_corpus(gpu, seed, model, n_str, lo, hi, prefix=pre)
+    counts2, offs2 = batch.split_offsets_csr(cps2, row2)
+    assert np.array_equal(counts2[1:], counts)
+    assert hashlib.sha256(offs2[counts2[0]:].tobytes()).hexdigest() == hashlib.sha256(offs.tobytes()).hexdigest()
+    # (5) oracle parity on a head, a middle and a tail sample (the oracle needs seconds for these)
+    for lo_s, hi_s in ((0, 20000), (n_str // 2, n_str // 2 + 5000), (n_str - 5000, n_str)):
+        sub_row = row[lo_s:hi_s + 1] - row[lo_s]
+        sub = cps[row[lo_s]:row[hi_s]]
+        ov, _ = oracle.split_batch(sub, sub_row, want_bits=False)
+        assert np.array_equal(ov != 0, flags[row[lo_s]:row[hi_s]])
+
+
+def test_long_documents(gpu, oracle):
+    """BASELINE configs[4] shape at a reduced count: 12 documents x 1 M chars, oracle parity on all of them."""
+    cps, row = _device_corpus(gpu, 0x1A70C0E0, 0, 12, 1_000_000, 1_000_000)
+    from latok_amd import batch
+    bits = batch.split_mask_batch(cps, row)
+    _, ob = oracle.split_batch(cps, row, want_values=False)
+    assert np.array_equal(ob, bits)

@@ -1,0 +1,128 @@
+"""Host-side logic and the C-ABI surface, without a GPU: the library loads and exports every symbol the header
+declares, the Python mirror has the reference's names/values, compute fails loudly when no device exists, and the
+product never reaches into oracle/."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, has_gpu
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "latok_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(latok_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from latok_amd import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    assert sorted(_lib.SIGNATURES) == syms, "latok_amd/_lib.py and include/latok_hip.h disagree"
+    for name in syms:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.latok_version()
+    assert lib.latok_device_count() >= 0
+
+
+def test_no_cpu_fallback_without_device():
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    from latok_amd import _lib, batch
+    from latok_amd.core import default_tokenizer as dt
+    lib = _lib.load()
+    assert lib.latok_init(0) == _lib.ERR_HIP and b"no HIP device" in lib.latok_last_error()
+    out = np.zeros(1, np.uint64)
+    cps = np.array([97, 98], np.uint32)
+    row = np.array([0, 2], np.int64)
+    assert lib.latok_split_mask_batch(cps.ctypes.data, row.ctypes.data, 1, 2, out.ctypes.data, 0, None) == _lib.ERR_NOT_INIT
+    with pytest.raises(RuntimeError):
+        batch.split_mask_batch(cps, row)
+    with pytest.raises(RuntimeError):
+        list(dt.tokenize("no gpu here"))
+
+
+def test_offsets_constants_match_reference():
+    """values of reference latok/core/offsets.py:3-49"""
+    from latok_amd.core import offsets as oft
+    masks = ["ALPHA", "DECIMAL", "DIGIT", "LOWER", "LINEBREAK", "SPACE", "TITLE", "UPPER", "XID_START", "XID_CONTINUE",
+             "PRINTABLE", "NUMERIC", "CASE_IGNORABLE", "CASED", "EXTENDED_CASE", "SPECIALS", "CHAR_AT", "CHAR_COLON",
+             "CHAR_SLASH", "CHAR_PERIOD"]
+    for i, n in enumerate(masks):
+        assert getattr(oft, n + "_MASK") == 1 << i
+    assert oft.CHAR_PERIOD_MASK == 0x080000 and oft.SPECIALS_MASK == 0x8000 and oft.PRINTABLE_MASK == 0x400
+    g = json.load(open(os.path.join(GOLDEN, "g1_notebook.json")))
+    from latok_amd.core.latok_utils import FEATURE_NAMES, NUM_FEATURES
+    assert FEATURE_NAMES == g["feature_names"] and NUM_FEATURES == oft.FEATURE_COUNT == 25
+    cols = dict(ALPHA=0, ALPHA_NUM=1, NUM=2, LOWER=3, UPPER=4, SPACE=5, SYMBOL=6, TWITTER=7, CHAR_AT=8, CHAR_COLON=9,
+                CHAR_SLASH=10, CHAR_PERIOD=11, PREV_ALPHA=12, NEXT_ALPHA=13, PREV_ALPHA_NUM=14, NEXT_ALPHA_NUM=15,
+                PREV_LOWER=16, NEXT_LOWER=17, PREV_SPACE=18, NEXT_SPACE=19, PREV_SYMBOL=20, NEXT_AT=21, NEXT_SLASH=22,
+                AFTER_NEXT_ALPHA=23, AFTER_NEXT_SLASH=24)
+    for n, v in cols.items():
+        assert getattr(oft, n + "_IDX") == v
+
+
+def test_rule_tables_match_reference():
+    """C_SPLIT / C_MASK / C_SYM values of reference default_tokenizer.py:108-110."""
+    from latok_amd.core import default_tokenizer as dt
+    from latok_amd.core.latok_utils import build_combo_matrix
+    assert dt.C_SPLIT.dtype == np.int8
+    assert dt.C_SPLIT.tolist() == [[5, -1], [6, -1], [20, -1], [4, 17], [4, 16]]
+    assert dt.C_MASK.tolist() == [[7, 18, 13, -1], [11, 18, 21, 23], [8, 14, 15, -1], [9, 22, 24, 12]]
+    assert dt.C_SYM.tolist() == [[6, 19]]
+    assert build_combo_matrix([[1], [2, 3, 4]]).tolist() == [[1, -1, -1], [2, 3, 4]]
+
+
+def test_pack_and_token_materialisation(oracle):
+    """host logic of latok_amd.batch: CSR packing and the reference's slice/strip loop, fed with oracle offsets."""
+    from latok_amd import batch
+    texts = ["This is a #test! Testing, Testing, 1 2 3", "", " ", "a", "  lead and trail  ", "日本語 テキスト🤓", "x\t\ny"]
+    cps, row = batch.pack(texts)
+    assert row.tolist() == np.cumsum([0] + [len(t) for t in texts]).tolist()
+    assert cps.dtype == np.uint32 and cps.size == row[-1]
+    for t in texts:
+        if t:
+            assert batch.spans_from_offsets(t, oracle.split_offsets(t)) == oracle.tokenize(t)
+    assert batch.spans_from_offsets("", np.zeros(0, np.int64)) == []
+    with pytest.raises(ValueError):
+        batch._csr(np.zeros(3, np.uint32), np.array([0, 5], np.int64))
+
+
+def test_compat_argument_errors_do_not_need_a_gpu():
+    from latok_amd import latok as ext
+    with pytest.raises(ValueError, match="must specify string"):
+        ext._gen_parse_matrix()
+    with pytest.raises(ValueError, match="two aligning 1d"):
+        ext._gen_block_mask(np.zeros(3))
+    with pytest.raises(ValueError, match="1d numpy array args"):
+        ext._gen_block_mask(np.zeros((2, 2)), np.zeros(4))
+    with pytest.raises(ValueError, match="matching length"):
+        ext._gen_block_mask(np.zeros(3), np.zeros(4))
+    with pytest.raises(ValueError, match="2d m and idxs"):
+        ext._combine_matrix_rows(np.zeros((2, 2)))
+    with pytest.raises(ValueError, match="2d numpy array args"):
+        ext._combine_matrix_rows(np.zeros(4), np.zeros(2))
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "latok_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")) or f == "Makefile":
+                src = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"latok_oracle|fused_model|oracle/|ref_loader|import oracle", src):
+                    # comments that merely mention the oracle directory are fine; imports / includes / links are not
+                    for line in src.splitlines():
+                        s = line.strip()
+                        if re.search(r"latok_oracle|fused_model|ref_loader", s) and not s.startswith(("//", "#", "*", "/*")):
+                            bad.append((f, s))
+    assert not bad, bad
+    # and the shared object has no dependency on oracle libraries
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(ROOT, "latok_amd", "liblatok_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "fused_model" not in out

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -130,7 +131,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
     HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
     if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));
-    HIP_TRY(latok::launch_scan_summaries(P, st));
+    HIP_TRY(latok::launch_scan_summaries(P, mode, st));
     HIP_TRY(latok::launch_fix_tiles(P, mode, g.n_cu, st));
     return LATOK_OK;
 }

@@ -17,6 +17,7 @@ constexpr int kStageBytes = 64 * 80;     // 64 rows of 64 code bytes + 16 B pad 
 constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo + string-start words = 5664
 constexpr int kWavesPerBlockMain = 16;   // 1024 threads, one block per CU: 41360 + 16*5664 = 131984 B of LDS
 constexpr int kWavesPerBlockFix = 4;
+constexpr bool kPrefetchMain = false;    // main kernel keeps the next tile's 16 KiB of loads in flight under phase 2
 
 constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;
@@ -33,7 +34,7 @@ struct SplitParams {
     const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues
-    int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing}
+    int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
     unsigned char* scan_agg;    // [ceil(n_tiles/1024)] x 32 B block aggregates of the summary scan
     int64_t* fix_list;          // [n_tiles]
     int* fix_q;                 // [n_tiles]
@@ -48,7 +49,7 @@ struct SplitParams {
 hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
                              int64_t* fix_count, hipStream_t st);
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
-hipError_t launch_scan_summaries(const SplitParams& P, hipStream_t st);
+hipError_t launch_scan_summaries(const SplitParams& P, int mode, hipStream_t st);
 hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st);
 

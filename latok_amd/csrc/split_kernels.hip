@@ -22,6 +22,7 @@
 // No MFMA: this is integer/bit work bounded by HBM reads (4 B/char), not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 #include "lane_math.h"
@@ -57,10 +58,47 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- cross-lane helpers on DPP / readlane (no LDS round trip, unlike ds_bpermute-based __shfl) -----------------
+// update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl=false): lanes without a valid source keep `old`.
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int lane_read(int v, int uniform_lane) { return __builtin_amdgcn_readlane(v, uniform_lane); }
+__device__ __forceinline__ int64_t lane_read64(int64_t v, int uniform_lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, uniform_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), uniform_lane);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    v += dpp_mov<kDppRowShr1, 0xF>(0, v);
+    v += dpp_mov<kDppRowShr2, 0xF>(0, v);
+    v += dpp_mov<kDppRowShr4, 0xF>(0, v);
+    v += dpp_mov<kDppRowShr8, 0xF>(0, v);   // lane 15 of every row now holds its row's sum
+    return lane_read(v, 15) + lane_read(v, 31) + lane_read(v, 47) + lane_read(v, 63);
+}
+
+// inclusive scan over the 64 lanes of the queue transfer functions, earlier lanes applied first; (0,0) is neutral
+// for the functions that occur here (a <= b, b >= 0)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ lk_qfn qfn_scan_step(lk_qfn inc) {
+    lk_qfn o;
+    o.a = dpp_mov<CTRL, ROW_MASK>(0, inc.a);
+    o.b = dpp_mov<CTRL, ROW_MASK>(0, inc.b);
+    return lk_qfn_then(o, inc);
+}
+__device__ __forceinline__ lk_qfn qfn_wave_scan(lk_qfn f) {
+    f = qfn_scan_step<kDppRowShr1, 0xF>(f);
+    f = qfn_scan_step<kDppRowShr2, 0xF>(f);
+    f = qfn_scan_step<kDppRowShr4, 0xF>(f);
+    f = qfn_scan_step<kDppRowShr8, 0xF>(f);
+    f = qfn_scan_step<kDppRowBcast15, 0xA>(f);   // rows 1 and 3 take the total of the row before them
+    f = qfn_scan_step<kDppRowBcast31, 0xC>(f);   // rows 2 and 3 take the total of rows 0..1
+    return f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -88,24 +126,46 @@ struct TileLds {
     lk_u64* bw;            // 65 words of string-start bits, wave private
 };
 
-template <int MODE>
-__device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
-                                             bool write_summary, int lane) {
+// PF: software prefetch.  `v` carries the 16 KiB of code points of a full tile in registers; when `v_valid` the loads
+// for THIS tile were issued while the previous tile was in phase 2.  After classifying, the loads of tile `t_next` are
+// issued so that they fly under this tile's phase 2.  Returns whether `v` now holds tile `t_next`.
+template <int MODE, bool PF>
+__device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
+                                             bool write_summary, int lane, u32x4 (&v)[16], bool v_valid,
+                                             int64_t t_next) {
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
+    bool next_valid = false;
+
+    // small loads first, so that their latency flies together with the 16 KiB of code points: the first string that
+    // starts in this tile, the start offsets of the next 64 strings, and the three halo characters
+    int64_t idx0 = P.tile_first[t];
+    int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+    uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
+    if (MODE != kModeBlockMask && lane < 3) {
+        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
+        if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
+    }
 
     // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
     } else if (t0 + kTile <= total) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-        u32x4 v[16];
+        if (!(PF && v_valid)) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
             *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
+        }
+        if (PF && t_next >= 0 && (t_next + 1) * kTile <= total) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+            next_valid = true;
         }
     } else {
 #pragma unroll 1
@@ -121,24 +181,17 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
-    if (MODE != kModeBlockMask && lane < 3) {
-        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
-        L.halo[lane] = (hp >= 0 && hp < total) ? (uint8_t)classify1(L.t1, L.t2, P.cps[hp]) : (uint8_t)0;
-    }
+    if (MODE != kModeBlockMask && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
     L.bw[lane] = 0;
     if (lane == 0) L.bw[64] = 0;
     wave_lds_sync();
-    {
-        int64_t idx0 = P.tile_first[t];
-        for (;;) {
-            const int64_t idx = idx0 + lane;
-            const int64_t ro = idx <= P.n_str ? P.row_off[idx] : INT64_MAX;
-            const int64_t rel = ro - t0;
-            if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
-            const int64_t last = __shfl(ro, 63);
-            if (last >= t0 + kTile + 64) break;
-            idx0 += 64;
-        }
+    for (;;) {
+        const int64_t rel = ro - t0;
+        if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
+        const int64_t last = lane_read64(ro, 63);
+        if (last >= t0 + kTile + 64) break;
+        idx0 += 64;
+        ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     }
     wave_lds_sync();
 
@@ -194,35 +247,52 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
 
     // forward: inclusive (max,+) scan of the per-word queue transfer functions over the 64 lanes
-    lk_qfn inc = lk_qfn_of(fw);
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        lk_qfn o;
-        o.a = __shfl_up(inc.a, dlt);
-        o.b = __shfl_up(inc.b, dlt);
-        if (lane >= dlt) inc = lk_qfn_then(o, inc);
-    }
-    lk_qfn exc;
-    exc.a = __shfl_up(inc.a, 1);
-    exc.b = __shfl_up(inc.b, 1);
-    const int r = lane > 0 ? lk_qfn_apply(exc, q_in) : q_in;
+    const lk_qfn inc = qfn_wave_scan(lk_qfn_of(fw));
+    lk_qfn exc;   // exclusive: the function of lanes 0..lane-1 (identity for lane 0)
+    exc.a = dpp_mov<kDppWaveShr1, 0xF>(0, inc.a);
+    exc.b = dpp_mov<kDppWaveShr1, 0xF>(0, inc.b);
+    const int r = lk_qfn_apply(exc, q_in);
     lk_qfn tile_fn;
-    tile_fn.a = __shfl(inc.a, 63);
-    tile_fn.b = __shfl(inc.b, 63);
+    tile_fn.a = lane_read(inc.a, 63);
+    tile_fn.b = lane_read(inc.b, 63);
     if (r > 0) lk_apply_extra(fw, r);
 
     if (write_summary) {
-        const lk_u64 closing_lanes = __ballot(fw.has_closing);
+        const lk_u64 cl = loc.S | B;                       // closing events of my word
+        const lk_u64 closing_lanes = __ballot(cl != 0);
         const int first_lane = closing_lanes ? lk_ctz(closing_lanes) : 64;
         const int contrib = lane < first_lane ? lk_popc(loc.start) : (lane == first_lane ? fw.head_starts : 0);
-        const int head = wave_sum(contrib);
-        if (lane == 0) P.summ[t] = make_int4(tile_fn.a, tile_fn.b, head, closing_lanes != 0);
+        const int head = __ballot(contrib != 0) ? wave_sum(contrib) : 0;   // starts are rare: usually no sum needed
+        // geometry of the two blocks that straddle the tile edges, so that the scan stage can patch the common cases
+        // in place instead of recomputing the tile:
+        //   c_rel : first closing event (4096 if none)       -> head block = [0, c_rel)
+        //   p_rel : first char of the open tail block          -> tail block = [p_rel, 4096)
+        //   head_sym / tail_sym : the one position of each block that can carry a C_SYM bit (its last char)
+        //   tail_keep : the tail block begins with a string start (its bit stays 1)
+        int c_rel = kTile, p_rel = 0, tail_keep = 0;
+        if (closing_lanes) {
+            const int last_lane = 63 - __builtin_clzll(closing_lanes);
+            const int my_first = cl ? 64 * lane + lk_ctz(cl) : 0;
+            const int top = cl ? 63 - __builtin_clzll(cl) : 0;
+            const int s_top = (int)((loc.S >> top) & 1ull);
+            c_rel = lane_read(my_first, first_lane);
+            p_rel = lane_read(64 * lane + top + s_top, last_lane);
+            tail_keep = lane_read(1 - s_top, last_lane);
+        }
+        const int hs_pos = c_rel > 0 ? c_rel - 1 : 0;
+        const int head_sym = c_rel > 0 ? lane_read((int)((loc.sym >> (hs_pos & 63)) & 1ull), hs_pos >> 6) : 0;
+        const int tail_sym = lane_read((int)(loc.sym >> 63), 63);
+        if (lane == 0) {
+            const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
+                             (tail_sym << 29);
+            P.summ[t] = make_int4(tile_fn.a, tile_fn.b, head, geom);
+        }
     }
 
     // backward: zeroing closings clear the block below them; the carry chain over lanes is one 64-bit add on ballots
     const lk_u64 zall = fw.zs | fw.zb;
-    const int z0_next = __shfl_down((int)(zall & 1ull), 1);
-    const lk_bwd bw = lk_backward_prepare(zall, loc.S, B, lane < 63 ? z0_next : 0);
+    const int z0_next = dpp_mov<kDppWaveShl1, 0xF>(0, (int)(zall & 1ull));   // lane 63 gets 0
+    const lk_bwd bw = lk_backward_prepare(zall, loc.S, B, z0_next);
     const int tz = tail_zero >= 0 ? tail_zero : (lk_qfn_apply(tile_fn, q_in) > 0);
     // chain order is lane 63 -> 0, so reverse the ballots: bit i' = lane 63 - i'
     const lk_u64 G = lk_rev(__ballot(bw.g)), Pm = lk_rev(__ballot(bw.p));
@@ -274,13 +344,14 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         }
     }
     wave_lds_sync();  // staging buffer is reused by this wave's next tile
+    return next_valid;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // stage 1 / stage 3 kernel.  FIX = false: all tiles, grid-stride, q_in = 0, provisional tail, writes summaries.
 //                            FIX = true : only the tiles listed by k_scan_summaries, with their exact inputs.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool FIX, int WPB>
+template <int MODE, bool FIX, int WPB, bool PREFETCH>
 __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTablesLdsBytes + WPB * kWaveLdsBytes];
 
@@ -301,7 +372,7 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar tile arithmetic
     TileLds L;
     L.t1 = lds;
     L.t2 = lds + kStage1Pad;
@@ -312,12 +383,15 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
 
     const int64_t wave_gid = (int64_t)blockIdx.x * WPB + wave;
     const int64_t n_waves = (int64_t)gridDim.x * WPB;
+    u32x4 v[16];
+    bool v_valid = false;
     for (int64_t i = wave_gid; i < n_items; i += n_waves) {
         if (FIX) {
             const int64_t t = P.fix_list[i];
-            process_tile<MODE>(P, L, t, P.fix_q[i], P.fix_tz[i], false, lane);
+            process_tile<MODE, false>(P, L, t, P.fix_q[i], P.fix_tz[i], false, lane, v, false, -1);
         } else {
-            process_tile<MODE>(P, L, i, 0, -1, true, lane);
+            const int64_t nxt = i + n_waves < n_items ? i + n_waves : -1;
+            v_valid = process_tile<MODE, PREFETCH>(P, L, i, 0, -1, true, lane, v, v_valid, nxt);
         }
     }
 }
@@ -396,18 +470,23 @@ __device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLds& L, Fn64* exc
     if (lane == 0) ef = fn_identity();
     Hd64 eh; eh.h = __shfl_down(hi.h, 1); eh.c = __shfl_down(hi.c, 1);
     if (lane == 63) eh = hd_identity();
-    Fn64 before = fn_identity(), all_f = fn_identity();
-    Hd64 after = hd_identity(), all_h = hd_identity();
+    // second level: every wave scans the 16 wave aggregates with shuffles (lanes 0..15), then picks its own entry
+    Fn64 wf = lane < kScanWaves ? L.fn_w[lane] : fn_identity();
+    Hd64 wh = lane < kScanWaves ? L.hd_w[lane] : hd_identity();
 #pragma unroll
-    for (int w = 0; w < kScanWaves; ++w) {
-        if (w < wave) before = fn_then(before, L.fn_w[w]);
-        all_f = fn_then(all_f, L.fn_w[w]);
+    for (int d = 1; d < kScanWaves; d <<= 1) {
+        Fn64 o; o.a = __shfl_up(wf.a, d); o.b = __shfl_up(wf.b, d);
+        if (lane >= d) wf = fn_then(o, wf);
+        Hd64 oh; oh.h = __shfl_down(wh.h, d); oh.c = __shfl_down(wh.c, d);
+        if (lane + d < kScanWaves) wh = hd_then(wh, oh);
     }
-#pragma unroll
-    for (int w = kScanWaves - 1; w >= 0; --w) {
-        if (w > wave) after = hd_then(L.hd_w[w], after);
-        all_h = hd_then(L.hd_w[w], all_h);
-    }
+    // inclusive prefix of waves 0..lane in wf, inclusive suffix of waves lane..15 in wh
+    Fn64 before; before.a = __shfl(wf.a, wave > 0 ? wave - 1 : 0); before.b = __shfl(wf.b, wave > 0 ? wave - 1 : 0);
+    if (wave == 0) before = fn_identity();
+    Hd64 after; after.h = __shfl(wh.h, wave < kScanWaves - 1 ? wave + 1 : 0); after.c = __shfl(wh.c, wave < kScanWaves - 1 ? wave + 1 : 0);
+    if (wave == kScanWaves - 1) after = hd_identity();
+    Fn64 all_f; all_f.a = __shfl(wf.a, kScanWaves - 1); all_f.b = __shfl(wf.b, kScanWaves - 1);
+    Hd64 all_h; all_h.h = __shfl(wh.h, 0); all_h.c = __shfl(wh.c, 0);
     *excl_fn = fn_then(before, ef);
     *excl_hd = hd_then(eh, after);
     *tot_fn = all_f;
@@ -424,11 +503,28 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_aggregate(const int4* __r
     if (t < n_tiles) {
         const int4 s = summ[t];
         f = fn_of(s);
-        h.h = s.z; h.c = s.w;
+        h.h = s.z; h.c = s.w & 1;
     }
     Fn64 ef, tf; Hd64 eh, th;
     block_scan(f, h, L, &ef, &eh, &tf, &th);
     if (threadIdx.x == 0) { agg_fn[blockIdx.x] = tf; agg_hd[blockIdx.x] = th; }
+}
+
+// clear mask bits [lo, hi) (clamped to limit); afterwards re-set the first / last bit of the range on request
+__device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t hi, int64_t limit, int keep_first,
+                                            int keep_last) {
+    if (hi > limit) hi = limit;
+    if (lo >= hi) return;
+    for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
+        const int64_t base = w << 6;
+        uint64_t m = ~0ull;
+        if (lo > base) m &= ~0ull << (lo - base);
+        if (hi < base + 64) m &= (1ull << (hi - base)) - 1ull;
+        uint64_t v = bits[w] & ~m;
+        if (keep_first && (lo >> 6) == w) v |= 1ull << (lo & 63);
+        if (keep_last && ((hi - 1) >> 6) == w) v |= 1ull << ((hi - 1) & 63);
+        bits[w] = v;
+    }
 }
 
 // stage 2b: one block per 1024 tiles.  Every block first composes the aggregates of the blocks before it (pending
@@ -437,6 +533,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_aggregate(const int4* __r
 __global__ __launch_bounds__(kScanThreads) void k_scan_resolve(const int4* __restrict__ summ, int64_t n_tiles,
                                                                const Fn64* __restrict__ agg_fn,
                                                                const Hd64* __restrict__ agg_hd, int n_blocks,
+                                                               uint64_t* __restrict__ patch_bits, int64_t total,
                                                                int64_t* __restrict__ fix_list, int* __restrict__ fix_q,
                                                                int* __restrict__ fix_tz, int64_t* __restrict__ fix_count) {
     __shared__ ScanLds L;
@@ -467,7 +564,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_resolve(const int4* __res
     if (t < n_tiles) {
         s = summ[t];
         f = fn_of(s);
-        h.h = s.z; h.c = s.w;
+        h.h = s.z; h.c = s.w & 1;
     }
     Fn64 ef, tf; Hd64 eh, th;
     block_scan(f, h, L, &ef, &eh, &tf, &th);
@@ -478,7 +575,19 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_resolve(const int4* __res
         const long long q_end = fn_apply(f, q_in);
         const long long h_next = hd_then(eh, rest).h;
         tz = (q_end + h_next) > 0;
-        need = q_in != 0 || tz != (s.y > 0);
+        const int tz0 = s.y > 0;
+        need = q_in != 0 || tz != tz0;
+        // Common cases are patched in place (bitmask mode): exactly one pending start entering a tile whose head
+        // block has no start of its own zeroes that head block; a tail block that turns out to be zeroed is cleared.
+        // What stays in a cleared block: the C_SYM bit of its last char and the bit of a string start.
+        const int geom = s.w;
+        if (need && patch_bits && (geom & 1) && q_in <= 1 && (q_in == 0 || s.z == 0)) {
+            const int64_t t0 = t * kTile;
+            const int64_t t_end = min(t0 + kTile, total);
+            if (q_in == 1) clear_range(patch_bits, t0, t0 + ((geom >> 1) & 0x1FFF), t_end, 0, (geom >> 27) & 1);
+            if (tz != tz0) clear_range(patch_bits, t0 + ((geom >> 14) & 0x1FFF), t_end, t_end, (geom >> 28) & 1, (geom >> 29) & 1);
+            need = 0;
+        }
     }
     // one atomic per wave (a single counter word saturates at a few dozen atomics per microsecond)
     const lk_u64 m = __ballot(need);
@@ -538,26 +647,42 @@ hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_ti
     return hipGetLastError();
 }
 
-hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
-    constexpr int WPB = kWavesPerBlockMain;
+template <int WPB, bool PF>
+static hipError_t launch_main_bits(const SplitParams& P, int n_cu, hipStream_t st) {
     const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
-    if (mode == kModeBits)
-        hipLaunchKernelGGL((k_split_tiles<kModeBits, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    hipLaunchKernelGGL((k_split_tiles<kModeBits, false, WPB, PF>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_summaries(const SplitParams& P, hipStream_t st) {
+hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
+    constexpr int WPB = kWavesPerBlockMain;
+    if (mode == kModeBits) {
+        static const int variant = [] { const char* e = getenv("LATOK_VARIANT"); return e ? atoi(e) : 0; }();
+        switch (variant) {   // experiment switch; 0 = shipped configuration
+            case 1: return launch_main_bits<16, false>(P, n_cu, st);
+            case 2: return launch_main_bits<12, true>(P, n_cu, st);
+            case 3: return launch_main_bits<8, true>(P, n_cu, st);
+            case 4: return launch_main_bits<12, false>(P, n_cu, st);
+            default: return launch_main_bits<WPB, kPrefetchMain>(P, n_cu, st);
+        }
+    }
+    const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
+    if (mode == kModeValues)
+        hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    else
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_summaries(const SplitParams& P, int mode, hipStream_t st) {
     const int n_blocks = (int)((P.n_tiles + kScanThreads - 1) / kScanThreads);
     Fn64* agg_fn = reinterpret_cast<Fn64*>(P.scan_agg);
     Hd64* agg_hd = reinterpret_cast<Hd64*>(P.scan_agg + (size_t)n_blocks * sizeof(Fn64));
     if (n_blocks > 1)
         hipLaunchKernelGGL(k_scan_aggregate, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd);
     hipLaunchKernelGGL(k_scan_resolve, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd,
-                       n_blocks, P.fix_list, P.fix_q, P.fix_tz, P.fix_count);
+                       n_blocks, mode == kModeBits ? P.bits_out : nullptr, P.total, P.fix_list, P.fix_q, P.fix_tz,
+                       P.fix_count);
     return hipGetLastError();
 }
 
@@ -567,11 +692,11 @@ hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_
     int blocks = blocks_for(P.n_tiles / 8 + 1, WPB, n_cu, 2);
     if (blocks > 2 * n_cu) blocks = 2 * n_cu;
     if (mode == kModeBits)
-        hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     else if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ struct TileSummary {
     int a, b;          // q transfer function of the tile
     int head_starts;   // starts before the first closing event of the tile
     int has_closing;
+    // geometry of the edge blocks (mirrors the packed `geom` word of the HIP kernel)
+    int c_rel, p_rel, head_sym, tail_keep, tail_sym;
 };
 
 inline uint32_t classify(uint32_t cp) {
@@ -45,7 +47,22 @@ struct Model {
     const int8_t* bm_a1 = nullptr;   // block-mask mode (compat _gen_block_mask): planes from byte arrays
     const int8_t* bm_a2 = nullptr;
     int8_t* bm_out = nullptr;
-    int64_t n_fix = 0;
+    int64_t n_fix = 0, n_patch = 0;
+
+    void clear_range(int64_t lo, int64_t hi, int64_t limit, int keep_first, int keep_last) {
+        if (hi > limit) hi = limit;
+        if (lo >= hi) return;
+        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
+            const int64_t base = w << 6;
+            uint64_t m = ~0ull;
+            if (lo > base) m &= ~0ull << (lo - base);
+            if (hi < base + 64) m &= (1ull << (hi - base)) - 1ull;
+            uint64_t v = bits[w] & ~m;
+            if (keep_first && (lo >> 6) == w) v |= 1ull << (lo & 63);
+            if (keep_last && ((hi - 1) >> 6) == w) v |= 1ull << ((hi - 1) & 63);
+            bits[w] = v;
+        }
+    }
 
     uint32_t code_at(int64_t p) const { return (cps && p >= 0 && p < total) ? classify(cps[p]) : 0u; }
 
@@ -117,6 +134,19 @@ struct Model {
         if (write_summary) {
             TileSummary& s = summ[(size_t)t];
             s.a = acc.a; s.b = acc.b; s.head_starts = head; s.has_closing = seen_closing;
+            s.c_rel = kTile; s.p_rel = 0; s.tail_keep = 0;
+            for (int j = 0; j < kLanes; ++j) {
+                const lk_u64 cl = loc[j].S | Bl[j];
+                if (!cl) continue;
+                if (s.c_rel == kTile) s.c_rel = 64 * j + lk_ctz(cl);
+                const int top = 63 - __builtin_clzll(cl);
+                const int s_top = (int)((loc[j].S >> top) & 1ull);
+                s.p_rel = 64 * j + top + s_top;
+                s.tail_keep = 1 - s_top;
+            }
+            const int hs = s.c_rel > 0 ? s.c_rel - 1 : 0;
+            s.head_sym = s.c_rel > 0 ? (int)((loc[hs >> 6].sym >> (hs & 63)) & 1ull) : 0;
+            s.tail_sym = (int)(loc[kLanes - 1].sym >> 63);
         }
         // backward fill, carry travels from lane 63 down to lane 0
         // tail_zero < 0: provisional decision = "a start is still pending at the tile end" (its closing event,
@@ -181,6 +211,16 @@ struct Model {
         for (int64_t t = 0; t < n_tiles; ++t) {
             const int tz0 = summ[(size_t)t].b > 0;
             if (q_in[(size_t)t] != 0 || tz[(size_t)t] != tz0) {
+                const TileSummary& sm = summ[(size_t)t];
+                if (bits && !values && !bm_out && sm.has_closing && q_in[(size_t)t] <= 1 &&
+                    (q_in[(size_t)t] == 0 || sm.head_starts == 0)) {
+                    // patch in place (mirrors k_scan_resolve)
+                    const int64_t t0 = t * kTile, t_end = std::min<int64_t>(t0 + kTile, total);
+                    if (q_in[(size_t)t] == 1) clear_range(t0, t0 + sm.c_rel, t_end, 0, sm.head_sym);
+                    if (tz[(size_t)t] != tz0) clear_range(t0 + sm.p_rel, t_end, t_end, sm.tail_keep, sm.tail_sym);
+                    ++n_patch;
+                    continue;
+                }
                 process_tile(t, (int)std::min<long long>(q_in[(size_t)t], 1 << 20), tz[(size_t)t], false);
                 ++n_fix;
             }
@@ -202,7 +242,7 @@ extern "C" int fused_split_batch(const uint32_t* cps, const int64_t* row_off, in
     m.values = values_out;
     m.bits = bits_out;
     m.run();
-    if (n_fix_out) *n_fix_out = m.n_fix;
+    if (n_fix_out) *n_fix_out = m.n_fix + m.n_patch;
     return 0;
 }
 

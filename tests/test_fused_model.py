@@ -44,6 +44,10 @@ def test_model_matches_oracle(model, oracle, kind, n, lo, hi):
         mv, mb, nf = run_model(model, cps, row)
         fixed += nf
         assert np.array_equal(ov, mv) and np.array_equal(ob, mb)
+        # bitmask-only mode takes the patch-in-place path of the scan stage for the common fix-up cases
+        pb = np.zeros_like(mb)
+        assert model.fused_split_batch(cps.ctypes.data, row.ctypes.data, len(row) - 1, None, pb.ctypes.data, None) == 0
+        assert np.array_equal(ob, pb)
     if kind in ("nospace_at", "rare_space_at"):
         assert fixed > 0, "the fix-up stage was never exercised"
 

@@ -17,7 +17,7 @@ constexpr int kStageBytes = 64 * 80;     // 64 rows of 64 code bytes + 16 B pad 
 constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo + string-start words = 5664
 constexpr int kWavesPerBlockMain = 16;   // 1024 threads, one block per CU: 41360 + 16*5664 = 131984 B of LDS
 constexpr int kWavesPerBlockFix = 4;
-constexpr bool kPrefetchMain = false;    // main kernel keeps the next tile's 16 KiB of loads in flight under phase 2
+constexpr int kPrefetchMain = 0;         // main kernel keeps the next tile's 16 KiB of loads in flight under phase 2
 
 constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;

@@ -49,6 +49,47 @@ LATOK_HD lk_u64 lk_transpose8(lk_u64 x) {
 }
 
 // 64 code bytes (d[k] = chars 4k..4k+3, little endian) -> 8 planes; plane[b] bit i = bit b of char i's code.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Device form: the same three delta-swap stages written on 32-bit halves, then the byte regrouping done with
+// v_perm_b32 (one instruction per output dword half-pair) instead of shift/mask chains.
+__device__ __forceinline__ void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
+    uint32_t lo[8], hi[8];   // after the transposes: byte b of lo[g] = plane b (b < 4), of hi[g] = plane 4 + b, chars 8g..8g+7
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        uint32_t a = d[2 * g], b = d[2 * g + 1], t;
+        t = (a ^ (a >> 7)) & 0x00AA00AAu;  a ^= t ^ (t << 7);
+        t = (b ^ (b >> 7)) & 0x00AA00AAu;  b ^= t ^ (t << 7);
+        t = (a ^ (a >> 14)) & 0x0000CCCCu; a ^= t ^ (t << 14);
+        t = (b ^ (b >> 14)) & 0x0000CCCCu; b ^= t ^ (t << 14);
+        // stage 3 of the 64-bit form: t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0 ; x ^= t ^ (t << 28)
+        t = (a ^ ((a >> 28) | (b << 4))) & 0xF0F0F0F0u;
+        a ^= t ^ (t << 28);
+        b ^= (t >> 4);
+        lo[g] = a;
+        hi[g] = b;
+    }
+    // 4x4 byte transposes: out[b] = {x0.byte b, x1.byte b, x2.byte b, x3.byte b}
+#define LK_T4(x0, x1, x2, x3, o0, o1, o2, o3)                                   \
+    {                                                                           \
+        const uint32_t e01 = __builtin_amdgcn_perm(x1, x0, 0x06020400u);        \
+        const uint32_t o01 = __builtin_amdgcn_perm(x1, x0, 0x07030501u);        \
+        const uint32_t e23 = __builtin_amdgcn_perm(x3, x2, 0x06020400u);        \
+        const uint32_t o23 = __builtin_amdgcn_perm(x3, x2, 0x07030501u);        \
+        o0 = __builtin_amdgcn_perm(e23, e01, 0x05040100u);                      \
+        o2 = __builtin_amdgcn_perm(e23, e01, 0x07060302u);                      \
+        o1 = __builtin_amdgcn_perm(o23, o01, 0x05040100u);                      \
+        o3 = __builtin_amdgcn_perm(o23, o01, 0x07060302u);                      \
+    }
+    uint32_t pl[8], ph[8];
+    LK_T4(lo[0], lo[1], lo[2], lo[3], pl[0], pl[1], pl[2], pl[3]);
+    LK_T4(lo[4], lo[5], lo[6], lo[7], ph[0], ph[1], ph[2], ph[3]);
+    LK_T4(hi[0], hi[1], hi[2], hi[3], pl[4], pl[5], pl[6], pl[7]);
+    LK_T4(hi[4], hi[5], hi[6], hi[7], ph[4], ph[5], ph[6], ph[7]);
+#undef LK_T4
+#pragma unroll
+    for (int b = 0; b < 8; ++b) plane[b] = (lk_u64)pl[b] | ((lk_u64)ph[b] << 32);
+}
+#else
 LATOK_HD void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
     lk_u64 y[8];
 #pragma unroll
@@ -61,6 +102,7 @@ LATOK_HD void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
         plane[b] = p;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Features of one word, decoded from the split-code planes (split_code.h).
@@ -89,15 +131,6 @@ LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
 struct lk_halo {
     uint32_t prev, next0, next1;
 };
-
-LATOK_HD lk_u64 lk_code_bit(uint32_t code, int feature /* index into lk_feat order */) {
-    lk_u64 p[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) p[b] = (code >> b) & 1u;
-    lk_feat f = lk_decode(p);
-    const lk_u64* a = &f.S;
-    return a[feature] & 1ull;
-}
 
 // outputs of the purely local rules for one word
 struct lk_local {

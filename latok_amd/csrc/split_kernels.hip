@@ -129,7 +129,9 @@ struct TileLds {
 // PF: software prefetch.  `v` carries the 16 KiB of code points of a full tile in registers; when `v_valid` the loads
 // for THIS tile were issued while the previous tile was in phase 2.  After classifying, the loads of tile `t_next` are
 // issued so that they fly under this tile's phase 2.  Returns whether `v` now holds tile `t_next`.
-template <int MODE, bool PF>
+// VMODE 0: the tile's loads are issued here.  1: `v` was loaded by the caller (first tile of a wave, requested before
+// the table copy).  2 (= PF): runtime `v_valid`, and the next tile's loads are issued after classification.
+template <int MODE, int VMODE>
 __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
                                              bool write_summary, int lane, u32x4 (&v)[16], bool v_valid,
                                              int64_t t_next) {
@@ -151,7 +153,35 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
     } else if (t0 + kTile <= total) {
-        if (!(PF && v_valid)) {
+        if (VMODE == 3) {
+            // half prefetch: v[0..7] (first 8 KiB) may already be here; the second half is requested now and is
+            // classified after the first
+            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+            u32x4 w[8];
+            if (!v_valid) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = __builtin_nontemporal_load(src + 64 * (8 + i));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t c = classify4(L.t1, L.t2, v[i]);
+                *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t c = classify4(L.t1, L.t2, w[i]);
+                *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * (8 + i) + 4u * lane)) = c;
+            }
+            if (t_next >= 0 && (t_next + 1) * kTile <= total) {
+                const u32x4* nsrc = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
+                next_valid = true;
+            }
+        } else {
+        if (VMODE == 0 || (VMODE == 2 && !v_valid)) {
             const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
@@ -161,11 +191,12 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
             *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
         }
-        if (PF && t_next >= 0 && (t_next + 1) * kTile <= total) {
+        if (VMODE == 2 && t_next >= 0 && (t_next + 1) * kTile <= total) {
             const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
             next_valid = true;
+        }
         }
     } else {
 #pragma unroll 1
@@ -351,7 +382,7 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
 // stage 1 / stage 3 kernel.  FIX = false: all tiles, grid-stride, q_in = 0, provisional tail, writes summaries.
 //                            FIX = true : only the tiles listed by k_scan_summaries, with their exact inputs.
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool FIX, int WPB, bool PREFETCH>
+template <int MODE, bool FIX, int WPB, int PREFETCH>
 __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kTablesLdsBytes + WPB * kWaveLdsBytes];
 
@@ -359,6 +390,21 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     if (FIX) {
         n_items = *P.fix_count;
         if (n_items == 0) return;  // uniform: nothing to repair, skip the table load
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar tile arithmetic
+    const int64_t wave_gid = (int64_t)blockIdx.x * WPB + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * WPB;
+
+    // the first tile's 16 KiB of code points are requested before anything else, so that HBM latency overlaps the
+    // table copy and the barrier below
+    u32x4 v[16];
+    bool v_valid = false;
+    if (!FIX && MODE != kModeBlockMask && wave_gid < n_items && (wave_gid + 1) * kTile <= P.total) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + wave_gid * kTile) + lane;
+#pragma unroll
+        for (int i = 0; i < (PREFETCH == 3 ? 8 : 16); ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        v_valid = true;
     }
     // cooperative table load (global/L2 -> LDS), 16 B per thread per step
     if (MODE != kModeBlockMask) {
@@ -371,8 +417,6 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar tile arithmetic
     TileLds L;
     L.t1 = lds;
     L.t2 = lds + kStage1Pad;
@@ -381,18 +425,21 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
 
-    const int64_t wave_gid = (int64_t)blockIdx.x * WPB + wave;
-    const int64_t n_waves = (int64_t)gridDim.x * WPB;
-    u32x4 v[16];
-    bool v_valid = false;
-    for (int64_t i = wave_gid; i < n_items; i += n_waves) {
-        if (FIX) {
-            const int64_t t = P.fix_list[i];
-            process_tile<MODE, false>(P, L, t, P.fix_q[i], P.fix_tz[i], false, lane, v, false, -1);
-        } else {
+    int64_t i = wave_gid;
+    if (FIX) {
+        for (; i < n_items; i += n_waves)
+            process_tile<MODE, 0>(P, L, P.fix_list[i], P.fix_q[i], P.fix_tz[i], false, lane, v, false, -1);
+    } else if (PREFETCH != 0) {
+        for (; i < n_items; i += n_waves) {
             const int64_t nxt = i + n_waves < n_items ? i + n_waves : -1;
             v_valid = process_tile<MODE, PREFETCH>(P, L, i, 0, -1, true, lane, v, v_valid, nxt);
         }
+    } else {
+        if (v_valid) {   // first tile: its loads were requested before the table copy
+            process_tile<MODE, 1>(P, L, i, 0, -1, true, lane, v, true, -1);
+            i += n_waves;
+        }
+        for (; i < n_items; i += n_waves) process_tile<MODE, 0>(P, L, i, 0, -1, true, lane, v, false, -1);
     }
 }
 
@@ -647,7 +694,7 @@ hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_ti
     return hipGetLastError();
 }
 
-template <int WPB, bool PF>
+template <int WPB, int PF>
 static hipError_t launch_main_bits(const SplitParams& P, int n_cu, hipStream_t st) {
     const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
     hipLaunchKernelGGL((k_split_tiles<kModeBits, false, WPB, PF>), dim3(blocks), dim3(WPB * 64), 0, st, P);
@@ -659,18 +706,19 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     if (mode == kModeBits) {
         static const int variant = [] { const char* e = getenv("LATOK_VARIANT"); return e ? atoi(e) : 0; }();
         switch (variant) {   // experiment switch; 0 = shipped configuration
-            case 1: return launch_main_bits<16, false>(P, n_cu, st);
-            case 2: return launch_main_bits<12, true>(P, n_cu, st);
-            case 3: return launch_main_bits<8, true>(P, n_cu, st);
-            case 4: return launch_main_bits<12, false>(P, n_cu, st);
+            case 1: return launch_main_bits<16, 0>(P, n_cu, st);
+            case 2: return launch_main_bits<12, 2>(P, n_cu, st);
+            case 3: return launch_main_bits<8, 2>(P, n_cu, st);
+            case 4: return launch_main_bits<12, 0>(P, n_cu, st);
+            case 5: return launch_main_bits<12, 3>(P, n_cu, st);
             default: return launch_main_bits<WPB, kPrefetchMain>(P, n_cu, st);
         }
     }
     const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
     if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 
@@ -692,11 +740,11 @@ hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_
     int blocks = blocks_for(P.n_tiles / 8 + 1, WPB, n_cu, 2);
     if (blocks > 2 * n_cu) blocks = 2 * n_cu;
     if (mode == kModeBits)
-        hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     else if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB, false>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
     return hipGetLastError();
 }
 

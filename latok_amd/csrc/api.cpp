@@ -1,7 +1,7 @@
 // api.cpp -- host side of liblatok_hip.so: the C ABI declared in include/latok_hip.h.
 //
 // Thin by design: argument checks, workspace management, H2D/D2H staging for host-pointer calls, and the launch
-// sequence of the four-stage pipeline (tile index -> tiles -> summary scan -> fix-up).  No compute happens on the
+// sequence of the two-stage pipeline (tiles -> resolve/repair).  No compute happens on the
 // host and there is no CPU fallback: without a HIP device every compute entry point fails.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -74,7 +74,7 @@ struct Ctx {
     // tables
     DevBuf t1, t2code, t2cls, cw;
     // pipeline workspace (sized by tiles)
-    DevBuf tile_first, summ, tile_q, fix_list, fix_q, fix_tz, fix_count;
+    DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, counts, bases, scalar, h_aux;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -83,12 +83,8 @@ struct Ctx {
 int ensure_workspace(int64_t n_tiles) {
     const size_t t = (size_t)(n_tiles > 0 ? n_tiles : 1);
     int rc;
-    if ((rc = g.tile_first.ensure(t * 8))) return rc;
     if ((rc = g.summ.ensure(t * 16))) return rc;
-    if ((rc = g.tile_q.ensure((t / 1024 + 2) * 32))) return rc;   // block aggregates of the summary scan
-    if ((rc = g.fix_list.ensure(t * 8))) return rc;
-    if ((rc = g.fix_q.ensure(t * 4))) return rc;
-    if ((rc = g.fix_tz.ensure(t * 4))) return rc;
+    if ((rc = g.seg_agg.ensure((t / 16 + 2) * 32))) return rc;   // <= one 32-byte aggregate pair per 16 tiles
     if ((rc = g.fix_count.ensure(8))) return rc;
     return LATOK_OK;
 }
@@ -98,7 +94,7 @@ int need_init() {
     return LATOK_OK;
 }
 
-// enqueue the four-stage pipeline on device-resident data
+// enqueue the pipeline on device-resident data
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
@@ -113,26 +109,22 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.n_str = n_str;
     P.total = total;
     P.n_tiles = n_tiles;
-    P.tile_first = (const int64_t*)g.tile_first.p;
+    latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
     P.t1 = (const uint8_t*)g.t1.p;
     P.t2 = (const uint8_t*)g.t2code.p;
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.summ = (int4*)g.summ.p;
-    P.scan_agg = (unsigned char*)g.tile_q.p;
-    P.fix_list = (int64_t*)g.fix_list.p;
-    P.fix_q = (int*)g.fix_q.p;
-    P.fix_tz = (int*)g.fix_tz.p;
+    P.seg_fn = (latok::Fn64*)g.seg_agg.p;
+    P.seg_hd = (latok::Hd64*)((char*)g.seg_agg.p + (size_t)P.n_segs * sizeof(latok::Fn64));
     P.fix_count = (int64_t*)g.fix_count.p;
     P.bm_a1 = bm_a1;
     P.bm_a2 = bm_a2;
     P.bm_flags = bm_flags;
-    HIP_TRY(latok::launch_tile_index(d_row, n_str, n_tiles, (int64_t*)g.tile_first.p, P.fix_count, st));
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
     HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
     if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));
-    HIP_TRY(latok::launch_scan_summaries(P, mode, st));
-    HIP_TRY(latok::launch_fix_tiles(P, mode, g.n_cu, st));
+    HIP_TRY(latok::launch_resolve_fix(P, mode, g.n_cu, st));
     return LATOK_OK;
 }
 
@@ -243,8 +235,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.tile_first, &g.summ, &g.tile_q, &g.fix_list, &g.fix_q,
-                      &g.fix_tz, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.counts, &g.bases, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.counts, &g.bases, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {

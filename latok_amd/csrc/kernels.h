@@ -15,42 +15,47 @@ constexpr int kStage2Len = 255 * 128;    // 32640, multiple of 16
 constexpr int kTablesLdsBytes = kStage1Pad + kStage2Len;   // 41360
 constexpr int kStageBytes = 64 * 80;     // 64 rows of 64 code bytes + 16 B pad (conflict-free ds_read_b128)
 constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo + string-start words = 5664
-constexpr int kWavesPerBlockMain = 16;   // 1024 threads, one block per CU: 41360 + 16*5664 = 131984 B of LDS
-constexpr int kWavesPerBlockFix = 4;
-constexpr int kPrefetchMain = 0;         // main kernel keeps the next tile's 16 KiB of loads in flight under phase 2
 
 constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;
 constexpr int kModeBlockMask = 2;        // compat _gen_block_mask: planes from caller byte arrays, byte mask out
 
 constexpr long long kNegInf64 = -(1ll << 60);
+constexpr int kWPB = 12;                 // waves per workgroup: 768 threads -> 168 VGPRs per lane, one workgroup per CU
+constexpr int kSegMax = kWPB * 64;       // tiles per segment = threads of the block-wide scans
+
+struct Fn64 {        // q transfer function of a run of tiles: f(q) = max(q + a, b); a <= kNegInf64 means constant b
+    long long a, b;
+};
+struct Hd64 {        // head descriptor of a run of tiles: starts before its first closing event, and whether it has one
+    long long h;
+    int c;
+};
 
 struct SplitParams {
     const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
     const int64_t* row_off;     // [n_str + 1]
     int64_t n_str, total, n_tiles;
-    const int64_t* tile_first;  // [n_tiles]
+    int seg_tiles;              // tiles per segment (16..1024)
+    int64_t n_segs;             // ceil(n_tiles / seg_tiles)
     const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
     const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
     uint64_t* bits_out;         // kModeBits
-    uint8_t* values_out;        // kModeValues
+    uint8_t* values_out;        // kModeValues / kModeBlockMask
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
-    unsigned char* scan_agg;    // [ceil(n_tiles/1024)] x 32 B block aggregates of the summary scan
-    int64_t* fix_list;          // [n_tiles]
-    int* fix_q;                 // [n_tiles]
-    int* fix_tz;                // [n_tiles]
-    int64_t* fix_count;         // [1]
+    Fn64* seg_fn;               // [n_segs] segment aggregates
+    Hd64* seg_hd;               // [n_segs]
+    int64_t* fix_count;         // [1] statistics: tiles recomputed by the resolve stage
     // kModeBlockMask only
     const int8_t* bm_a1;        // "starts" bytes [total]
     const int8_t* bm_a2;        // "spaces" bytes [total]
     const int* bm_flags;        // {any(a1), any(a2)}
 };
 
-hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
-                             int64_t* fix_count, hipStream_t st);
+
+void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs);
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
-hipError_t launch_scan_summaries(const SplitParams& P, int mode, hipStream_t st);
-hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st);
 
 // aux_kernels.hip

@@ -68,6 +68,13 @@ __device__ __forceinline__ int dpp_mov(int old, int src) {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
 }
 __device__ __forceinline__ int lane_read(int v, int uniform_lane) { return __builtin_amdgcn_readlane(v, uniform_lane); }
+// values that are wave-uniform by construction but live in VGPRs: move them to SGPRs
+__device__ __forceinline__ int to_scalar(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t to_scalar64(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ int64_t lane_read64(int64_t v, int uniform_lane) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, uniform_lane);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), uniform_lane);
@@ -102,20 +109,6 @@ __device__ __forceinline__ lk_qfn qfn_wave_scan(lk_qfn f) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// stage 0: tile_first[t] = index of the first string whose start offset is >= t * kTile
-// (one thread per row_off entry, including the end sentinel row_off[n_str])
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void k_tile_index(const int64_t* __restrict__ row_off, int64_t n_str, int64_t n_tiles,
-                             int64_t* __restrict__ tile_first, int64_t* __restrict__ fix_count) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) *fix_count = 0;   // consumed two launches later by the summary scan
-    if (s > n_str) return;
-    const int64_t cur = row_off[s] / kTile;
-    const int64_t prev = s > 0 ? row_off[s - 1] / kTile : -1;
-    for (int64_t w = prev + 1; w <= cur && w < n_tiles; ++w) tile_first[w] = s;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // the tile function
 // ---------------------------------------------------------------------------------------------------------------
 struct TileLds {
@@ -129,19 +122,18 @@ struct TileLds {
 // PF: software prefetch.  `v` carries the 16 KiB of code points of a full tile in registers; when `v_valid` the loads
 // for THIS tile were issued while the previous tile was in phase 2.  After classifying, the loads of tile `t_next` are
 // issued so that they fly under this tile's phase 2.  Returns whether `v` now holds tile `t_next`.
-// VMODE 0: the tile's loads are issued here.  1: `v` was loaded by the caller (first tile of a wave, requested before
-// the table copy).  2 (= PF): runtime `v_valid`, and the next tile's loads are issued after classification.
-template <int MODE, int VMODE>
-__device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
-                                             bool write_summary, int lane, u32x4 (&v)[16], bool v_valid,
-                                             int64_t t_next) {
+// idx0 = index of the first string that starts at or after the tile's first char.
+// PRELOADED: the caller already requested the tile's 16 KiB into `vin` (first tile of a workgroup's first segment).
+// The tile summary goes to global memory (for the resolve stage) and, when summ_l != nullptr, to the block's LDS copy.
+template <int MODE, bool PRELOADED = false>
+__device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
+                                             int tail_zero, bool write_summary, int4* summ_l, int lane,
+                                             const u32x4* vin = nullptr) {
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
-    bool next_valid = false;
 
-    // small loads first, so that their latency flies together with the 16 KiB of code points: the first string that
-    // starts in this tile, the start offsets of the next 64 strings, and the three halo characters
-    int64_t idx0 = P.tile_first[t];
+    // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
+    // the next 64 strings and the three halo characters
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
     if (MODE != kModeBlockMask && lane < 3) {
@@ -153,35 +145,11 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
     } else if (t0 + kTile <= total) {
-        if (VMODE == 3) {
-            // half prefetch: v[0..7] (first 8 KiB) may already be here; the second half is requested now and is
-            // classified after the first
-            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-            u32x4 w[8];
-            if (!v_valid) {
+        u32x4 v[16];
+        if (PRELOADED) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = __builtin_nontemporal_load(src + 64 * (8 + i));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t c = classify4(L.t1, L.t2, v[i]);
-                *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t c = classify4(L.t1, L.t2, w[i]);
-                *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * (8 + i) + 4u * lane)) = c;
-            }
-            if (t_next >= 0 && (t_next + 1) * kTile <= total) {
-                const u32x4* nsrc = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
-                next_valid = true;
-            }
+            for (int i = 0; i < 16; ++i) v[i] = vin[i];
         } else {
-        if (VMODE == 0 || (VMODE == 2 && !v_valid)) {
             const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
@@ -190,13 +158,6 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
             *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
-        }
-        if (VMODE == 2 && t_next >= 0 && (t_next + 1) * kTile <= total) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-            next_valid = true;
-        }
         }
     } else {
 #pragma unroll 1
@@ -316,7 +277,9 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
         if (lane == 0) {
             const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
                              (tail_sym << 29);
-            P.summ[t] = make_int4(tile_fn.a, tile_fn.b, head, geom);
+            const int4 sv = make_int4(tile_fn.a, tile_fn.b, head, geom);
+            P.summ[t] = sv;
+            if (summ_l) *summ_l = sv;
         }
     }
 
@@ -375,72 +338,6 @@ __device__ __forceinline__ bool process_tile(const SplitParams& P, const TileLds
         }
     }
     wave_lds_sync();  // staging buffer is reused by this wave's next tile
-    return next_valid;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// stage 1 / stage 3 kernel.  FIX = false: all tiles, grid-stride, q_in = 0, provisional tail, writes summaries.
-//                            FIX = true : only the tiles listed by k_scan_summaries, with their exact inputs.
-// ---------------------------------------------------------------------------------------------------------------
-template <int MODE, bool FIX, int WPB, int PREFETCH>
-__global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kTablesLdsBytes + WPB * kWaveLdsBytes];
-
-    int64_t n_items = P.n_tiles;
-    if (FIX) {
-        n_items = *P.fix_count;
-        if (n_items == 0) return;  // uniform: nothing to repair, skip the table load
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> scalar tile arithmetic
-    const int64_t wave_gid = (int64_t)blockIdx.x * WPB + wave;
-    const int64_t n_waves = (int64_t)gridDim.x * WPB;
-
-    // the first tile's 16 KiB of code points are requested before anything else, so that HBM latency overlaps the
-    // table copy and the barrier below
-    u32x4 v[16];
-    bool v_valid = false;
-    if (!FIX && MODE != kModeBlockMask && wave_gid < n_items && (wave_gid + 1) * kTile <= P.total) {
-        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + wave_gid * kTile) + lane;
-#pragma unroll
-        for (int i = 0; i < (PREFETCH == 3 ? 8 : 16); ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-        v_valid = true;
-    }
-    // cooperative table load (global/L2 -> LDS), 16 B per thread per step
-    if (MODE != kModeBlockMask) {
-        const uint4* s1 = reinterpret_cast<const uint4*>(P.t1);
-        uint4* d1 = reinterpret_cast<uint4*>(lds);
-        for (int i = threadIdx.x; i < kStage1Pad / 16; i += WPB * 64) d1[i] = s1[i];
-        const uint4* s2 = reinterpret_cast<const uint4*>(P.t2);
-        uint4* d2 = reinterpret_cast<uint4*>(lds + kStage1Pad);
-        for (int i = threadIdx.x; i < kStage2Len / 16; i += WPB * 64) d2[i] = s2[i];
-    }
-    __syncthreads();
-
-    TileLds L;
-    L.t1 = lds;
-    L.t2 = lds + kStage1Pad;
-    uint8_t* mine = lds + kTablesLdsBytes + wave * kWaveLdsBytes;
-    L.stage = mine;
-    L.halo = mine + kStageBytes;
-    L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
-
-    int64_t i = wave_gid;
-    if (FIX) {
-        for (; i < n_items; i += n_waves)
-            process_tile<MODE, 0>(P, L, P.fix_list[i], P.fix_q[i], P.fix_tz[i], false, lane, v, false, -1);
-    } else if (PREFETCH != 0) {
-        for (; i < n_items; i += n_waves) {
-            const int64_t nxt = i + n_waves < n_items ? i + n_waves : -1;
-            v_valid = process_tile<MODE, PREFETCH>(P, L, i, 0, -1, true, lane, v, v_valid, nxt);
-        }
-    } else {
-        if (v_valid) {   // first tile: its loads were requested before the table copy
-            process_tile<MODE, 1>(P, L, i, 0, -1, true, lane, v, true, -1);
-            i += n_waves;
-        }
-        for (; i < n_items; i += n_waves) process_tile<MODE, 0>(P, L, i, 0, -1, true, lane, v, false, -1);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -449,9 +346,6 @@ __global__ __launch_bounds__(WPB * 64) void k_split_tiles(SplitParams P) {
 // next closing event: backward scan).  Tiles whose provisional assumptions (q_in == 0, tail = "pending at end") do
 // not hold are appended to the fix list.  One workgroup; each thread owns a contiguous chunk of tiles.
 // ---------------------------------------------------------------------------------------------------------------
-struct Fn64 {
-    long long a, b;  // f(q) = max(q + a, b); a <= kNegInf64 means constant b
-};
 __device__ __forceinline__ Fn64 fn_then(Fn64 f1, Fn64 f2) {
     Fn64 f;
     const bool c1 = f1.a <= kNegInf64, c2 = f2.a <= kNegInf64;
@@ -473,10 +367,6 @@ __device__ __forceinline__ Fn64 fn_of(int4 s) {
     return f;
 }
 // backward element: (has_closing, head_starts); (c1,h1) followed by (c2,h2) = (c1|c2, c1 ? h1 : h1+h2)
-struct Hd64 {
-    long long h;
-    int c;
-};
 __device__ __forceinline__ Hd64 hd_then(Hd64 x, Hd64 y) {
     Hd64 r;
     r.c = x.c | y.c;
@@ -484,8 +374,8 @@ __device__ __forceinline__ Hd64 hd_then(Hd64 x, Hd64 y) {
     return r;
 }
 
-constexpr int kScanThreads = 1024;   // tiles per scan block
-constexpr int kScanWaves = kScanThreads / 64;
+constexpr int kScanThreads = kWPB * 64;   // one element per thread of the workgroup
+constexpr int kScanWaves = kWPB;
 
 __device__ __forceinline__ Fn64 fn_identity() { Fn64 f; f.a = 0; f.b = 0; return f; }   // identity on q >= 0
 __device__ __forceinline__ Hd64 hd_identity() { Hd64 h; h.h = 0; h.c = 0; return h; }
@@ -540,22 +430,6 @@ __device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLds& L, Fn64* exc
     *tot_hd = all_h;
 }
 
-// stage 2a: one block per 1024 tiles -> block aggregates (transfer function of the block, head descriptor of the block)
-__global__ __launch_bounds__(kScanThreads) void k_scan_aggregate(const int4* __restrict__ summ, int64_t n_tiles,
-                                                                 Fn64* __restrict__ agg_fn, Hd64* __restrict__ agg_hd) {
-    __shared__ ScanLds L;
-    const int64_t t = (int64_t)blockIdx.x * kScanThreads + threadIdx.x;
-    Fn64 f = fn_identity();
-    Hd64 h = hd_identity();
-    if (t < n_tiles) {
-        const int4 s = summ[t];
-        f = fn_of(s);
-        h.h = s.z; h.c = s.w & 1;
-    }
-    Fn64 ef, tf; Hd64 eh, th;
-    block_scan(f, h, L, &ef, &eh, &tf, &th);
-    if (threadIdx.x == 0) { agg_fn[blockIdx.x] = tf; agg_hd[blockIdx.x] = th; }
-}
 
 // clear mask bits [lo, hi) (clamped to limit); afterwards re-set the first / last bit of the range on request
 __device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t hi, int64_t limit, int keep_first,
@@ -574,81 +448,284 @@ __device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t 
     }
 }
 
-// stage 2b: one block per 1024 tiles.  Every block first composes the aggregates of the blocks before it (pending
-// starts entering the block) and after it (starts before the next closing after the block), then resolves its own
-// tiles and appends the ones whose provisional assumptions were wrong to the fix list.
-__global__ __launch_bounds__(kScanThreads) void k_scan_resolve(const int4* __restrict__ summ, int64_t n_tiles,
-                                                               const Fn64* __restrict__ agg_fn,
-                                                               const Hd64* __restrict__ agg_hd, int n_blocks,
-                                                               uint64_t* __restrict__ patch_bits, int64_t total,
-                                                               int64_t* __restrict__ fix_list, int* __restrict__ fix_q,
-                                                               int* __restrict__ fix_tz, int64_t* __restrict__ fix_count) {
-    __shared__ ScanLds L;
-    const int b = blockIdx.x;
-    // (1) aggregates of the other blocks, contiguous range per thread, ordered
-    Fn64 pf = fn_identity();
-    Hd64 sh = hd_identity();
-    if (n_blocks > 1) {
-        const int per = (n_blocks + kScanThreads - 1) / kScanThreads;
-        const int lo = min((int)threadIdx.x * per, n_blocks), hi = min(lo + per, n_blocks);
+// ---------------------------------------------------------------------------------------------------------------
+// lower_bound over the row offsets: smallest s in [0, n_entries] with row_off[s] >= c (n_entries if none).
+// k-ary search: every thread of the block (or lane of the wave) probes one position per round, so 1 M strings need
+// two rounds (block) / four rounds (wave) of one L2 access each.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t block_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
+                                                     int* scratch /* >= blockDim.x / 64 ints of LDS */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NT = blockDim.x, NW = NT >> 6;
+    int64_t lo = 0, hi = n_entries;
+    while (hi > lo) {
+        const int64_t len = hi - lo;
+        const int64_t step = (len + NT - 1) / NT;
+        const int64_t p = lo + (int64_t)tid * step;
+        const bool pred = p < hi && row_off[p] >= c;
+        const lk_u64 m = __ballot(pred);
+        __syncthreads();
+        if (lane == 0) scratch[wave] = m ? wave * 64 + lk_ctz(m) : NT;
+        __syncthreads();
+        int f = NT;
+        for (int w = 0; w < NW; ++w) f = min(f, scratch[w]);
+        if (f == NT) {
+            const int64_t n_valid = (len + step - 1) / step;
+            lo = min(lo + (n_valid - 1) * step + 1, hi);   // everything probed is < c
+        } else {
+            hi = lo + (int64_t)f * step;                   // row_off[hi] >= c
+            if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+        }
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t wave_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
+                                                    int lane) {
+    int64_t lo = 0, hi = n_entries;
+    while (hi > lo) {
+        const int64_t len = hi - lo;
+        const int64_t step = (len + 63) / 64;
+        const int64_t p = lo + (int64_t)lane * step;
+        const bool pred = p < hi && row_off[p] >= c;
+        const lk_u64 m = __ballot(pred);
+        if (!m) {
+            const int64_t n_valid = (len + step - 1) / step;
+            lo = min(lo + (n_valid - 1) * step + 1, hi);
+        } else {
+            const int f = lk_ctz(m);
+            hi = lo + (int64_t)f * step;
+            if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+        }
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS map of both kernels (one workgroup of kWPB waves per CU)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLdsWaves = kTablesLdsBytes;                         // 16 x kWaveLdsBytes
+constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSegMax]: first string of each tile of the segment
+constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
+constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
+constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
+constexpr int kLdsTotal = kLdsMisc + 256;
+static_assert(sizeof(ScanLds) <= 512, "scan scratch");
+static_assert(kSegMax == kWPB * 64, "one tile per thread in the block-wide scans");
+static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
+static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0, "alignment");
+
+__device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) {
+    const uint4* s1 = reinterpret_cast<const uint4*>(P.t1);
+    uint4* d1 = reinterpret_cast<uint4*>(lds);
+    for (int i = threadIdx.x; i < kStage1Pad / 16; i += kWPB * 64) d1[i] = s1[i];
+    const uint4* s2 = reinterpret_cast<const uint4*>(P.t2);
+    uint4* d2 = reinterpret_cast<uint4*>(lds + kStage1Pad);
+    for (int i = threadIdx.x; i < kStage2Len / 16; i += kWPB * 64) d2[i] = s2[i];
+}
+
+__device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
+    TileLds L;
+    L.t1 = lds;
+    L.t2 = lds + kStage1Pad;
+    uint8_t* mine = lds + kLdsWaves + wave * kWaveLdsBytes;
+    L.stage = mine;
+    L.halo = mine + kStageBytes;
+    L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 1: the tiles.  The tile range is cut into segments of P.seg_tiles (<= 1024) consecutive tiles; a workgroup
+// owns whole segments (grid-stride), its 16 waves take the segment's tiles round-robin.  Per segment the workgroup
+//   (a) finds the first string of the segment with a block-wide k-ary search over row_off and derives, in LDS, the
+//       first string of every tile (this replaces a separate indexing pass over row_off),
+//   (b) runs the tiles, each publishing its 16-byte summary to LDS and to global memory,
+//   (c) composes the segment's transfer function / head descriptor with a block-wide scan -> one aggregate per segment.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE, bool FIRST>
+__device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane, int wave,
+                                            const u32x4* v, bool v_valid) {
+    const int S = P.seg_tiles;
+    const TileLds L = wave_lds(lds, wave);
+    int* tf = reinterpret_cast<int*>(lds + kLdsTf);
+    int4* sm = reinterpret_cast<int4*>(lds + kLdsSumm);
+    ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
+    int* misc = reinterpret_cast<int*>(lds + kLdsMisc);
+
+    const int64_t T0 = seg * S;
+    const int64_t T1 = min(T0 + S, P.n_tiles);
+    const int n_seg = (int)(T1 - T0);
+    // (a) first string of the segment, then of each of its tiles
+    const int64_t s_lo = to_scalar64(block_lower_bound(P.row_off, P.n_str + 1, T0 * kTile, misc));
+    {
+        const int64_t c1 = T1 * kTile;
+        for (int64_t chunk = s_lo;; chunk += kWPB * 64) {
+            const int64_t s = chunk + tid;
+            int passed = 1;
+            if (s <= P.n_str) {
+                const int64_t p = P.row_off[s];
+                const int64_t prev = s > 0 ? P.row_off[s - 1] : -1;
+                int64_t w0 = (prev < 0 ? 0 : prev / kTile + 1);
+                int64_t w1 = p / kTile;
+                if (w0 < T0) w0 = T0;
+                if (w1 > T1 - 1) w1 = T1 - 1;
+                for (int64_t w = w0; w <= w1; ++w) tf[w - T0] = (int)(s - s_lo);
+                passed = p >= c1 || s == P.n_str;
+            }
+            if (__syncthreads_or(passed)) break;
+        }
+    }
+    __syncthreads();   // tables (first segment) and tf are in place
+    // (b) the tiles
+    int k = wave;
+    if (FIRST && v_valid) {   // this wave's first tile was requested before the table copy and the index prologue
+        process_tile<MODE, true>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, v);
+        k += kWPB;
+    }
+    for (; k < n_seg; k += kWPB) process_tile<MODE>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane);
+    __syncthreads();
+    // (c) segment aggregate
+    {
         Fn64 f = fn_identity();
         Hd64 h = hd_identity();
-        for (int j = lo; j < hi; ++j) {
-            if (j < b) f = fn_then(f, agg_fn[j]);
-            if (j > b) h = hd_then(h, agg_hd[j]);
+        if (tid < n_seg) {
+            const int4 s = sm[tid];
+            f = fn_of(s);
+            h.h = s.z; h.c = s.w & 1;
         }
-        Fn64 ef; Hd64 eh;
-        block_scan(f, h, L, &ef, &eh, &pf, &sh);
+        Fn64 ef, tfn; Hd64 eh, th;
+        block_scan(f, h, scan, &ef, &eh, &tfn, &th);
+        if (tid == 0) { P.seg_fn[seg] = tfn; P.seg_hd[seg] = th; }
     }
-    const long long q_block_in = fn_apply(pf, 0);
-    Hd64 rest; rest.h = sh.h; rest.c = 1;   // what follows the block: sh.h starts before the next closing
+    __syncthreads();
+}
 
-    // (2) my tile
-    const int64_t t = (int64_t)b * kScanThreads + threadIdx.x;
-    int4 s = make_int4(0, 0, 0, 0);
-    Fn64 f = fn_identity();
-    Hd64 h = hd_identity();
-    if (t < n_tiles) {
-        s = summ[t];
-        f = fn_of(s);
-        h.h = s.z; h.c = s.w & 1;
-    }
-    Fn64 ef, tf; Hd64 eh, th;
-    block_scan(f, h, L, &ef, &eh, &tf, &th);
-    long long q_in = 0;
-    int tz = 0, need = 0;
-    if (t < n_tiles) {
-        q_in = fn_apply(ef, q_block_in);
-        const long long q_end = fn_apply(f, q_in);
-        const long long h_next = hd_then(eh, rest).h;
-        tz = (q_end + h_next) > 0;
-        const int tz0 = s.y > 0;
-        need = q_in != 0 || tz != tz0;
-        // Common cases are patched in place (bitmask mode): exactly one pending start entering a tile whose head
-        // block has no start of its own zeroes that head block; a tail block that turns out to be zeroed is cleared.
-        // What stays in a cleared block: the C_SYM bit of its last char and the bit of a string start.
-        const int geom = s.w;
-        if (need && patch_bits && (geom & 1) && q_in <= 1 && (q_in == 0 || s.z == 0)) {
-            const int64_t t0 = t * kTile;
-            const int64_t t_end = min(t0 + kTile, total);
-            if (q_in == 1) clear_range(patch_bits, t0, t0 + ((geom >> 1) & 0x1FFF), t_end, 0, (geom >> 27) & 1);
-            if (tz != tz0) clear_range(patch_bits, t0 + ((geom >> 14) & 0x1FFF), t_end, t_end, (geom >> 28) & 1, (geom >> 29) & 1);
-            need = 0;
+template <int MODE>
+__global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsTotal];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar tile arithmetic
+    if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
+
+    // every wave requests its first tile (16 KiB) before anything else: the HBM latency then overlaps the table copy
+    // and the index prologue of the first segment.  `v` is dead in the steady-state loop below.
+    u32x4 v[16];
+    bool v_valid = false;
+    {
+        const int64_t t = (int64_t)blockIdx.x * P.seg_tiles + wave;
+        if (MODE != kModeBlockMask && wave < P.seg_tiles && t < P.n_tiles && (t + 1) * kTile <= P.total) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t * kTile) + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+            v_valid = true;
         }
     }
-    // one atomic per wave (a single counter word saturates at a few dozen atomics per microsecond)
-    const lk_u64 m = __ballot(need);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(reinterpret_cast<unsigned long long*>(fix_count), (unsigned long long)lk_popc(m));
-        base = __shfl(base, 0);
-        if (need) {
-            const unsigned long long slot = base + (unsigned long long)lk_popc(m & ((1ull << lane) - 1ull));
-            fix_list[slot] = t;
-            fix_q[slot] = (int)(q_in < (1 << 20) ? q_in : (1 << 20));   // a tile has <= 4096 closings: clamp is exact
-            fix_tz[slot] = tz;
+    if (MODE != kModeBlockMask) load_tables(lds, P);   // the first segment's barriers publish the tables
+    run_segment<MODE, true>(P, lds, blockIdx.x, tid, lane, wave, v, v_valid);
+    for (int64_t seg = (int64_t)blockIdx.x + gridDim.x; seg < P.n_segs; seg += gridDim.x)
+        run_segment<MODE, false>(P, lds, seg, tid, lane, wave, nullptr, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stage 2: resolve + repair.  Same segment ownership.  Per segment the workgroup composes the aggregates of the
+// segments before it (pending starts entering the segment) and after it (starts before the next closing event),
+// scans its own tiles, and for every tile whose provisional assumptions (no pending start enters, tail block decided
+// by "pending at the tile end") were wrong: patches the bitmask in place for the common cases, or recomputes the tile
+// with the exact inputs (the same tile code; Unicode tables are only copied to LDS if that ever happens).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsTotal];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = P.seg_tiles;
+    ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
+    int* misc = reinterpret_cast<int*>(lds + kLdsMisc);          // misc[0] = number of tiles to recompute
+    int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment
+    int2* fix_in = reinterpret_cast<int2*>(lds + kLdsSumm);      // {q_in, tail_zero}
+    bool tables_loaded = false;
+
+    for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
+        const int64_t T0 = seg * S;
+        const int64_t T1 = min(T0 + S, P.n_tiles);
+        const int n_seg = (int)(T1 - T0);
+        // (1) aggregates of the other segments: contiguous range per thread, ordered
+        Fn64 pf = fn_identity();
+        Hd64 sh = hd_identity();
+        if (P.n_segs > 1) {
+            const int64_t per = (P.n_segs + kScanThreads - 1) / kScanThreads;
+            const int64_t lo = min((int64_t)tid * per, P.n_segs), hi = min(lo + per, P.n_segs);
+            Fn64 f = fn_identity();
+            Hd64 h = hd_identity();
+            for (int64_t j = lo; j < hi; ++j) {
+                if (j < seg) f = fn_then(f, P.seg_fn[j]);
+                if (j > seg) h = hd_then(h, P.seg_hd[j]);
+            }
+            Fn64 ef; Hd64 eh;
+            block_scan(f, h, scan, &ef, &eh, &pf, &sh);
         }
+        const long long q_seg_in = fn_apply(pf, 0);
+        Hd64 rest; rest.h = sh.h; rest.c = 1;   // what follows the segment: sh.h starts before the next closing
+
+        // (2) my tile
+        if (tid == 0) misc[0] = 0;
+        const int64_t t = T0 + tid;
+        int4 s = make_int4(0, 0, 0, 0);
+        Fn64 f = fn_identity();
+        Hd64 h = hd_identity();
+        if (tid < n_seg) {
+            s = P.summ[t];
+            f = fn_of(s);
+            h.h = s.z; h.c = s.w & 1;
+        }
+        Fn64 ef, tfn; Hd64 eh, th;
+        block_scan(f, h, scan, &ef, &eh, &tfn, &th);   // (its barriers also publish misc[0] = 0)
+        if (tid < n_seg) {
+            const long long q_in = fn_apply(ef, q_seg_in);
+            const long long q_end = fn_apply(f, q_in);
+            const long long h_next = hd_then(eh, rest).h;
+            const int tz = (q_end + h_next) > 0;
+            const int tz0 = s.y > 0;
+            if (q_in != 0 || tz != tz0) {
+                const int geom = s.w;
+                if (MODE == kModeBits && (geom & 1) && q_in <= 1 && (q_in == 0 || s.z == 0)) {
+                    // Patch in place: one pending start entering a tile whose head block has no start of its own
+                    // zeroes that head block; a tail block that turns out to be zeroed is cleared.  What stays in a
+                    // cleared block: the C_SYM bit of its last char and the bit of a string start.
+                    const int64_t t0 = t * kTile;
+                    const int64_t t_end = min(t0 + kTile, P.total);
+                    if (q_in == 1) clear_range(P.bits_out, t0, t0 + ((geom >> 1) & 0x1FFF), t_end, 0, (geom >> 27) & 1);
+                    if (tz != tz0)
+                        clear_range(P.bits_out, t0 + ((geom >> 14) & 0x1FFF), t_end, t_end, (geom >> 28) & 1, (geom >> 29) & 1);
+                } else {
+                    const int slot = atomicAdd(&misc[0], 1);
+                    fix_t[slot] = tid;
+                    fix_in[slot] = make_int2((int)(q_in < (1 << 20) ? q_in : (1 << 20)), tz);   // <= 4096 closings/tile
+                }
+            }
+        }
+        __syncthreads();
+        // (3) recompute what could not be patched (rare)
+        const int n_fix = misc[0];
+        if (n_fix > 0) {
+            if (!tables_loaded && MODE != kModeBlockMask) {
+                load_tables(lds, P);
+                tables_loaded = true;
+                __syncthreads();
+            }
+            const TileLds L = wave_lds(lds, wave);
+            for (int i = wave; i < n_fix; i += kWPB) {
+                const int64_t tt = T0 + fix_t[i];
+                const int2 in = fix_in[i];
+                const int64_t idx0 = wave_lower_bound(P.row_off, P.n_str + 1, tt * kTile, lane);
+                process_tile<MODE>(P, L, tt, idx0, in.x, in.y, false, nullptr, lane);
+            }
+            if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.fix_count), (unsigned long long)n_fix);
+        }
+        __syncthreads();
     }
 }
 
@@ -676,75 +753,31 @@ hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int
 // ---------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------
-static inline int blocks_for(int64_t n_items, int wpb, int n_cu, int max_blocks_per_cu) {
-    int64_t b = (n_items + wpb - 1) / wpb;
-    const int64_t cap = (int64_t)n_cu * max_blocks_per_cu;
-    if (b > cap) b = cap;
-    if (b < 1) b = 1;
-    return (int)b;
+void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
+    int64_t s = (n_tiles + n_cu - 1) / n_cu;     // one segment per workgroup when the batch is small
+    if (s < kWPB) s = kWPB;
+    if (s > kSegMax) s = kSegMax;
+    *seg_tiles = (int)s;
+    *n_segs = (n_tiles + s - 1) / s;
 }
 
-hipError_t launch_tile_index(const int64_t* row_off, int64_t n_str, int64_t n_tiles, int64_t* tile_first,
-                             int64_t* fix_count, hipStream_t st) {
-    const int64_t n = n_str + 1;
-    const int threads = 256;
-    const int64_t blocks = (n + threads - 1) / threads;
-    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)blocks), dim3(threads), 0, st, row_off, n_str, n_tiles, tile_first,
-                       fix_count);
-    return hipGetLastError();
-}
-
-template <int WPB, int PF>
-static hipError_t launch_main_bits(const SplitParams& P, int n_cu, hipStream_t st) {
-    const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
-    hipLaunchKernelGGL((k_split_tiles<kModeBits, false, WPB, PF>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    return hipGetLastError();
+static inline int grid_for(const SplitParams& P, int n_cu) {
+    return (int)(P.n_segs < n_cu ? (P.n_segs < 1 ? 1 : P.n_segs) : n_cu);
 }
 
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
-    constexpr int WPB = kWavesPerBlockMain;
-    if (mode == kModeBits) {
-        static const int variant = [] { const char* e = getenv("LATOK_VARIANT"); return e ? atoi(e) : 0; }();
-        switch (variant) {   // experiment switch; 0 = shipped configuration
-            case 1: return launch_main_bits<16, 0>(P, n_cu, st);
-            case 2: return launch_main_bits<12, 2>(P, n_cu, st);
-            case 3: return launch_main_bits<8, 2>(P, n_cu, st);
-            case 4: return launch_main_bits<12, 0>(P, n_cu, st);
-            case 5: return launch_main_bits<12, 3>(P, n_cu, st);
-            default: return launch_main_bits<WPB, kPrefetchMain>(P, n_cu, st);
-        }
-    }
-    const int blocks = blocks_for(P.n_tiles, WPB, n_cu, 1);
-    if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, false, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, false, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+    const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
+    if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
+    else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
 
-hipError_t launch_scan_summaries(const SplitParams& P, int mode, hipStream_t st) {
-    const int n_blocks = (int)((P.n_tiles + kScanThreads - 1) / kScanThreads);
-    Fn64* agg_fn = reinterpret_cast<Fn64*>(P.scan_agg);
-    Hd64* agg_hd = reinterpret_cast<Hd64*>(P.scan_agg + (size_t)n_blocks * sizeof(Fn64));
-    if (n_blocks > 1)
-        hipLaunchKernelGGL(k_scan_aggregate, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd);
-    hipLaunchKernelGGL(k_scan_resolve, dim3(n_blocks), dim3(kScanThreads), 0, st, P.summ, P.n_tiles, agg_fn, agg_hd,
-                       n_blocks, mode == kModeBits ? P.bits_out : nullptr, P.total, P.fix_list, P.fix_q, P.fix_tz,
-                       P.fix_count);
-    return hipGetLastError();
-}
-
-hipError_t launch_fix_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
-    constexpr int WPB = kWavesPerBlockFix;
-    // the number of tiles to repair is only known on the device; a modest fixed grid loops over the list
-    int blocks = blocks_for(P.n_tiles / 8 + 1, WPB, n_cu, 2);
-    if (blocks > 2 * n_cu) blocks = 2 * n_cu;
-    if (mode == kModeBits)
-        hipLaunchKernelGGL((k_split_tiles<kModeBits, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else if (mode == kModeValues)
-        hipLaunchKernelGGL((k_split_tiles<kModeValues, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
-    else
-        hipLaunchKernelGGL((k_split_tiles<kModeBlockMask, true, WPB, 0>), dim3(blocks), dim3(WPB * 64), 0, st, P);
+hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
+    const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
+    if (mode == kModeBits) hipLaunchKernelGGL((k_resolve_fix<kModeBits>), grid, block, 0, st, P);
+    else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues>), grid, block, 0, st, P);
+    else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
 

@@ -29,6 +29,24 @@
 
 namespace latok {
 
+// Diagnostic build only (-DLATOK_STAMPS): s_memtime stamps at phase boundaries of the tile function, summed per wave and
+// added to a global array at the end of the kernel.  Never compiled into the shipped library.
+#ifdef LATOK_STAMPS
+__device__ unsigned long long g_stamp_sum[16];
+__device__ unsigned long long g_stamp_cnt;
+#define LATOK_STAMP(k)                                                                           \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if ((k) > 0) stamp_acc[(k)] += t_ - stamp_prev;                                          \
+        stamp_prev = t_;                                                                         \
+    } while (0)
+#else
+#define LATOK_STAMP(k) do { } while (0)
+#endif
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t stage_addr(uint32_t p) { return p + ((p >> 6) << 4); }  // 64-byte rows, 16 B pad
@@ -124,13 +142,23 @@ struct TileLds {
 // issued so that they fly under this tile's phase 2.  Returns whether `v` now holds tile `t_next`.
 // idx0 = index of the first string that starts at or after the tile's first char.
 // PRELOADED: the caller already requested the tile's 16 KiB into `vin` (first tile of a workgroup's first segment).
-// The tile summary goes to global memory (for the resolve stage) and, when summ_l != nullptr, to the block's LDS copy.
-template <int MODE, bool PRELOADED = false>
-__device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
+// With write_summary the tile summary is written to *summ_l (LDS copy of the segment).
+// Returns this lane's 64-bit boundary word (kModeBits); with DEFER the caller stores it later (write combining).
+template <int MODE, bool PRELOADED = false, bool DEFER = false>
+__device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
                                              int tail_zero, bool write_summary, int4* summ_l, int lane,
-                                             const u32x4* vin = nullptr) {
+                                             const u32x4* vin = nullptr
+#ifdef LATOK_STAMPS
+                                             , unsigned long long* stamp_acc = nullptr
+#endif
+                                             ) {
+#ifdef LATOK_STAMPS
+    unsigned long long stamp_prev = 0, stamp_dummy[16];
+    if (!stamp_acc) stamp_acc = stamp_dummy;
+#endif
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
+    LATOK_STAMP(0);
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
     // the next 64 strings and the three halo characters
@@ -154,6 +182,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
         }
+        LATOK_STAMP(1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
@@ -176,6 +205,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     if (MODE != kModeBlockMask && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
     L.bw[lane] = 0;
     if (lane == 0) L.bw[64] = 0;
+    LATOK_STAMP(2);
     wave_lds_sync();
     for (;;) {
         const int64_t rel = ro - t0;
@@ -186,6 +216,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     }
     wave_lds_sync();
+    LATOK_STAMP(3);
 
     // ---- phase 2: lane = one 64-char word ---------------------------------------------------------------------
     const lk_u64 B = L.bw[lane];
@@ -236,6 +267,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         const lk_feat f = lk_decode(plane);
         loc = lk_rules(f, h, B, Bn);
     }
+    LATOK_STAMP(4);
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
 
     // forward: inclusive (max,+) scan of the per-word queue transfer functions over the 64 lanes
@@ -248,6 +280,7 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     tile_fn.a = lane_read(inc.a, 63);
     tile_fn.b = lane_read(inc.b, 63);
     if (r > 0) lk_apply_extra(fw, r);
+    LATOK_STAMP(5);
 
     if (write_summary) {
         const lk_u64 cl = loc.S | B;                       // closing events of my word
@@ -277,13 +310,15 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
         if (lane == 0) {
             const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
                              (tail_sym << 29);
-            const int4 sv = make_int4(tile_fn.a, tile_fn.b, head, geom);
-            P.summ[t] = sv;
-            if (summ_l) *summ_l = sv;
+            *summ_l = make_int4(tile_fn.a, tile_fn.b, head, geom);   // LDS; the segment publishes them in one burst
+#ifdef LATOK_AB_SUMM_PER_TILE
+            P.summ[t] = *summ_l;
+#endif
         }
     }
 
     // backward: zeroing closings clear the block below them; the carry chain over lanes is one 64-bit add on ballots
+    LATOK_STAMP(6);
     const lk_u64 zall = fw.zs | fw.zb;
     const int z0_next = dpp_mov<kDppWaveShl1, 0xF>(0, (int)(zall & 1ull));   // lane 63 gets 0
     const lk_bwd bw = lk_backward_prepare(zall, loc.S, B, z0_next);
@@ -295,12 +330,15 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
     const int cin = (int)((carries_in >> (63 - lane)) & 1ull);
     const lk_u64 cleared = lk_backward_fill(bw, cin, loc.S);
 
+    LATOK_STAMP(7);
+    lk_u64 out_word = 0;
     if (base < total) {
         const int64_t remain = total - base;
         const lk_u64 valid = remain >= 64 ? ~0ull : ((1ull << remain) - 1ull);
         const lk_u64 keep = ~cleared;
         if (MODE == kModeBits) {
-            P.bits_out[base >> 6] = ((loc.raw & keep) | loc.sym | B) & valid;
+            out_word = ((loc.raw & keep) | loc.sym | B) & valid;
+            if (!DEFER) P.bits_out[base >> 6] = out_word;
         } else {
             // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
             // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the
@@ -337,7 +375,9 @@ __device__ __forceinline__ void process_tile(const SplitParams& P, const TileLds
             }
         }
     }
+    LATOK_STAMP(8);
     wave_lds_sync();  // staging buffer is reused by this wave's next tile
+    return out_word;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -543,9 +583,17 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 //   (b) runs the tiles, each publishing its 16-byte summary to LDS and to global memory,
 //   (c) composes the segment's transfer function / head descriptor with a block-wide scan -> one aggregate per segment.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef LATOK_STAMPS
+#define LATOK_STAMP_ARG , stamp_acc
+#define LATOK_STAMP_PARAM , unsigned long long* stamp_acc
+#else
+#define LATOK_STAMP_ARG
+#define LATOK_STAMP_PARAM
+#endif
+
 template <int MODE, bool FIRST>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane, int wave,
-                                            const u32x4* v, bool v_valid) {
+                                            const u32x4* v, bool v_valid LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
     const TileLds L = wave_lds(lds, wave);
     int* tf = reinterpret_cast<int*>(lds + kLdsTf);
@@ -578,12 +626,42 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     }
     __syncthreads();   // tables (first segment) and tf are in place
     // (b) the tiles
+    // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
+    // One 512-byte store per 16 KiB tile, interleaved with the read stream, costs ~5 % of HBM throughput.
+    constexpr bool kDefer = MODE == kModeBits;
+    lk_u64 obuf[8];
+    int slot = 0, k_first = wave;   // buffered tiles are k_first, k_first + kWPB, ...
+    const int64_t n_words = (P.total + 63) >> 6;
+    auto flush = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < slot) {
+                const int64_t w = (T0 + k_first + j * kWPB) * 64 + lane;
+                if (w < n_words) P.bits_out[w] = obuf[j];
+            }
+        }
+        slot = 0;
+    };
+    auto put = [&](lk_u64 w, int k) {
+        if (slot == 0) k_first = k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
+        if (++slot == 8) flush();
+    };
     int k = wave;
     if (FIRST && v_valid) {   // this wave's first tile was requested before the table copy and the index prologue
-        process_tile<MODE, true>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, v);
+        const lk_u64 w = process_tile<MODE, true, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, v LATOK_STAMP_ARG);
+        if (kDefer) put(w, k);
         k += kWPB;
     }
-    for (; k < n_seg; k += kWPB) process_tile<MODE>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane);
+    for (; k < n_seg; k += kWPB) {
+        const lk_u64 w = process_tile<MODE, false, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, nullptr LATOK_STAMP_ARG);
+        if (kDefer) put(w, k);
+#ifdef LATOK_STAMPS
+        stamp_acc[0] += 1;
+#endif
+    }
+    if (kDefer) flush();
     __syncthreads();
     // (c) segment aggregate
     {
@@ -591,6 +669,9 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         Hd64 h = hd_identity();
         if (tid < n_seg) {
             const int4 s = sm[tid];
+#ifndef LATOK_AB_SUMM_PER_TILE
+            P.summ[T0 + tid] = s;            // coalesced: 16 B per thread, one burst per segment
+#endif
             f = fn_of(s);
             h.h = s.z; h.c = s.w & 1;
         }
@@ -623,9 +704,17 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
         }
     }
     if (MODE != kModeBlockMask) load_tables(lds, P);   // the first segment's barriers publish the tables
-    run_segment<MODE, true>(P, lds, blockIdx.x, tid, lane, wave, v, v_valid);
+#ifdef LATOK_STAMPS
+    unsigned long long stamp_acc[16];
+    for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
+#endif
+    run_segment<MODE, true>(P, lds, blockIdx.x, tid, lane, wave, v, v_valid LATOK_STAMP_ARG);
     for (int64_t seg = (int64_t)blockIdx.x + gridDim.x; seg < P.n_segs; seg += gridDim.x)
-        run_segment<MODE, false>(P, lds, seg, tid, lane, wave, nullptr, false);
+        run_segment<MODE, false>(P, lds, seg, tid, lane, wave, nullptr, false LATOK_STAMP_ARG);
+#ifdef LATOK_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 9; ++i) atomicAdd(&g_stamp_sum[i], stamp_acc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -780,5 +869,16 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
     else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
+
+#ifdef LATOK_STAMPS
+extern "C" int latok_diag_stamps(unsigned long long* out16, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp_sum), 16 * sizeof(unsigned long long));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 }  // namespace latok

@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W                        # one rank per GPU
 
-A "step" is one pass of the whole pipeline (tile index -> fused tiles kernel -> summary scan -> fix-up) over one batch
+A "step" is one pass of the whole pipeline (fused tiles kernel -> resolve/repair kernel) over one batch
 of synthetic strings that is already resident in HBM.  Workload at every N = BASELINE.json configs[1] per GPU
 ("1 M synthetic ASCII strings, avg 128 chars"); with N ranks each rank owns an independent shard of 1 M strings of the
 same corpus (string ids rank*1M ...), i.e. configs[3]'s sharding with per-GPU work held fixed -> "scaling": "weak".
@@ -13,7 +13,7 @@ No collective on the data path: strings are independent.  torch i
 the barrier and the max-over-ranks of the wall time.
 
 Prints ONE JSON line on rank 0.  Besides the contract keys it carries
-  roofline     -- dominant kernel (k_split_tiles): algorithmic HBM bytes per launch / its HIP-event time, vs 8 TB/s
+  roofline     -- dominant kernel (k_tiles_main): algorithmic HBM bytes per launch / its HIP-event time, vs 8 TB/s
   cpu_baseline -- the reference's own C functions (oracle/_ref, built from the reference's latok.c) under a restated
                   NumPy glue, 1 thread, timed on this host on the same corpus (N = 1, rank 0 only); "port" numbers of
                   oracle/latok_oracle.c ride along in cpu_baseline_port.
@@ -211,7 +211,7 @@ def main():
                        "chars_total": chars_all, "utf8_bytes_total": utf8_all, "sharding": f"{world} x independent string shards"},
             "ms_per_step_hip_events_rank0": ms_events.value / args.steps,
             "fix_tiles_rank0": n_fix.value, "tiles_rank0": (total + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
-            "roofline": {"bound": "hbm", "kernel": "k_split_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_read, "kernel_ms": t_kernel * 1e3,
                          "pipeline_frac": alg_read / (ms_events.value / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS},

@@ -46,7 +46,7 @@ int latok_shutdown(void);
 const char* latok_last_error(void);    /* message of the last failure on this thread */
 const char* latok_version(void);
 
-/* Grow the library-owned workspace (tile index, tile summaries, host-mode staging) for batches of up to
+/* Grow the library-owned workspace (tile summaries, segment aggregates) for batches of up to
  * `max_chars` code points / `max_strings` strings, so that later calls allocate nothing. */
 int latok_reserve(int64_t max_chars, int64_t max_strings);
 
@@ -116,7 +116,7 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
 /* ---- measurement ----------------------------------------------------------------------------------------------- */
 /* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
  * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
- * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (split_tiles), measured with its own
+ * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (k_tiles_main), measured with its own
  * event pair per launch in `iters` further passes; n_fix_tiles_out = tiles re-done by the fix-up stage in the last
  * pass.  Any may be NULL (a NULL output skips its passes), so warm-up-only and kernel-only calls are possible. */
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,

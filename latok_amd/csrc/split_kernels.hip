@@ -843,7 +843,11 @@ hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
-    int64_t s = (n_tiles + n_cu - 1) / n_cu;     // one segment per workgroup when the batch is small
+    // every workgroup gets the same number of (almost) equally sized segments: `rounds` segments of
+    // ceil(n_tiles / (n_cu * rounds)) tiles, rounds = smallest count that keeps a segment within kSegMax tiles
+    const int64_t per_cu = (n_tiles + n_cu - 1) / n_cu;
+    const int64_t rounds = per_cu > kSegMax ? (per_cu + kSegMax - 1) / kSegMax : 1;
+    int64_t s = (n_tiles + (int64_t)n_cu * rounds - 1) / ((int64_t)n_cu * rounds);
     if (s < kWPB) s = kWPB;
     if (s > kSegMax) s = kSegMax;
     *seg_tiles = (int)s;

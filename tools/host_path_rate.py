@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Dev tool: PCIe-inclusive rate of the host-pointer API (H2D of the batch + pipeline + D2H of the bitmask)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from latok_amd import _lib, batch
+lib = _lib.ensure_init()
+n = 1_000_000
+row = np.zeros(n + 1, np.int64)
+lib.latok_corpus_offsets(0x1A70C0DE, 0, n, 64, 192, row.ctypes.data)
+cps = np.zeros(int(row[-1]), np.uint32)
+lib.latok_corpus_fill_host(0x1A70C0DE, 0, 0, n, row.ctypes.data, cps.ctypes.data)
+batch.split_mask_batch(cps, row)
+t = time.perf_counter()
+for _ in range(5):
+    batch.split_mask_batch(cps, row)
+dt = (time.perf_counter() - t) / 5
+print(f"host-pointer split_mask_batch: {dt * 1e3:.2f} ms per 1M-string batch = {cps.size / dt / 1e9:.2f} GB/s UTF-8 (PCIe-inclusive, pageable host memory)")
+t = time.perf_counter()
+counts, offs = batch.split_offsets_csr(cps, row)
+dt = time.perf_counter() - t
+print(f"host-pointer split_offsets_csr: {dt * 1e3:.2f} ms ({offs.size} boundaries)")

@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--strings", type=int, default=0, help="strings per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strings", type=int, default=1_000_000)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for real runs; gloo lets several ranks rehearse on one GPU")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device for this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,15 +127,19 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU", file=sys.stderr)
         sys.exit(2)
 
+    device = args.device if args.device >= 0 else local_rank
     dist = tdev = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        tdev = torch.device("cuda", local_rank)
-        dist.init_process_group(backend="nccl", device_id=tdev)
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(device)
+            tdev = torch.device("cuda", device)
+            dist.init_process_group(backend="nccl", device_id=tdev)
+        else:
+            dist.init_process_group(backend="gloo")
 
-    lib = _lib.ensure_init(local_rank)
+    lib = _lib.ensure_init(device)
     model, seed, lo, hi, n_default, desc = WORKLOADS[args.workload]
     n_str = args.strings or n_default
     sid0, n_str = shard_string_ids(n_str, rank)
@@ -155,8 +162,9 @@ def main():
     def sync_all():
         _lib.check(lib.latok_sync())
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
+            if tdev is not None:
+                import torch
+                torch.cuda.synchronize()
             dist.barrier()
 
     # ---- W untimed warm-up steps, then exactly K timed steps ------------------------------------------------------
@@ -167,7 +175,7 @@ def main():
     t0 = time.perf_counter()
     _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, args.steps, C.byref(ms_events), None, None))
     _lib.check(lib.latok_sync())
-    if dist is not None:
+    if tdev is not None:
         import torch
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0

@@ -111,7 +111,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.n_tiles = n_tiles;
     latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
     P.t1 = (const uint8_t*)g.t1.p;
-    P.t2 = (const uint8_t*)g.t2code.p;
+    P.t2 = (const uint8_t*)g.t1.p + latok::kStage1Pad;
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.summ = (int4*)g.summ.p;
@@ -217,13 +217,12 @@ int latok_init(int device) {
     std::vector<uint8_t> t2code(latok::kStage2Len);
     for (int i = 0; i < latok::kStage2Len; ++i) t2code[i] = kClassCode[kStage2[i]];
     int rc;
-    if ((rc = g.t1.ensure(t1.size()))) return rc;
-    if ((rc = g.t2code.ensure(t2code.size()))) return rc;
+    if ((rc = g.t1.ensure(t1.size() + t2code.size()))) return rc;   // [stage1 | stage2 codes], contiguous like in LDS
     if ((rc = g.t2cls.ensure(sizeof(kStage2)))) return rc;
     if ((rc = g.cw.ensure(sizeof(kClassWord)))) return rc;
     if ((rc = g.scalar.ensure(64))) return rc;
     HIP_TRY(hipMemcpy(g.t1.p, t1.data(), t1.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(g.t2code.p, t2code.data(), t2code.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char*)g.t1.p + t1.size(), t2code.data(), t2code.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(g.t2cls.p, kStage2, sizeof(kStage2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(g.cw.p, kClassWord, sizeof(kClassWord), hipMemcpyHostToDevice));
     g.device = device;

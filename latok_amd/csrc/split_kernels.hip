@@ -555,13 +555,24 @@ static_assert(kSegMax == kWPB * 64, "one tile per thread in the block-wide scans
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
 static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0, "alignment");
 
+// Both tables are contiguous in LDS ([stage1 | stage2]) and in global memory (api.cpp uploads them back to back), so the
+// copy is one stream of kTablesLdsBytes / 16 vectors; all of a thread's loads are issued before its first LDS write.
 __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) {
-    const uint4* s1 = reinterpret_cast<const uint4*>(P.t1);
-    uint4* d1 = reinterpret_cast<uint4*>(lds);
-    for (int i = threadIdx.x; i < kStage1Pad / 16; i += kWPB * 64) d1[i] = s1[i];
-    const uint4* s2 = reinterpret_cast<const uint4*>(P.t2);
-    uint4* d2 = reinterpret_cast<uint4*>(lds + kStage1Pad);
-    for (int i = threadIdx.x; i < kStage2Len / 16; i += kWPB * 64) d2[i] = s2[i];
+    constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
+    constexpr int kPer = (kVec + kWPB * 64 - 1) / (kWPB * 64);    // 4 with 768 threads
+    const uint4* src = reinterpret_cast<const uint4*>(P.t1);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    uint4 tmp[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + j * kWPB * 64;
+        if (i < kVec) tmp[j] = src[i];
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = threadIdx.x + j * kWPB * 64;
+        if (i < kVec) dst[i] = tmp[j];
+    }
 }
 
 __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {

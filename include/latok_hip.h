@@ -75,6 +75,16 @@ int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64
                               int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
                               int flags, void* stream);
 
+/* Token spans: everything tokenize() does after np.nonzero (reference default_tokenizer.py:149-158), on the device:
+ * consecutive boundaries delimit a token, leading/trailing SPACE-class chars are stripped (str.strip()), whitespace-only
+ * tokens are dropped.  counts_out[n_str] = tokens per string; spans_out[2*k], spans_out[2*k+1] = [start, end) of token
+ * k relative to its string start (tokens of string 0 first).  spans_cap = capacity in tokens; *n_tokens_out = total
+ * (host pointer).  LATOK_ERR_INVALID when spans_cap is too small (n_tokens_out still holds the needed count).
+ * Synchronous in both pointer modes. */
+int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                            int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                            int flags, void* stream);
+
 /* ---- the reference's three native functions, one string at a time (compat surface) ---------------------------- */
 /* _gen_parse_matrix (latok.c:31-138): n code points -> int8[n][25], C-contiguous. */
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream);

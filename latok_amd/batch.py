@@ -78,6 +78,21 @@ def split_offsets_batch(texts):
     return np.split(offsets, np.cumsum(counts)[:-1])
 
 
+def token_spans_csr(cps, row_off):
+    """(counts int64[n], spans int64[n_tokens, 2]): [start, end) of every token of every string, already stripped and
+    with whitespace-only tokens dropped -- everything reference tokenize() does after np.nonzero, on the device."""
+    cps, row_off = _csr(cps, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    spans = np.empty((max(total, 1), 2), np.int64)   # at most one token per char
+    n_tok = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_token_spans_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
+                                           spans.shape[0], C.byref(n_tok), 0, None))
+    return counts, spans[:n_tok.value].copy()
+
+
 def spans_from_offsets(text, nz):
     """Token strings of one text from its boundary offsets, as the reference's loop builds them
     (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""
@@ -99,4 +114,12 @@ def spans_from_offsets(text, nz):
 def tokenize_batch(texts):
     """list[str] -> list[list[str]], each as list(tokenize(text)) of the reference (default_tokenizer.py:137-160);
     an empty string yields [] instead of the reference's IndexError."""
-    return [spans_from_offsets(t, nz) for t, nz in zip(texts, split_offsets_batch(texts))]
+    if len(texts) == 0:
+        return []
+    cps, row_off = pack(texts)
+    counts, spans = token_spans_csr(cps, row_off)
+    out, k = [], 0
+    for text, n in zip(texts, counts.tolist()):
+        out.append([text[a:b] for a, b in spans[k:k + n].tolist()])
+        k += n
+    return out

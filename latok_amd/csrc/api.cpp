@@ -76,7 +76,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, counts, bases, scalar, h_aux;
+    DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scalar, h_aux;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
 
@@ -98,7 +98,7 @@ int need_init() {
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
-                 const int* bm_flags = nullptr) {
+                 const int* bm_flags = nullptr, uint64_t* d_space = nullptr) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     int rc = ensure_workspace(n_tiles);
@@ -114,6 +114,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.t2 = (const uint8_t*)g.t1.p + latok::kStage1Pad;
     P.bits_out = d_bits;
     P.values_out = d_values;
+    P.space_out = d_space;
     P.summ = (int4*)g.summ.p;
     P.seg_fn = (latok::Fn64*)g.seg_agg.p;
     P.seg_hd = (latok::Hd64*)((char*)g.seg_agg.p + (size_t)P.n_segs * sizeof(latok::Fn64));
@@ -234,7 +235,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.counts, &g.bases, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -268,14 +269,14 @@ int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_
     return split_common(cps, row_off, n_str, total_chars, values_out, latok::kModeValues, flags, stream);
 }
 
-int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
-                              int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
-                              int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+// shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
+static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+                          int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
+                          void* stream) {
     int rc = need_init();
     if (rc) return rc;
-    if (!n_offsets_out) return fail(LATOK_ERR_INVALID, "n_offsets_out is NULL");
-    *n_offsets_out = 0;
+    if (!n_items_out) return fail(LATOK_ERR_INVALID, "the total-count output pointer is NULL");
+    *n_items_out = 0;
     hipStream_t st = stream ? (hipStream_t)stream : g.stream;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
@@ -299,29 +300,52 @@ int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64
     }
     const size_t words = (size_t)((total + 63) / 64);
     if ((rc = g.bits.ensure(words * 8 + 8))) return rc;
+    if (spans && (rc = g.space.ensure(words * 8 + 8))) return rc;
     if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
     if ((rc = g.bases.ensure((size_t)n_str * 8))) return rc;
-    if ((rc = run_pipeline(d_cps, d_row, n_str, total, (uint64_t*)g.bits.p, nullptr, latok::kModeBits, st))) return rc;
+    uint64_t* d_bits = (uint64_t*)g.bits.p;
+    uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
+    if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, d_space)))
+        return rc;
     int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
-    HIP_TRY(latok::launch_count_boundaries((const uint64_t*)g.bits.p, d_row, n_str, d_counts, st));
+    if (spans) HIP_TRY(latok::launch_count_spans(d_bits, d_space, d_row, n_str, d_counts, st));
+    else HIP_TRY(latok::launch_count_boundaries(d_bits, d_row, n_str, d_counts, st));
     HIP_TRY(latok::launch_exclusive_scan(d_counts, n_str, (int64_t*)g.bases.p, (int64_t*)g.scalar.p, st));
-    int64_t n_off = 0;
-    HIP_TRY(hipMemcpyAsync(&n_off, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
+    int64_t n_items = 0;
+    HIP_TRY(hipMemcpyAsync(&n_items, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *n_offsets_out = n_off;
+    *n_items_out = n_items;
     if (!dev) HIP_TRY(hipMemcpy(counts_out, g.counts.p, (size_t)n_str * 8, hipMemcpyDeviceToHost));
-    if (n_off > offsets_cap) return fail(LATOK_ERR_INVALID, "offsets_cap too small: need %lld", (long long)n_off);
-    if (n_off == 0) return LATOK_OK;
-    if (!offsets_out) return fail(LATOK_ERR_INVALID, "offsets_out is NULL");
-    int64_t* d_off = offsets_out;
+    if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
+    if (n_items == 0) return LATOK_OK;
+    if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
+    const size_t item_bytes = spans ? 16 : 8;
+    int64_t* d_items = items_out;
     if (!dev) {
-        if ((rc = g.h_out.ensure((size_t)n_off * 8))) return rc;
-        d_off = (int64_t*)g.h_out.p;
+        if ((rc = g.h_out.ensure((size_t)n_items * item_bytes))) return rc;
+        d_items = (int64_t*)g.h_out.p;
     }
-    HIP_TRY(latok::launch_write_offsets((const uint64_t*)g.bits.p, d_row, n_str, (const int64_t*)g.bases.p, d_off, st));
-    if (!dev) HIP_TRY(hipMemcpyAsync(offsets_out, d_off, (size_t)n_off * 8, hipMemcpyDeviceToHost, st));
+    if (spans) HIP_TRY(latok::launch_write_spans(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
+    else HIP_TRY(latok::launch_write_offsets(d_bits, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
+    if (!dev) HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LATOK_OK;
+}
+
+int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+                              int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
+                              int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return compact_common(false, cps, row_off, n_str, total, counts_out, offsets_out, offsets_cap, n_offsets_out, flags,
+                          stream);
+}
+
+int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+                            int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out, int flags,
+                            void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return compact_common(true, cps, row_off, n_str, total, counts_out, spans_out, spans_cap, n_tokens_out, flags, stream);
 }
 
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream) {

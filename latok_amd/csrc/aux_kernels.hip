@@ -135,6 +135,85 @@ __global__ void k_write_offsets(const uint64_t* __restrict__ bits, const int64_t
         }
 }
 
+// ---- token spans (reference default_tokenizer.py:149-158: slice between consecutive boundaries, strip, drop empties) ---
+// A token is [a, e) between two consecutive boundaries of its string (the last one ends at the string end); strip()
+// removes SPACE-class chars at both ends (the reference's SPACE set equals Python's str.isspace set).
+// first position in [from, to) whose bit in `bits` is 0, or `to`
+__device__ __forceinline__ int64_t next_zero_bit(const uint64_t* bits, int64_t from, int64_t to) {
+    for (int64_t w = from >> 6; from < to; ++w) {
+        uint64_t x = ~bits[w];
+        const int64_t base = w << 6;
+        if (from > base) x &= ~0ull << (from - base);
+        if (x) {
+            const int64_t p = base + __builtin_ctzll(x);
+            return p < to ? p : to;
+        }
+        from = base + 64;
+    }
+    return to;
+}
+// last position in [from, to) whose bit is 0, plus one; `from` if none
+__device__ __forceinline__ int64_t prev_zero_end(const uint64_t* bits, int64_t from, int64_t to) {
+    for (int64_t w = (to - 1) >> 6; to > from; --w) {
+        uint64_t x = ~bits[w];
+        const int64_t base = w << 6;
+        if (to < base + 64) x &= (1ull << (to - base)) - 1ull;
+        if (x) {
+            const int64_t p = base + 63 - __builtin_clzll(x);
+            return p >= from ? p + 1 : from;
+        }
+        to = base;
+    }
+    return from;
+}
+
+template <bool WRITE>
+__global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                              const int64_t* __restrict__ row_off, int64_t n_str, int64_t* __restrict__ counts,
+                              const int64_t* __restrict__ out_base, int64_t* __restrict__ spans) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    const int64_t lo = row_off[s], hi = row_off[s + 1];
+    int64_t n = 0, k = WRITE ? out_base[s] : 0;
+    int64_t a = -1;   // start of the open token (the previous boundary)
+    auto emit = [&](int64_t from, int64_t to) {
+        const int64_t a2 = next_zero_bit(space, from, to);
+        if (a2 >= to) return;                         // whitespace only: dropped like the reference's `if token:`
+        const int64_t e2 = prev_zero_end(space, a2, to);
+        if (WRITE) { spans[2 * k] = a2 - lo; spans[2 * k + 1] = e2 - lo; }
+        ++k;
+        ++n;
+    };
+    if (hi > lo) {
+        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
+            uint64_t x = mask_word(bits, w, lo, hi);
+            while (x) {
+                const int64_t e = (w << 6) + __builtin_ctzll(x);
+                x &= x - 1;
+                if (a >= 0) emit(a, e);
+                a = e;
+            }
+        }
+        if (a >= 0) emit(a, hi);                      // the last token runs to the end of the string
+    }
+    if (!WRITE) counts[s] = n;
+}
+
+hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                              int64_t* counts, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL((k_token_spans<false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
+                       row_off, n_str, counts, nullptr, nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                              const int64_t* out_base, int64_t* spans, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL((k_token_spans<true>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
+                       row_off, n_str, nullptr, out_base, spans);
+    return hipGetLastError();
+}
+
 // single-block exclusive scan of int64 counts (chunk per thread + Hillis-Steele across threads)
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const int64_t* __restrict__ in, int64_t n,
                                                          int64_t* __restrict__ out, int64_t* __restrict__ total) {

@@ -42,6 +42,7 @@ struct SplitParams {
     const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
+    uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
     Fn64* seg_fn;               // [n_segs] segment aggregates
     Hd64* seg_hd;               // [n_segs]
@@ -68,6 +69,10 @@ hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off,
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, hipStream_t st);
 hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
                                 int64_t* offsets, hipStream_t st);
+hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                              int64_t* counts, hipStream_t st);
+hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                              const int64_t* out_base, int64_t* spans, hipStream_t st);
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
 hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);

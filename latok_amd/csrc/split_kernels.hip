@@ -339,6 +339,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         if (MODE == kModeBits) {
             out_word = ((loc.raw & keep) | loc.sym | B) & valid;
             if (!DEFER) P.bits_out[base >> 6] = out_word;
+            if (P.space_out) P.space_out[base >> 6] = loc.S & valid;   // token-span mode only
         } else {
             // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
             // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the

@@ -309,3 +309,21 @@ def test_long_documents(gpu, oracle):
     bits = batch.split_mask_batch(cps, row)
     _, ob = oracle.split_batch(cps, row, want_values=False)
     assert np.array_equal(ob, bits)
+
+
+def test_token_spans_on_device(gpu, oracle):
+    """latok_token_spans_batch == the reference's slice/strip/drop-empty loop (default_tokenizer.py:149-158)."""
+    from latok_amd import batch
+    rng = random.Random(77)
+    texts = [G1, "", " ", "  lead and trail  ", "a", "x\t\ny", "tab\tsep nbsp ls　ideo  ", "   ", "a  b   c",
+             "foo@bar.com, .@user hi", "http://a@b X,y z", "日本語のテキスト、です。 🤓 ok "] + \
+        random_strings(rng, 300, 0, 120, ALPHABETS["mixed"]) + random_strings(rng, 50, 0, 400, ALPHABETS["words"]) + \
+        random_strings(rng, 3, 5000, 20000, ALPHABETS["mixed"]) + random_strings(rng, 100, 0, 30, list("ab \t\n"))
+    got = batch.tokenize_batch(texts)
+    for t, g in zip(texts, got):
+        want = oracle.tokenize(t) if t else []
+        assert g == want, (t[:80], g[:10], want[:10])
+    cps, row = pack(texts)
+    counts, spans = batch.token_spans_csr(cps, row)
+    assert counts.sum() == len(spans) and (spans[:, 1] > spans[:, 0]).all()
+    assert counts.tolist() == [len(x) for x in got]

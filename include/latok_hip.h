@@ -85,6 +85,14 @@ int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t
                             int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                             int flags, void* stream);
 
+/* Token feature vectors: reference featurize() (default_tokenizer.py:163-191) for a whole batch without the n x 25
+ * matrix.  Per kept token k: spans4_out[4k..4k+3] = {raw_start, raw_end, strip_start, strip_end} (LaToken.start_idx /
+ * end_idx are the raw span, LaToken.text is text[strip_start:strip_end]); features_out[25k..25k+24] = sum of the 25
+ * feature columns over the raw span in uint8 wrap-around arithmetic (latok.c:342-354).  cap in tokens. */
+int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                               int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
+                               int64_t* n_tokens_out, int flags, void* stream);
+
 /* ---- the reference's three native functions, one string at a time (compat surface) ---------------------------- */
 /* _gen_parse_matrix (latok.c:31-138): n code points -> int8[n][25], C-contiguous. */
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream);

@@ -12,3 +12,26 @@ All compute goes through ``liblatok_hip.so`` (C ABI in include/latok_hip.h).  Th
 harmless, but every compute call raises ``RuntimeError`` when the library or a HIP device is missing.
 """
 __version__ = "0.1.0"
+
+
+def install_as_latok():
+    """Register this package under the reference's import names, so unmodified reference callers keep working:
+
+        import latok_amd; latok_amd.install_as_latok()
+        from latok.core.default_tokenizer import tokenize      # reference spelling, HIP implementation
+        from latok.latok import _gen_parse_matrix
+
+    (reference import sites: latok/core/default_tokenizer.py:33-36, scripts/timing/time_tokenizer.py:20-21).
+    Refuses to shadow a different, already imported ``latok`` package."""
+    import importlib
+    import sys
+    me = sys.modules[__name__]
+    other = sys.modules.get("latok")
+    if other is not None and other is not me:
+        raise RuntimeError("a different 'latok' package is already imported")
+    names = {"latok": __name__, "latok.latok": __name__ + ".latok", "latok.core": __name__ + ".core",
+             "latok.core.offsets": __name__ + ".core.offsets", "latok.core.latok_utils": __name__ + ".core.latok_utils",
+             "latok.core.default_tokenizer": __name__ + ".core.default_tokenizer"}
+    for alias, real in names.items():
+        sys.modules[alias] = importlib.import_module(real)
+    return me

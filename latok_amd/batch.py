@@ -93,6 +93,37 @@ def token_spans_csr(cps, row_off):
     return counts, spans[:n_tok.value].copy()
 
 
+def token_features_csr(cps, row_off):
+    """(counts int64[n], spans int64[n_tokens, 4] = {raw_start, raw_end, strip_start, strip_end},
+    features int8[n_tokens, 25]): reference featurize() for a whole batch, without the n x 25 matrix."""
+    cps, row_off = _csr(cps, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    cap = max(total, 1)
+    spans = np.empty((cap, 4), np.int64)
+    feats = np.empty((cap, _lib.FEATURE_COUNT), np.int8)
+    n_tok = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_token_features_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
+                                              _ptr(feats), cap, C.byref(n_tok), 0, None))
+    return counts, spans[:n_tok.value].copy(), feats[:n_tok.value].copy()
+
+
+def featurize_batch(texts):
+    """list[str] -> list[list[LaToken]], each as list(featurize(text)) of the reference."""
+    from .core.latok_utils import LaToken
+    if len(texts) == 0:
+        return []
+    cps, row_off = pack(texts)
+    counts, spans, feats = token_features_csr(cps, row_off)
+    out, k = [], 0
+    for text, n in zip(texts, counts.tolist()):
+        out.append([LaToken(text[c:d], a, b, feats[k + j]) for j, (a, b, c, d) in enumerate(spans[k:k + n].tolist())])
+        k += n
+    return out
+
+
 def spans_from_offsets(text, nz):
     """Token strings of one text from its boundary offsets, as the reference's loop builds them
     (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""

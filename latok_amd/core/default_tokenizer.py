@@ -92,12 +92,9 @@ def tokenize(text: str):
 
 def featurize(text: str):
     """Yield the tokens of ``text`` as ``LaToken`` with their summed feature vectors
-    (reference default_tokenizer.py:163-191).  The reference indexes matrix rows with ``np.arange(..., dtype=np.int8)``
-    and therefore breaks past character 127; rows are summed here for any position."""
-    non_zero = _boundaries(text)
-    m = _gen_parse_matrix(text)
-    if len(non_zero) > 0:
-        for a, b in _spans(text, non_zero):
-            token = text[a:b].strip()
-            if token:
-                yield LaToken(token, a, b, m[a:b].sum(axis=0, dtype=np.int64).astype(np.int8))
+    (reference default_tokenizer.py:163-191), computed on the device without building the n x 25 matrix.
+    start_idx / end_idx are the unstripped span between boundaries, like the reference; the reference indexes matrix
+    rows with ``np.arange(..., dtype=np.int8)`` and therefore breaks past character 127 -- any position works here."""
+    if len(text) == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    yield from _batch.featurize_batch([text])[0]

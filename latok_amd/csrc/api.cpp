@@ -272,7 +272,8 @@ int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_
 // shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
 static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
-                          void* stream) {
+                          void* stream, int8_t* features_out = nullptr) {
+    const bool feats = features_out != nullptr;
     int rc = need_init();
     if (rc) return rc;
     if (!n_items_out) return fail(LATOK_ERR_INVALID, "the total-count output pointer is NULL");
@@ -320,15 +321,27 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
     if (n_items == 0) return LATOK_OK;
     if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
-    const size_t item_bytes = spans ? 16 : 8;
+    const size_t item_bytes = feats ? 32 : (spans ? 16 : 8);
     int64_t* d_items = items_out;
+    int8_t* d_feat = features_out;
     if (!dev) {
         if ((rc = g.h_out.ensure((size_t)n_items * item_bytes))) return rc;
         d_items = (int64_t*)g.h_out.p;
+        if (feats) {
+            if ((rc = g.h_aux.ensure((size_t)n_items * LATOK_FEATURE_COUNT))) return rc;
+            d_feat = (int8_t*)g.h_aux.p;
+        }
     }
-    if (spans) HIP_TRY(latok::launch_write_spans(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
+    if (feats)
+        HIP_TRY(latok::launch_write_features(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, d_cps,
+                                             (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p,
+                                             d_feat, st));
+    else if (spans) HIP_TRY(latok::launch_write_spans(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
     else HIP_TRY(latok::launch_write_offsets(d_bits, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
-    if (!dev) HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
+        if (feats) HIP_TRY(hipMemcpyAsync(features_out, d_feat, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return LATOK_OK;
 }
@@ -346,6 +359,16 @@ int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t
                             void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     return compact_common(true, cps, row_off, n_str, total, counts_out, spans_out, spans_cap, n_tokens_out, flags, stream);
+}
+
+int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+                               int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
+                               int64_t* n_tokens_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!features_out && cap > 0) return fail(LATOK_ERR_INVALID, "features_out is NULL");
+    int8_t dummy = 0;
+    return compact_common(true, cps, row_off, n_str, total, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
+                          features_out ? features_out : &dummy);
 }
 
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream) {

@@ -20,6 +20,26 @@ __device__ __forceinline__ uint32_t base_word(const uint8_t* t1, const uint8_t* 
     return cw[t2cls[((uint32_t)t1[hi] << kTblShift) | (cp & ((1u << kTblShift) - 1u))]];
 }
 
+// 25 feature bits of one char from its base word `w` and the base words of its neighbours inside the string
+// (p = previous, x = next, y = after next; 0 where they do not exist).  Bit c = reference column c (offsets.py:24-49).
+__device__ __forceinline__ uint32_t feature_row_bits(uint32_t w, uint32_t p, uint32_t x, uint32_t y, bool first, bool last) {
+    uint32_t r = w & 0xFFFu;
+    r |= ((p >> 0) & 1u) << 12;                        // PREV_ALPHA
+    r |= ((x >> 0) & 1u) << 13;                        // NEXT_ALPHA
+    r |= ((p >> 1) & 1u) << 14;                        // PREV_ALPHA_NUM
+    r |= ((x >> 1) & 1u) << 15;                        // NEXT_ALPHA_NUM
+    r |= ((p >> 3) & 1u) << 16;                        // PREV_LOWER
+    r |= ((x >> 3) & 1u) << 17;                        // NEXT_LOWER
+    r |= (first ? 1u : (p >> 5) & 1u) << 18;           // PREV_SPACE (string start counts as space)
+    r |= (last ? 1u : (x >> 5) & 1u) << 19;            // NEXT_SPACE (string end counts as space)
+    r |= ((p >> 6) & 1u) << 20;                        // PREV_SYMBOL
+    r |= ((x >> 8) & 1u) << 21;                        // NEXT_AT
+    r |= ((x >> 10) & 1u) << 22;                       // NEXT_SLASH
+    r |= ((y >> 0) & 1u) << 23;                        // AFTER_NEXT_ALPHA
+    r |= ((y >> 10) & 1u) << 24;                       // AFTER_NEXT_SLASH
+    return r;
+}
+
 __global__ void k_parse_matrix(const uint32_t* __restrict__ cps, int64_t n, const uint8_t* __restrict__ t1,
                                const uint8_t* __restrict__ t2cls, const uint16_t* __restrict__ cw,
                                int8_t* __restrict__ out) {
@@ -29,22 +49,10 @@ __global__ void k_parse_matrix(const uint32_t* __restrict__ cps, int64_t n, cons
     const uint32_t p = i > 0 ? base_word(t1, t2cls, cw, cps[i - 1]) : 0u;
     const uint32_t x = i + 1 < n ? base_word(t1, t2cls, cw, cps[i + 1]) : 0u;
     const uint32_t y = i + 2 < n ? base_word(t1, t2cls, cw, cps[i + 2]) : 0u;
+    const uint32_t bits = feature_row_bits(w, p, x, y, i == 0, i + 1 == n);
     int8_t* row = out + i * 25;
 #pragma unroll
-    for (int c = 0; c < 12; ++c) row[c] = (int8_t)((w >> c) & 1u);
-    row[12] = (int8_t)((p >> 0) & 1u);                         // PREV_ALPHA
-    row[13] = (int8_t)((x >> 0) & 1u);                         // NEXT_ALPHA
-    row[14] = (int8_t)((p >> 1) & 1u);                         // PREV_ALPHA_NUM
-    row[15] = (int8_t)((x >> 1) & 1u);                         // NEXT_ALPHA_NUM
-    row[16] = (int8_t)((p >> 3) & 1u);                         // PREV_LOWER
-    row[17] = (int8_t)((x >> 3) & 1u);                         // NEXT_LOWER
-    row[18] = (int8_t)(i > 0 ? (p >> 5) & 1u : 1u);            // PREV_SPACE (string start counts as space)
-    row[19] = (int8_t)(i + 1 < n ? (x >> 5) & 1u : 1u);        // NEXT_SPACE (string end counts as space)
-    row[20] = (int8_t)((p >> 6) & 1u);                         // PREV_SYMBOL
-    row[21] = (int8_t)((x >> 8) & 1u);                         // NEXT_AT
-    row[22] = (int8_t)((x >> 10) & 1u);                        // NEXT_SLASH
-    row[23] = (int8_t)((y >> 0) & 1u);                         // AFTER_NEXT_ALPHA
-    row[24] = (int8_t)((y >> 10) & 1u);                        // AFTER_NEXT_SLASH
+    for (int c = 0; c < 25; ++c) row[c] = (int8_t)((bits >> c) & 1u);
 }
 
 hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1, const uint8_t* t2cls,
@@ -167,10 +175,21 @@ __device__ __forceinline__ int64_t prev_zero_end(const uint64_t* bits, int64_t f
     return from;
 }
 
-template <bool WRITE>
+// FEATURES: additionally the reference's per-token feature vector (featurize, default_tokenizer.py:163-191): the
+// sum of the 25 matrix columns over the UNSTRIPPED span between two boundaries (uint8 wrap-around like
+// _combine_matrix_rows' 1-D branch, latok.c:342-354), and spans become {raw_start, raw_end, strip_start, strip_end}.
+struct FeatTables {
+    const uint32_t* cps;
+    const uint8_t* t1;
+    const uint8_t* t2cls;
+    const uint16_t* cw;
+    int8_t* features;   // [n_tokens][25]
+};
+
+template <bool WRITE, bool FEATURES>
 __global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
                               const int64_t* __restrict__ row_off, int64_t n_str, int64_t* __restrict__ counts,
-                              const int64_t* __restrict__ out_base, int64_t* __restrict__ spans) {
+                              const int64_t* __restrict__ out_base, int64_t* __restrict__ spans, FeatTables F) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_str) return;
     const int64_t lo = row_off[s], hi = row_off[s + 1];
@@ -180,7 +199,26 @@ __global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t*
         const int64_t a2 = next_zero_bit(space, from, to);
         if (a2 >= to) return;                         // whitespace only: dropped like the reference's `if token:`
         const int64_t e2 = prev_zero_end(space, a2, to);
-        if (WRITE) { spans[2 * k] = a2 - lo; spans[2 * k + 1] = e2 - lo; }
+        if (WRITE && !FEATURES) { spans[2 * k] = a2 - lo; spans[2 * k + 1] = e2 - lo; }
+        if (WRITE && FEATURES) {
+            spans[4 * k] = from - lo; spans[4 * k + 1] = to - lo; spans[4 * k + 2] = a2 - lo; spans[4 * k + 3] = e2 - lo;
+            uint8_t acc[25];
+#pragma unroll
+            for (int c = 0; c < 25; ++c) acc[c] = 0;
+            uint32_t p = from > lo ? base_word(F.t1, F.t2cls, F.cw, F.cps[from - 1]) : 0u;
+            uint32_t w = base_word(F.t1, F.t2cls, F.cw, F.cps[from]);
+            uint32_t x = from + 1 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[from + 1]) : 0u;
+            for (int64_t i = from; i < to; ++i) {
+                const uint32_t y = i + 2 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[i + 2]) : 0u;
+                const uint32_t r = feature_row_bits(w, p, x, y, i == lo, i + 1 == hi);
+#pragma unroll
+                for (int c = 0; c < 25; ++c) acc[c] = (uint8_t)(acc[c] + ((r >> c) & 1u));
+                p = w; w = x; x = y;
+            }
+            int8_t* dst = F.features + k * 25;
+#pragma unroll
+            for (int c = 0; c < 25; ++c) dst[c] = (int8_t)acc[c];
+        }
         ++k;
         ++n;
     };
@@ -202,15 +240,24 @@ __global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t*
 hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
                               int64_t* counts, hipStream_t st) {
     if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_token_spans<false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
-                       row_off, n_str, counts, nullptr, nullptr);
+    hipLaunchKernelGGL((k_token_spans<false, false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
+                       row_off, n_str, counts, nullptr, nullptr, FeatTables{});
     return hipGetLastError();
 }
 hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
                               const int64_t* out_base, int64_t* spans, hipStream_t st) {
     if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_token_spans<true>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
-                       row_off, n_str, nullptr, out_base, spans);
+    hipLaunchKernelGGL((k_token_spans<true, false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
+                       row_off, n_str, nullptr, out_base, spans, FeatTables{});
+    return hipGetLastError();
+}
+hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                                 const int64_t* out_base, int64_t* spans4, const uint32_t* cps, const uint8_t* t1,
+                                 const uint8_t* t2cls, const uint16_t* cw, int8_t* features, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    FeatTables F{cps, t1, t2cls, cw, features};
+    hipLaunchKernelGGL((k_token_spans<true, true>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
+                       row_off, n_str, nullptr, out_base, spans4, F);
     return hipGetLastError();
 }
 

@@ -73,6 +73,9 @@ hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const
                               int64_t* counts, hipStream_t st);
 hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
                               const int64_t* out_base, int64_t* spans, hipStream_t st);
+hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
+                                 const int64_t* out_base, int64_t* spans4, const uint32_t* cps, const uint8_t* t1,
+                                 const uint8_t* t2cls, const uint16_t* cw, int8_t* features, hipStream_t st);
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
 hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);

@@ -327,3 +327,29 @@ def test_token_spans_on_device(gpu, oracle):
     counts, spans = batch.token_spans_csr(cps, row)
     assert counts.sum() == len(spans) and (spans[:, 1] > spans[:, 0]).all()
     assert counts.tolist() == [len(x) for x in got]
+
+
+def test_featurize_on_device(gpu, oracle):
+    """featurize(): per-token sum of matrix rows over the unstripped span (default_tokenizer.py:163-191), against the
+    oracle's matrix; includes tokens beyond char 127 (where the reference's int8 row index overflows) and > 255 chars
+    (uint8 wrap-around of the sums)."""
+    from latok_amd import batch
+    from latok_amd.core import default_tokenizer as dt
+    rng = random.Random(5)
+    texts = [G1, "a", " x ", "http://" + "a" * 300 + " tail", "foo@bar.com, .@user hi #tag"] + \
+        random_strings(rng, 120, 1, 200, ALPHABETS["mixed"]) + random_strings(rng, 30, 1, 300, ALPHABETS["words"])
+    got = batch.featurize_batch(texts)
+    for t, toks in zip(texts, got):
+        m = oracle.gen_parse_matrix(t).astype(np.uint8)
+        nz = oracle.split_offsets(t).tolist() + [len(t)]
+        want = []
+        for a, b in zip(nz[:-1], nz[1:]):
+            if t[a:b].strip():
+                want.append((t[a:b].strip(), a, b, m[a:b].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8)))
+        assert len(toks) == len(want), t
+        for tok, (txt, a, b, f) in zip(toks, want):
+            assert (tok.text, tok.start_idx, tok.end_idx) == (txt, a, b)
+            assert tok.features.dtype == np.int8 and np.array_equal(tok.features, f), (t[a:b], tok.features, f)
+    one = list(dt.featurize(G1))
+    assert [x.text for x in one] == oracle.tokenize(G1)
+    assert one[3].feature_weights()["Twitter"] == 1 and one[3].weight() > 0

@@ -126,3 +126,15 @@ def test_product_never_touches_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(ROOT, "latok_amd", "liblatok_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out and "fused_model" not in out
+
+
+def test_install_as_latok_aliases_reference_import_names():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import latok_amd; latok_amd.install_as_latok(); "
+            "from latok.core.default_tokenizer import tokenize, featurize, gen_split_mask, C_SPLIT; "
+            "from latok.latok import _gen_parse_matrix, _gen_block_mask, _combine_matrix_rows; "
+            "from latok.core.latok_utils import gen_parse_matrix, LaToken, FEATURE_NAMES; import latok.core.offsets as oft; "
+            "import latok_amd.core.default_tokenizer as d; assert tokenize is d.tokenize and oft.FEATURE_COUNT == 25; print('ok')") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]

@@ -71,9 +71,11 @@ __device__ __forceinline__ uint32_t classify4(const uint8_t* t1, const uint8_t* 
 
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wave is executed in issue order; this only stops the compiler from reordering across it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // fences restricted to the LDS address space: a plain wavefront fence makes hipcc drain vmcnt(0) as well, i.e.
+    // wait for this tile's output store (and any load in flight) before the next tile's loads can be issued
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // ---- cross-lane helpers on DPP / readlane (no LDS round trip, unlike ds_bpermute-based __shfl) -----------------

@@ -353,3 +353,42 @@ def test_featurize_on_device(gpu, oracle):
     one = list(dt.featurize(G1))
     assert [x.text for x in one] == oracle.tokenize(G1)
     assert one[3].feature_weights()["Twitter"] == 1 and one[3].weight() > 0
+
+
+def test_beyond_4GiB_batch(gpu, oracle):
+    """One GPU's share of BASELINE configs[3]: 12.5 M strings, 1.6e9 chars = 6.4 GB of code points, device resident
+    (byte offsets exceed 32 bits).  Device-pointer API; oracle parity on slices from the head, the middle and the tail."""
+    from latok_amd import _lib
+    lib = gpu
+    n_str, seed, model, lo, hi = 12_500_000, 0x1A70C0DE, 0, 64, 192
+    row = np.zeros(n_str + 1, np.int64)
+    _lib.check(lib.latok_corpus_offsets(seed, 0, n_str, lo, hi, row.ctypes.data))
+    total = int(row[-1])
+    assert total * 4 > 2 ** 32
+    n_words = (total + 63) // 64
+    d_row, d_cps, d_bits = lib.latok_dev_alloc(row.nbytes), lib.latok_dev_alloc(total * 4), lib.latok_dev_alloc(n_words * 8)
+    assert d_row and d_cps and d_bits
+    try:
+        _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
+        _lib.check(lib.latok_corpus_fill_device(seed, model, 0, n_str, d_row, d_cps, None))
+        _lib.check(lib.latok_split_mask_batch(d_cps, d_row, n_str, total, d_bits, _lib.DEVICE_PTRS, None))
+        _lib.check(lib.latok_sync())
+        bits = np.zeros(n_words, np.uint64)
+        _lib.check(lib.latok_memcpy_d2h(bits.ctypes.data, d_bits, bits.nbytes))
+        for s0 in (0, n_str // 2, n_str - 4000):
+            s1 = s0 + 4000
+            c0, c1 = int(row[s0]), int(row[s1])
+            cps = np.zeros(c1 - c0, np.uint32)
+            _lib.check(lib.latok_memcpy_d2h(cps.ctypes.data, d_cps + 4 * c0, cps.nbytes))
+            ov, _ = oracle.split_batch(cps, row[s0:s1 + 1] - c0, want_bits=False)
+            w0, w1 = c0 // 64, (c1 + 63) // 64
+            got = bits_to_bool(bits[w0:w1], (w1 - w0) * 64)[c0 - w0 * 64:c1 - w0 * 64]
+            assert np.array_equal(got, ov != 0), s0
+        # every string start is a boundary, nothing set beyond the last char
+        starts = row[:-1]
+        assert ((bits[starts >> 6] >> (starts & 63).astype(np.uint64)) & np.uint64(1)).all()
+        if total % 64:
+            assert int(bits[-1]) >> (total % 64) == 0
+    finally:
+        for p in (d_row, d_cps, d_bits):
+            lib.latok_dev_free(p)

@@ -76,7 +76,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scalar, h_aux;
+    DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scan_tot, tok_sid, scalar, h_aux;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
 
@@ -235,7 +235,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -312,7 +312,9 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
     if (spans) HIP_TRY(latok::launch_count_spans(d_bits, d_space, d_row, n_str, d_counts, st));
     else HIP_TRY(latok::launch_count_boundaries(d_bits, d_row, n_str, d_counts, st));
-    HIP_TRY(latok::launch_exclusive_scan(d_counts, n_str, (int64_t*)g.bases.p, (int64_t*)g.scalar.p, st));
+    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(n_str) * 8))) return rc;   // block totals of the scan
+    HIP_TRY(latok::launch_exclusive_scan(d_counts, n_str, (int64_t*)g.bases.p, (int64_t*)g.scalar.p,
+                                         (int64_t*)g.scan_tot.p, st));
     int64_t n_items = 0;
     HIP_TRY(hipMemcpyAsync(&n_items, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -332,10 +334,12 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
             d_feat = (int8_t*)g.h_aux.p;
         }
     }
-    if (feats)
-        HIP_TRY(latok::launch_write_features(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, d_cps,
-                                             (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p,
-                                             d_feat, st));
+    if (feats) {
+        if ((rc = g.tok_sid.ensure((size_t)n_items * 8))) return rc;   // token -> string map between the two passes
+        HIP_TRY(latok::launch_write_features(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, n_items,
+                                             (int64_t*)g.tok_sid.p, d_cps, (const uint8_t*)g.t1.p,
+                                             (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p, d_feat, st));
+    }
     else if (spans) HIP_TRY(latok::launch_write_spans(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
     else HIP_TRY(latok::launch_write_offsets(d_bits, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
     if (!dev) {

@@ -184,6 +184,7 @@ struct FeatTables {
     const uint8_t* t2cls;
     const uint16_t* cw;
     int8_t* features;   // [n_tokens][25]
+    int64_t* tok_sid;   // [n_tokens] scratch: string id of every token (pass 1 -> pass 2)
 };
 
 template <bool WRITE, bool FEATURES>
@@ -200,24 +201,9 @@ __global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t*
         if (a2 >= to) return;                         // whitespace only: dropped like the reference's `if token:`
         const int64_t e2 = prev_zero_end(space, a2, to);
         if (WRITE && !FEATURES) { spans[2 * k] = a2 - lo; spans[2 * k + 1] = e2 - lo; }
-        if (WRITE && FEATURES) {
+        if (WRITE && FEATURES) {   // pass 1 of featurize: spans + owning string; the sums are done one thread per token
             spans[4 * k] = from - lo; spans[4 * k + 1] = to - lo; spans[4 * k + 2] = a2 - lo; spans[4 * k + 3] = e2 - lo;
-            uint8_t acc[25];
-#pragma unroll
-            for (int c = 0; c < 25; ++c) acc[c] = 0;
-            uint32_t p = from > lo ? base_word(F.t1, F.t2cls, F.cw, F.cps[from - 1]) : 0u;
-            uint32_t w = base_word(F.t1, F.t2cls, F.cw, F.cps[from]);
-            uint32_t x = from + 1 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[from + 1]) : 0u;
-            for (int64_t i = from; i < to; ++i) {
-                const uint32_t y = i + 2 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[i + 2]) : 0u;
-                const uint32_t r = feature_row_bits(w, p, x, y, i == lo, i + 1 == hi);
-#pragma unroll
-                for (int c = 0; c < 25; ++c) acc[c] = (uint8_t)(acc[c] + ((r >> c) & 1u));
-                p = w; w = x; x = y;
-            }
-            int8_t* dst = F.features + k * 25;
-#pragma unroll
-            for (int c = 0; c < 25; ++c) dst[c] = (int8_t)acc[c];
+            F.tok_sid[k] = s;
         }
         ++k;
         ++n;
@@ -237,6 +223,32 @@ __global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t*
     if (!WRITE) counts[s] = n;
 }
 
+// pass 2 of featurize: one thread per token sums the 25 feature bits of every char of the token's raw span
+__global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_tok, const int64_t* __restrict__ row_off,
+                                 FeatTables F) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_tok) return;
+    const int64_t s = F.tok_sid[k];
+    const int64_t lo = row_off[s], hi = row_off[s + 1];
+    const int64_t from = lo + spans4[4 * k], to = lo + spans4[4 * k + 1];
+    uint8_t acc[25];
+#pragma unroll
+    for (int c = 0; c < 25; ++c) acc[c] = 0;
+    uint32_t p = from > lo ? base_word(F.t1, F.t2cls, F.cw, F.cps[from - 1]) : 0u;
+    uint32_t w = base_word(F.t1, F.t2cls, F.cw, F.cps[from]);
+    uint32_t x = from + 1 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[from + 1]) : 0u;
+    for (int64_t i = from; i < to; ++i) {
+        const uint32_t y = i + 2 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[i + 2]) : 0u;
+        const uint32_t r = feature_row_bits(w, p, x, y, i == lo, i + 1 == hi);
+#pragma unroll
+        for (int c = 0; c < 25; ++c) acc[c] = (uint8_t)(acc[c] + ((r >> c) & 1u));
+        p = w; w = x; x = y;
+    }
+    int8_t* dst = F.features + k * 25;
+#pragma unroll
+    for (int c = 0; c < 25; ++c) dst[c] = (int8_t)acc[c];
+}
+
 hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
                               int64_t* counts, hipStream_t st) {
     if (n_str <= 0) return hipSuccess;
@@ -252,40 +264,90 @@ hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const
     return hipGetLastError();
 }
 hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                                 const int64_t* out_base, int64_t* spans4, const uint32_t* cps, const uint8_t* t1,
-                                 const uint8_t* t2cls, const uint16_t* cw, int8_t* features, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    FeatTables F{cps, t1, t2cls, cw, features};
+                                 const int64_t* out_base, int64_t* spans4, int64_t n_tok, int64_t* tok_sid,
+                                 const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
+                                 int8_t* features, hipStream_t st) {
+    if (n_str <= 0 || n_tok <= 0) return hipSuccess;
+    FeatTables F{cps, t1, t2cls, cw, features, tok_sid};
     hipLaunchKernelGGL((k_token_spans<true, true>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
                        row_off, n_str, nullptr, out_base, spans4, F);
+    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, st, spans4, n_tok, row_off, F);
     return hipGetLastError();
 }
 
-// single-block exclusive scan of int64 counts (chunk per thread + Hillis-Steele across threads)
-__global__ __launch_bounds__(1024) void k_exclusive_scan(const int64_t* __restrict__ in, int64_t n,
-                                                         int64_t* __restrict__ out, int64_t* __restrict__ total) {
-    __shared__ long long s[1024];
-    const int tid = threadIdx.x;
-    const int64_t chunk = (n + 1023) / 1024;
-    const int64_t lo = min((int64_t)tid * chunk, n), hi = min(lo + chunk, n);
-    long long sum = 0;
-    for (int64_t i = lo; i < hi; ++i) sum += in[i];
-    s[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        long long o = 0;
-        if (tid >= d) o = s[tid - d];
-        __syncthreads();
-        s[tid] += o;
-        __syncthreads();
+// ---- device-wide exclusive scan of int64 counts: per-block scan + scan of the block totals + fix-up -----------------
+constexpr int kScanBlock = 1024;
+constexpr int kScanItems = 4;                       // elements per thread
+constexpr int kScanChunk = kScanBlock * kScanItems; // elements per block
+
+__device__ __forceinline__ long long block_exclusive_scan_ll(long long v, long long* total, long long* lds /*[16]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
     }
-    long long run = tid > 0 ? s[tid - 1] : 0;
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    long long before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        const long long x = lds[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+// out[i] = exclusive prefix inside the block's chunk; block_tot[b] = sum of the chunk
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const int64_t* __restrict__ in, int64_t n,
+                                                           int64_t* __restrict__ out, int64_t* __restrict__ block_tot) {
+    __shared__ long long lds[kScanBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
+    long long v[kScanItems], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = base + j < n ? in[base + j] : 0;
+        sum += v[j];
+    }
+    long long tot;
+    long long run = block_exclusive_scan_ll(sum, &tot, lds);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+// exclusive scan of the block totals by one block (in place), grand total -> *total
+__global__ __launch_bounds__(kScanBlock) void k_scan_totals(int64_t* __restrict__ block_tot, int64_t n_blocks,
+                                                            int64_t* __restrict__ total) {
+    __shared__ long long lds[kScanBlock / 64];
+    const int64_t per = (n_blocks + kScanBlock - 1) / kScanBlock;
+    const int64_t lo = min((int64_t)threadIdx.x * per, n_blocks), hi = min(lo + per, n_blocks);
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += block_tot[i];
+    long long tot;
+    long long run = block_exclusive_scan_ll(sum, &tot, lds);
     for (int64_t i = lo; i < hi; ++i) {
-        const long long v = in[i];
-        out[i] = run;
+        const long long v = block_tot[i];
+        block_tot[i] = run;
         run += v;
     }
-    if (tid == 1023) *total = s[1023];
+    if (threadIdx.x == 0) *total = tot;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ out, int64_t n,
+                                                         const int64_t* __restrict__ block_tot) {
+    const long long add = block_tot[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+        if (base + j < n) out[base + j] += add;
 }
 
 hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
@@ -295,10 +357,15 @@ hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off,
                        n_str, counts);
     return hipGetLastError();
 }
-hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, hipStream_t st) {
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, in, n, out, total);
+hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
+                                 hipStream_t st) {
+    const int64_t n_blocks = scan_blocks(n);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, in, n, out, block_tot);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, st, block_tot, n_blocks, total);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, out, n, block_tot);
     return hipGetLastError();
 }
+int64_t scan_blocks(int64_t n) { return n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1; }
 hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
                                 int64_t* offsets, hipStream_t st) {
     if (n_str <= 0) return hipSuccess;

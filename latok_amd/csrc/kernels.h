@@ -66,7 +66,9 @@ hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t strid
                                int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
 hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
                                    hipStream_t st);
-hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, hipStream_t st);
+int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_tot`
+hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
+                                 hipStream_t st);
 hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
                                 int64_t* offsets, hipStream_t st);
 hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
@@ -74,8 +76,9 @@ hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const
 hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
                               const int64_t* out_base, int64_t* spans, hipStream_t st);
 hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                                 const int64_t* out_base, int64_t* spans4, const uint32_t* cps, const uint8_t* t1,
-                                 const uint8_t* t2cls, const uint16_t* cw, int8_t* features, hipStream_t st);
+                                 const int64_t* out_base, int64_t* spans4, int64_t n_tok, int64_t* tok_sid,
+                                 const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
+                                 int8_t* features, hipStream_t st);
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
 hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);

@@ -49,7 +49,8 @@ __device__ unsigned long long g_stamp_cnt;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t stage_addr(uint32_t p) { return p + ((p >> 6) << 4); }  // 64-byte rows, 16 B pad
+// staging layout: 64-byte rows padded to 80 bytes: byte p of the tile lives at p + 16 * (p / 64)
+__device__ __forceinline__ uint32_t stage_addr(uint32_t p) { return p + ((p >> 6) << 4); }
 
 __device__ __forceinline__ uint32_t classify1(const uint8_t* t1, const uint8_t* t2, uint32_t cp) {
     const uint32_t hi = min(cp >> kTblShift, (uint32_t)(kStage1Len - 1));
@@ -139,17 +140,14 @@ struct TileLds {
     lk_u64* bw;            // 65 words of string-start bits, wave private
 };
 
-// PF: software prefetch.  `v` carries the 16 KiB of code points of a full tile in registers; when `v_valid` the loads
-// for THIS tile were issued while the previous tile was in phase 2.  After classifying, the loads of tile `t_next` are
-// issued so that they fly under this tile's phase 2.  Returns whether `v` now holds tile `t_next`.
+// One tile = 4096 chars, one wave.  (Register prefetch of the next tile -- full, half, quarter; 8/10/12/16 waves per
+// CU -- was measured and gives nothing: see DESIGN.md, so the tile function stays simple.)
 // idx0 = index of the first string that starts at or after the tile's first char.
-// PRELOADED: the caller already requested the tile's 16 KiB into `vin` (first tile of a workgroup's first segment).
 // With write_summary the tile summary is written to *summ_l (LDS copy of the segment).
 // Returns this lane's 64-bit boundary word (kModeBits); with DEFER the caller stores it later (write combining).
-template <int MODE, bool PRELOADED = false, bool DEFER = false>
+template <int MODE, bool DEFER = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
-                                             int tail_zero, bool write_summary, int4* summ_l, int lane,
-                                             const u32x4* vin = nullptr
+                                             int tail_zero, bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
                                              , unsigned long long* stamp_acc = nullptr
 #endif
@@ -160,6 +158,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #endif
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
+    const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
     LATOK_STAMP(0);
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
@@ -176,19 +175,14 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
-        if (PRELOADED) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = vin[i];
-        } else {
-            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-        }
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
         LATOK_STAMP(1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
-            *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
         }
     } else {
 #pragma unroll 1
@@ -200,7 +194,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
             v.z = p + 2 < total ? P.cps[p + 2] : 0xFFFFFFFFu;
             v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
             const uint32_t c = classify4(L.t1, L.t2, v);
-            *reinterpret_cast<uint32_t*>(L.stage + stage_addr(256u * i + 4u * lane)) = c;
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
@@ -256,13 +250,14 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         uint32_t d[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint4 q = *reinterpret_cast<const uint4*>(L.stage + stage_addr(64u * lane + 16u * k));
+            const uint4 q = *reinterpret_cast<const uint4*>(L.stage + 80u * lane + 16u * k);   // == stage_addr(64 lane + 16 k)
             d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
         }
         lk_halo h;
-        h.prev = lane > 0 ? L.stage[stage_addr(64u * lane - 1u)] : L.halo[0];
-        h.next0 = lane < 63 ? L.stage[stage_addr(64u * lane + 64u)] : L.halo[1];
-        h.next1 = lane < 63 ? L.stage[stage_addr(64u * lane + 65u)] : L.halo[2];
+        // neighbours of the word in the padded layout: stage_addr(64 lane - 1) = 80 lane - 17, (64 lane + 64) = 80 lane + 80
+        h.prev = lane > 0 ? L.stage[80u * lane - 17u] : L.halo[0];
+        h.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[1];
+        h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
         lk_bitslice64(d, plane);
@@ -605,9 +600,9 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 #define LATOK_STAMP_PARAM
 #endif
 
-template <int MODE, bool FIRST>
-__device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane, int wave,
-                                            const u32x4* v, bool v_valid LATOK_STAMP_PARAM) {
+template <int MODE>
+__device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
+                                            int wave LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
     const TileLds L = wave_lds(lds, wave);
     int* tf = reinterpret_cast<int*>(lds + kLdsTf);
@@ -662,14 +657,8 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
         if (++slot == 8) flush();
     };
-    int k = wave;
-    if (FIRST && v_valid) {   // this wave's first tile was requested before the table copy and the index prologue
-        const lk_u64 w = process_tile<MODE, true, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, v LATOK_STAMP_ARG);
-        if (kDefer) put(w, k);
-        k += kWPB;
-    }
-    for (; k < n_seg; k += kWPB) {
-        const lk_u64 w = process_tile<MODE, false, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane, nullptr LATOK_STAMP_ARG);
+    for (int k = wave; k < n_seg; k += kWPB) {
+        const lk_u64 w = process_tile<MODE, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
         stamp_acc[0] += 1;
@@ -704,27 +693,12 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar tile arithmetic
     if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
 
-    // every wave requests its first tile (16 KiB) before anything else: the HBM latency then overlaps the table copy
-    // and the index prologue of the first segment.  `v` is dead in the steady-state loop below.
-    u32x4 v[16];
-    bool v_valid = false;
-    {
-        const int64_t t = (int64_t)blockIdx.x * P.seg_tiles + wave;
-        if (MODE != kModeBlockMask && wave < P.seg_tiles && t < P.n_tiles && (t + 1) * kTile <= P.total) {
-            const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t * kTile) + lane;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-            v_valid = true;
-        }
-    }
     if (MODE != kModeBlockMask) load_tables(lds, P);   // the first segment's barriers publish the tables
 #ifdef LATOK_STAMPS
     unsigned long long stamp_acc[16];
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
 #endif
-    run_segment<MODE, true>(P, lds, blockIdx.x, tid, lane, wave, v, v_valid LATOK_STAMP_ARG);
-    for (int64_t seg = (int64_t)blockIdx.x + gridDim.x; seg < P.n_segs; seg += gridDim.x)
-        run_segment<MODE, false>(P, lds, seg, tid, lane, wave, nullptr, false LATOK_STAMP_ARG);
+    for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) run_segment<MODE>(P, lds, seg, tid, lane, wave LATOK_STAMP_ARG);
 #ifdef LATOK_STAMPS
     if (lane == 0)
         for (int i = 0; i < 9; ++i) atomicAdd(&g_stamp_sum[i], stamp_acc[i]);

@@ -85,6 +85,22 @@ int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t
                             int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                             int flags, void* stream);
 
+/* ---- UTF-8 ingest (one step before the path: the reference reads CPython's PEP-393 buffer, latok.c:53-55,79) ---------
+ * A batch can also be handed over as UTF-8: `utf8` = packed bytes of all strings, `byte_off[n_str + 1]` = byte offset
+ * of each string (byte_off[0] == 0).  The library decodes on the device (one code point per lead byte; input must be
+ * valid UTF-8, "surrogatepass" forms decode as they are, truncated sequences give U+FFFD) and runs the same pipeline.
+ * All results are in CODE-POINT units, exactly what the reference would report for the decoded str.  With host
+ * pointers this moves 1 byte per ASCII char over PCIe instead of 4. */
+int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                            uint32_t* cps_out, int64_t cps_cap, int64_t* cp_row_off_out, int64_t* total_cps_out, int flags,
+                            void* stream);
+int latok_split_offsets_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                   int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
+                                   int64_t* n_offsets_out, int flags, void* stream);
+int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                 int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                 int flags, void* stream);
+
 /* Token feature vectors: reference featurize() (default_tokenizer.py:163-191) for a whole batch without the n x 25
  * matrix.  Per kept token k: spans4_out[4k..4k+3] = {raw_start, raw_end, strip_start, strip_end} (LaToken.start_idx /
  * end_idx are the raw span, LaToken.text is text[strip_start:strip_end]); features_out[25k..25k+24] = sum of the 25

@@ -124,6 +124,66 @@ def featurize_batch(texts):
     return out
 
 
+# ---- UTF-8 ingest -------------------------------------------------------------------------------------------------------
+def pack_utf8(blobs):
+    """list[bytes] (each valid UTF-8) -> (utf8 uint8[total_bytes], byte_off int64[n+1])."""
+    lens = np.fromiter((len(b) for b in blobs), dtype=np.int64, count=len(blobs))
+    byte_off = np.zeros(len(blobs) + 1, np.int64)
+    np.cumsum(lens, out=byte_off[1:])
+    return np.frombuffer(b"".join(blobs), dtype=np.uint8), byte_off
+
+
+def _csr_u8(utf8, byte_off):
+    utf8 = np.ascontiguousarray(utf8, dtype=np.uint8)
+    byte_off = np.ascontiguousarray(byte_off, dtype=np.int64)
+    if byte_off.ndim != 1 or byte_off.size < 1 or (byte_off.size > 1 and utf8.size < int(byte_off[-1])):
+        raise ValueError("byte_off must be n_str + 1 offsets into utf8")
+    return utf8, byte_off
+
+
+def utf8_decode_csr(utf8, byte_off):
+    """Device decode of a UTF-8 CSR batch -> (cps uint32[total_cps], cp_row_off int64[n+1])."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    cps = np.empty(max(total, 1), np.uint32)
+    row = np.zeros(n_str + 1, np.int64)
+    n = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_utf8_decode_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(cps), cps.size, _ptr(row),
+                                           C.byref(n), 0, None))
+    return cps[:n.value].copy(), row
+
+
+def split_offsets_utf8_csr(utf8, byte_off):
+    """(counts, offsets) like split_offsets_csr, input handed over as UTF-8 (1 byte per ASCII char over PCIe).
+    Offsets are code-point indices, as the reference reports them for the decoded str."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    offsets = np.empty(max(total, 1), np.int64)
+    n_off = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_offsets_utf8_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(offsets),
+                                                  offsets.size, C.byref(n_off), 0, None))
+    return counts, offsets[:n_off.value].copy()
+
+
+def token_spans_utf8_csr(utf8, byte_off):
+    """(counts, spans[n_tokens, 2]) like token_spans_csr for a UTF-8 CSR batch; spans are code-point indices."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    spans = np.empty((max(total, 1), 2), np.int64)
+    n_tok = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_token_spans_utf8_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(spans),
+                                                spans.shape[0], C.byref(n_tok), 0, None))
+    return counts, spans[:n_tok.value].copy()
+
+
 def spans_from_offsets(text, nz):
     """Token strings of one text from its boundary offsets, as the reference's loop builds them
     (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""

@@ -77,6 +77,7 @@ struct Ctx {
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scan_tot, tok_sid, scalar, h_aux;
+    DevBuf u_bytes, u_boff, u_cnt, u_row;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
 
@@ -235,7 +236,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -269,10 +270,49 @@ int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_
     return split_common(cps, row_off, n_str, total_chars, values_out, latok::kModeValues, flags, stream);
 }
 
+// UTF-8 ingest: decode a CSR batch of UTF-8 strings into the library's device buffers (g.h_cps = packed code points,
+// g.u_row = code-point row offsets).  Inputs are host or device pointers per `dev`.  One blocking 8-byte read.
+static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                    bool dev, hipStream_t st, int64_t* total_cps_out) {
+    int rc;
+    *total_cps_out = 0;
+    const uint8_t* d_u8 = u8;
+    const int64_t* d_boff = byte_off;
+    if (dev) {
+        if ((rc = resolve_total_device(byte_off, n_str, &total_bytes, st))) return rc;
+    } else {
+        if ((rc = check_csr_host(byte_off, n_str, &total_bytes))) return rc;
+    }
+    if (n_str == 0) return LATOK_OK;
+    if (total_bytes > 0 && !u8) return fail(LATOK_ERR_INVALID, "utf8 buffer is NULL");
+    if (!dev) {
+        if ((rc = g.u_bytes.ensure((size_t)total_bytes + 16))) return rc;
+        if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+        if (total_bytes > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, u8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+        d_u8 = (const uint8_t*)g.u_bytes.p;
+        d_boff = (const int64_t*)g.u_boff.p;
+    }
+    if ((rc = g.u_cnt.ensure((size_t)n_str * 8))) return rc;
+    if ((rc = g.u_row.ensure((size_t)(n_str + 1) * 8))) return rc;
+    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(n_str) * 8))) return rc;
+    HIP_TRY(latok::launch_utf8_count(d_u8, d_boff, n_str, (int64_t*)g.u_cnt.p, st));
+    // exclusive scan of the counts = code-point row offsets; the grand total lands in row[n_str]
+    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.u_cnt.p, n_str, (int64_t*)g.u_row.p,
+                                         (int64_t*)g.u_row.p + n_str, (int64_t*)g.scan_tot.p, st));
+    int64_t total_cps = 0;
+    HIP_TRY(hipMemcpyAsync(&total_cps, (int64_t*)g.u_row.p + n_str, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = g.h_cps.ensure((size_t)total_cps * 4 + 16))) return rc;
+    HIP_TRY(latok::launch_utf8_decode(d_u8, d_boff, n_str, (const int64_t*)g.u_row.p, (uint32_t*)g.h_cps.p, st));
+    *total_cps_out = total_cps;
+    return LATOK_OK;
+}
+
 // shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
 static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
-                          void* stream, int8_t* features_out = nullptr) {
+                          void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr) {
     const bool feats = features_out != nullptr;
     int rc = need_init();
     if (rc) return rc;
@@ -282,7 +322,11 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
-    if (dev) {
+    if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
+        if ((rc = decode_utf8_to_workspace(utf8, row_off, n_str, total, dev, st, &total))) return rc;
+        d_cps = (const uint32_t*)g.h_cps.p;
+        d_row = (const int64_t*)g.u_row.p;
+    } else if (dev) {
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
         if (total > 0 && ((uintptr_t)cps & 15) != 0)
             return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
@@ -291,7 +335,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     }
     if (n_str == 0) return LATOK_OK;
     if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
-    if (!dev) {
+    if (!dev && !utf8) {
         if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
         if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
         if (total > 0) HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
@@ -363,6 +407,46 @@ int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t
                             void* stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     return compact_common(true, cps, row_off, n_str, total, counts_out, spans_out, spans_cap, n_tokens_out, flags, stream);
+}
+
+int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                            uint32_t* cps_out, int64_t cps_cap, int64_t* cp_row_off_out, int64_t* total_cps_out, int flags,
+                            void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    int64_t total_cps = 0;
+    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total_cps))) return rc;
+    *total_cps_out = total_cps;
+    if (n_str == 0) return LATOK_OK;
+    if (total_cps > cps_cap) return fail(LATOK_ERR_INVALID, "cps_cap too small: need %lld", (long long)total_cps);
+    if (!cp_row_off_out || (total_cps > 0 && !cps_out)) return fail(LATOK_ERR_INVALID, "NULL output buffer");
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (total_cps > 0) HIP_TRY(hipMemcpyAsync(cps_out, g.h_cps.p, (size_t)total_cps * 4, kind, st));
+    HIP_TRY(hipMemcpyAsync(cp_row_off_out, g.u_row.p, (size_t)(n_str + 1) * 8, kind, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_split_offsets_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                   int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
+                                   int64_t* n_offsets_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    static const uint8_t empty = 0;
+    return compact_common(false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
+                          n_offsets_out, flags, stream, nullptr, utf8 ? utf8 : &empty);
+}
+
+int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                 int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                 int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    static const uint8_t empty = 0;
+    return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
+                          flags, stream, nullptr, utf8 ? utf8 : &empty);
 }
 
 int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,

@@ -374,6 +374,56 @@ hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, in
     return hipGetLastError();
 }
 
+// ---- UTF-8 ingest: decode a CSR batch of UTF-8 strings to packed UTF-32 on the device --------------
+// The reference never sees UTF-8: it reads CPython's PEP-393 buffer (latok.c:53-55,79).  Feeding the GPU path from
+// UTF-8 cuts the host->device bytes ~4x for ASCII.  One thread per string (strings are short in batch workloads).
+// One code point per lead byte; continuation bytes that do not belong to a lead byte are skipped, truncated or
+// malformed sequences yield U+FFFD -- input is expected to be valid UTF-8 ("surrogatepass" forms decode as they are).
+__device__ __forceinline__ bool utf8_is_lead(uint8_t b) { return (b & 0xC0u) != 0x80u; }
+
+__global__ void k_utf8_count(const uint8_t* __restrict__ u8, const int64_t* __restrict__ byte_off, int64_t n_str,
+                             int64_t* __restrict__ counts) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    int64_t n = 0;
+    for (int64_t i = byte_off[s]; i < byte_off[s + 1]; ++i) n += utf8_is_lead(u8[i]);
+    counts[s] = n;
+}
+
+__global__ void k_utf8_decode(const uint8_t* __restrict__ u8, const int64_t* __restrict__ byte_off, int64_t n_str,
+                              const int64_t* __restrict__ cp_off, uint32_t* __restrict__ cps) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_str) return;
+    const int64_t hi = byte_off[s + 1];
+    int64_t k = cp_off[s];
+    for (int64_t i = byte_off[s]; i < hi;) {
+        const uint32_t b0 = u8[i++];
+        if (!utf8_is_lead((uint8_t)b0)) continue;                 // stray continuation byte
+        uint32_t cp = b0;
+        int extra = 0;
+        if (b0 >= 0xF0u) { cp = b0 & 0x07u; extra = 3; }
+        else if (b0 >= 0xE0u) { cp = b0 & 0x0Fu; extra = 2; }
+        else if (b0 >= 0xC0u) { cp = b0 & 0x1Fu; extra = 1; }
+        for (; extra > 0; --extra) {
+            if (i < hi && !utf8_is_lead(u8[i])) cp = (cp << 6) | (u8[i++] & 0x3Fu);
+            else { cp = 0xFFFDu; break; }                          // truncated sequence
+        }
+        cps[k++] = cp;
+    }
+}
+
+hipError_t launch_utf8_count(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t* counts, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_utf8_count, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, u8, byte_off, n_str, counts);
+    return hipGetLastError();
+}
+hipError_t launch_utf8_decode(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, const int64_t* cp_off,
+                              uint32_t* cps, hipStream_t st) {
+    if (n_str <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_utf8_decode, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, u8, byte_off, n_str, cp_off, cps);
+    return hipGetLastError();
+}
+
 // ---- synthetic corpus ------------------------------------------------------------------------------------------
 __global__ void k_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str,
                               const int64_t* __restrict__ row_off, uint32_t* __restrict__ cps) {

@@ -729,6 +729,11 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
         const int64_t T0 = seg * S;
         const int64_t T1 = min(T0 + S, P.n_tiles);
         const int n_seg = (int)(T1 - T0);
+        // my tile's summary is requested first: its latency overlaps the scan of the segment aggregates
+        if (tid == 0) misc[0] = 0;
+        const int64_t t = T0 + tid;
+        int4 s = make_int4(0, 0, 0, 0);
+        if (tid < n_seg) s = P.summ[t];
         // (1) aggregates of the other segments: contiguous range per thread, ordered
         Fn64 pf = fn_identity();
         Hd64 sh = hd_identity();
@@ -748,13 +753,9 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
         Hd64 rest; rest.h = sh.h; rest.c = 1;   // what follows the segment: sh.h starts before the next closing
 
         // (2) my tile
-        if (tid == 0) misc[0] = 0;
-        const int64_t t = T0 + tid;
-        int4 s = make_int4(0, 0, 0, 0);
         Fn64 f = fn_identity();
         Hd64 h = hd_identity();
         if (tid < n_seg) {
-            s = P.summ[t];
             f = fn_of(s);
             h.h = s.z; h.c = s.w & 1;
         }

@@ -392,3 +392,30 @@ def test_beyond_4GiB_batch(gpu, oracle):
     finally:
         for p in (d_row, d_cps, d_bits):
             lib.latok_dev_free(p)
+
+
+def test_utf8_ingest(gpu, oracle):
+    """UTF-8 CSR input: device decode == Python's decoder, and offsets / spans equal the UTF-32 path."""
+    from latok_amd import batch
+    rng = random.Random(123)
+    texts = [G1, "", "\u65e5\u672c\u8a9e\u306e\u30c6\u30ad\u30b9\u30c8\u3001\u3067\u3059\u3002 \U0001f913 ok", "\u00e9\u00e0 x",
+             "\U0010ffff max  \u07ff \u0800 \uffff", "a"] + \
+        random_strings(rng, 400, 0, 150, ALPHABETS["mixed"]) + random_strings(rng, 5, 3000, 9000, ALPHABETS["mixed"])
+    blobs = [t.encode("utf-8") for t in texts]
+    u8, boff = batch.pack_utf8(blobs)
+    cps, row = batch.utf8_decode_csr(u8, boff)
+    want_cps, want_row = pack(texts)
+    assert np.array_equal(row, want_row) and np.array_equal(cps, want_cps)
+    c1, o1 = batch.split_offsets_utf8_csr(u8, boff)
+    c2, o2 = batch.split_offsets_csr(want_cps, want_row)
+    assert np.array_equal(c1, c2) and np.array_equal(o1, o2)
+    exp = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
+    assert np.array_equal(o1, np.concatenate(exp))
+    t1, s1 = batch.token_spans_utf8_csr(u8, boff)
+    t2, s2 = batch.token_spans_csr(want_cps, want_row)
+    assert np.array_equal(t1, t2) and np.array_equal(s1, s2)
+    # lone surrogates survive the round trip ("surrogatepass"), empty batch is fine
+    odd = ["\ud800 x \udfff"]
+    cps, row = batch.utf8_decode_csr(*batch.pack_utf8([t.encode("utf-8", "surrogatepass") for t in odd]))
+    assert np.array_equal(cps, pack(odd)[0])
+    assert batch.split_offsets_utf8_csr(np.zeros(0, np.uint8), np.zeros(1, np.int64))[1].size == 0

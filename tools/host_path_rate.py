@@ -20,3 +20,16 @@ t = time.perf_counter()
 counts, offs = batch.split_offsets_csr(cps, row)
 dt = time.perf_counter() - t
 print(f"host-pointer split_offsets_csr: {dt * 1e3:.2f} ms ({offs.size} boundaries)")
+# same batch handed over as UTF-8 (ASCII corpus: 1 byte per char over PCIe instead of 4)
+u8 = cps.astype(np.uint8)
+t = time.perf_counter()
+for _ in range(3):
+    c2, o2 = batch.split_offsets_utf8_csr(u8, row)
+dt8 = (time.perf_counter() - t) / 3
+t = time.perf_counter()
+for _ in range(3):
+    c1, o1 = batch.split_offsets_csr(cps, row)
+dt32 = (time.perf_counter() - t) / 3
+assert np.array_equal(o1, o2)
+print(f"host-pointer offsets: UTF-32 input {dt32 * 1e3:.1f} ms, UTF-8 input {dt8 * 1e3:.1f} ms per 1M-string batch "
+      f"({cps.size / dt32 / 1e9:.2f} vs {cps.size / dt8 / 1e9:.2f} GB/s UTF-8, output copy of {o1.size} int64 offsets included)")

@@ -94,6 +94,10 @@ int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t
 int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                             uint32_t* cps_out, int64_t cps_cap, int64_t* cp_row_off_out, int64_t* total_cps_out, int flags,
                             void* stream);
+/* boundary bitmask over the DECODED code points (bit i = code point i of the packed batch) + the code-point row offsets */
+int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out,
+                                int64_t* total_cps_out, int flags, void* stream);
 int latok_split_offsets_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                    int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
                                    int64_t* n_offsets_out, int flags, void* stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "latok_split_offsets_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_token_spans_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_utf8_decode_batch": (ci, [vp, vp, i64, i64, vp, i64, vp, C.POINTER(i64), ci, vp]),
+    "latok_split_mask_utf8_batch": (ci, [vp, vp, i64, i64, vp, i64, vp, C.POINTER(i64), ci, vp]),
     "latok_split_offsets_utf8_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_token_spans_utf8_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_token_features_batch": (ci, [vp, vp, i64, i64, vp, vp, vp, i64, C.POINTER(i64), ci, vp]),

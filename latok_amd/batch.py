@@ -155,6 +155,20 @@ def utf8_decode_csr(utf8, byte_off):
     return cps[:n.value].copy(), row
 
 
+def split_mask_utf8_csr(utf8, byte_off):
+    """(bits uint64[ceil(total_cps/64)], cp_row_off int64[n+1]): boundary bitmask over the decoded code points."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    bits = np.zeros((total + 63) // 64, np.uint64)
+    row = np.zeros(n_str + 1, np.int64)
+    n = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_mask_utf8_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(bits), bits.size, _ptr(row),
+                                               C.byref(n), 0, None))
+    return bits[:(n.value + 63) // 64], row
+
+
 def split_offsets_utf8_csr(utf8, byte_off):
     """(counts, offsets) like split_offsets_csr, input handed over as UTF-8 (1 byte per ASCII char over PCIe).
     Offsets are code-point indices, as the reference reports them for the decoded str."""

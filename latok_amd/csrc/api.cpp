@@ -77,7 +77,7 @@ struct Ctx {
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scan_tot, tok_sid, scalar, h_aux;
-    DevBuf u_bytes, u_boff, u_cnt, u_row;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
+    DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
 
@@ -236,7 +236,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -293,18 +293,21 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
         d_u8 = (const uint8_t*)g.u_bytes.p;
         d_boff = (const int64_t*)g.u_boff.p;
     }
-    if ((rc = g.u_cnt.ensure((size_t)n_str * 8))) return rc;
+    const int64_t n_blocks = latok::utf8_blocks(total_bytes);
+    if ((rc = g.u_cnt.ensure((size_t)n_blocks * 16 + 16))) return rc;               // block counts | block bases
     if ((rc = g.u_row.ensure((size_t)(n_str + 1) * 8))) return rc;
-    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(n_str) * 8))) return rc;
-    HIP_TRY(latok::launch_utf8_count(d_u8, d_boff, n_str, (int64_t*)g.u_cnt.p, st));
-    // exclusive scan of the counts = code-point row offsets; the grand total lands in row[n_str]
-    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.u_cnt.p, n_str, (int64_t*)g.u_row.p,
-                                         (int64_t*)g.u_row.p + n_str, (int64_t*)g.scan_tot.p, st));
+    if ((rc = g.u_pref.ensure((size_t)(n_blocks * 256) * 2 + 16))) return rc;       // u16 prefix per 16-byte chunk
+    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(n_blocks) * 8))) return rc;
+    int64_t* d_cnt = (int64_t*)g.u_cnt.p;
+    int64_t* d_base = d_cnt + n_blocks;
+    HIP_TRY(latok::launch_utf8_block_counts(d_u8, total_bytes, d_cnt, st));
+    HIP_TRY(latok::launch_exclusive_scan(d_cnt, n_blocks, d_base, (int64_t*)g.scalar.p, (int64_t*)g.scan_tot.p, st));
     int64_t total_cps = 0;
-    HIP_TRY(hipMemcpyAsync(&total_cps, (int64_t*)g.u_row.p + n_str, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&total_cps, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = g.h_cps.ensure((size_t)total_cps * 4 + 16))) return rc;
-    HIP_TRY(latok::launch_utf8_decode(d_u8, d_boff, n_str, (const int64_t*)g.u_row.p, (uint32_t*)g.h_cps.p, st));
+    HIP_TRY(latok::launch_utf8_decode(d_u8, total_bytes, d_boff, n_str, d_base, (uint16_t*)g.u_pref.p, total_cps,
+                                      (uint32_t*)g.h_cps.p, (int64_t*)g.u_row.p, st));
     *total_cps_out = total_cps;
     return LATOK_OK;
 }
@@ -426,6 +429,37 @@ int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_
     if (!cp_row_off_out || (total_cps > 0 && !cps_out)) return fail(LATOK_ERR_INVALID, "NULL output buffer");
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (total_cps > 0) HIP_TRY(hipMemcpyAsync(cps_out, g.h_cps.p, (size_t)total_cps * 4, kind, st));
+    HIP_TRY(hipMemcpyAsync(cp_row_off_out, g.u_row.p, (size_t)(n_str + 1) * 8, kind, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out,
+                                int64_t* total_cps_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    int64_t total = 0;
+    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total))) return rc;
+    *total_cps_out = total;
+    if (n_str == 0) return LATOK_OK;
+    const int64_t words = (total + 63) / 64;
+    if (words > mask_cap_words) return fail(LATOK_ERR_INVALID, "mask_cap_words too small: need %lld", (long long)words);
+    if (!cp_row_off_out || (words > 0 && !mask_bits_out)) return fail(LATOK_ERR_INVALID, "NULL output buffer");
+    uint64_t* d_bits = mask_bits_out;
+    if (!dev) {
+        if ((rc = g.h_out.ensure((size_t)words * 8 + 8))) return rc;
+        d_bits = (uint64_t*)g.h_out.p;
+    }
+    if ((rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.u_row.p, n_str, total, d_bits, nullptr,
+                           latok::kModeBits, st)))
+        return rc;
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!dev && words > 0) HIP_TRY(hipMemcpyAsync(mask_bits_out, d_bits, (size_t)words * 8, kind, st));
     HIP_TRY(hipMemcpyAsync(cp_row_off_out, g.u_row.p, (size_t)(n_str + 1) * 8, kind, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LATOK_OK;

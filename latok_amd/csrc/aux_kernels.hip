@@ -381,46 +381,143 @@ hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, in
 // malformed sequences yield U+FFFD -- input is expected to be valid UTF-8 ("surrogatepass" forms decode as they are).
 __device__ __forceinline__ bool utf8_is_lead(uint8_t b) { return (b & 0xC0u) != 0x80u; }
 
-__global__ void k_utf8_count(const uint8_t* __restrict__ u8, const int64_t* __restrict__ byte_off, int64_t n_str,
-                             int64_t* __restrict__ counts) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_str) return;
-    int64_t n = 0;
-    for (int64_t i = byte_off[s]; i < byte_off[s + 1]; ++i) n += utf8_is_lead(u8[i]);
-    counts[s] = n;
+// Chunk-parallel decode: the byte stream is cut into 16-byte chunks (one per thread, 4 KiB per 256-thread block).
+//   pass 1  k_utf8_block_counts : lead bytes per block                       -> block_cnt[b]
+//   (device-wide exclusive scan of block_cnt -> block_base[b], grand total = number of code points)
+//   pass 2  k_utf8_decode_chunks: per block, exclusive scan of the chunk counts; every lead byte of a chunk is decoded
+//                                 and stored at cps[block_base + chunk prefix + rank]; chunk prefixes are kept (u16)
+//   pass 3  k_utf8_cp_offsets   : code-point offset of every string start from block_base + chunk prefix + the leads
+//                                 of its chunk before it
+// Everything is coalesced; strings never have to be walked byte by byte.
+constexpr int kU8Threads = 256;
+constexpr int kU8Chunk = 16;
+constexpr int kU8Block = kU8Threads * kU8Chunk;   // 4096 bytes
+
+// 16 bytes of the stream starting at byte p (zero beyond `total`), as 4 little-endian dwords
+__device__ __forceinline__ uint4 utf8_load16(const uint8_t* __restrict__ u8, int64_t p, int64_t total) {
+    uint4 v = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);   // padding looks like continuation bytes
+    if (p + 16 <= total && ((uintptr_t)(u8 + p) & 15) == 0) return *reinterpret_cast<const uint4*>(u8 + p);
+    uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+    for (int i = 0; i < 16; ++i)
+        if (p + i < total) w[i >> 2] = (w[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)u8[p + i] << (8 * (i & 3)));
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+}
+// bit i of the result = byte i of the dword is a lead byte ((b & 0xC0) != 0x80)
+__device__ __forceinline__ uint32_t utf8_lead_nibble(uint32_t w) {
+    const uint32_t cont = (w & 0x80808080u) & ~((w << 1) & 0x80808080u);   // top bits "10"
+    const uint32_t lead = (~cont) & 0x80808080u;
+    return (((lead >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+__device__ __forceinline__ uint32_t utf8_lead_mask16(uint4 v) {
+    return utf8_lead_nibble(v.x) | (utf8_lead_nibble(v.y) << 4) | (utf8_lead_nibble(v.z) << 8) | (utf8_lead_nibble(v.w) << 12);
 }
 
-__global__ void k_utf8_decode(const uint8_t* __restrict__ u8, const int64_t* __restrict__ byte_off, int64_t n_str,
-                              const int64_t* __restrict__ cp_off, uint32_t* __restrict__ cps) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_str) return;
-    const int64_t hi = byte_off[s + 1];
-    int64_t k = cp_off[s];
-    for (int64_t i = byte_off[s]; i < hi;) {
-        const uint32_t b0 = u8[i++];
-        if (!utf8_is_lead((uint8_t)b0)) continue;                 // stray continuation byte
+__device__ __forceinline__ int block_exclusive_scan_int(int v, int* total, int* lds /*[kU8Threads/64]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < kU8Threads / 64; ++w) {
+        if (w < wave) before += lds[w];
+        all += lds[w];
+    }
+    *total = all;
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(kU8Threads) void k_utf8_block_counts(const uint8_t* __restrict__ u8, int64_t total,
+                                                                  int64_t* __restrict__ block_cnt) {
+    __shared__ int lds[kU8Threads / 64];
+    const int64_t p = ((int64_t)blockIdx.x * kU8Threads + threadIdx.x) * kU8Chunk;
+    const int c = p < total ? __popc(utf8_lead_mask16(utf8_load16(u8, p, total))) : 0;
+    int tot;
+    (void)block_exclusive_scan_int(c, &tot, lds);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t* __restrict__ u8, int64_t total,
+                                                                   const int64_t* __restrict__ block_base,
+                                                                   uint16_t* __restrict__ chunk_pref,
+                                                                   uint32_t* __restrict__ cps) {
+    __shared__ int lds[kU8Threads / 64];
+    const int64_t chunk = (int64_t)blockIdx.x * kU8Threads + threadIdx.x;
+    const int64_t p = chunk * kU8Chunk;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t leads = 0;
+    if (p < total) {
+        v = utf8_load16(u8, p, total);
+        leads = utf8_lead_mask16(v);
+    }
+    int tot;
+    const int excl = block_exclusive_scan_int(__popc(leads), &tot, lds);
+    if (p >= total) return;
+    chunk_pref[chunk] = (uint16_t)excl;
+    if (!leads) return;
+    // bytes p .. p+18: the chunk plus the 3 bytes a sequence that starts in its last byte may need
+    uint32_t w[5] = {v.x, v.y, v.z, v.w, 0x80808080u};
+    {
+        uint32_t nx = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int64_t q = p + 16 + i;
+            nx |= (uint32_t)(q < total ? u8[q] : 0xFFu) << (8 * i);   // 0xFF = "not a continuation byte"
+        }
+        w[4] = nx | 0xFF000000u;
+    }
+    int64_t k = block_base[blockIdx.x] + excl;
+    for (uint32_t m = leads; m; m &= m - 1) {
+        const int i = __builtin_ctz(m);
+        auto byte_at = [&](int j) -> uint32_t { return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu; };
+        const uint32_t b0 = byte_at(i);
         uint32_t cp = b0;
         int extra = 0;
         if (b0 >= 0xF0u) { cp = b0 & 0x07u; extra = 3; }
         else if (b0 >= 0xE0u) { cp = b0 & 0x0Fu; extra = 2; }
         else if (b0 >= 0xC0u) { cp = b0 & 0x1Fu; extra = 1; }
-        for (; extra > 0; --extra) {
-            if (i < hi && !utf8_is_lead(u8[i])) cp = (cp << 6) | (u8[i++] & 0x3Fu);
-            else { cp = 0xFFFDu; break; }                          // truncated sequence
+        for (int j = 1; j <= extra; ++j) {
+            const uint32_t b = byte_at(i + j);
+            if ((b & 0xC0u) == 0x80u) cp = (cp << 6) | (b & 0x3Fu);
+            else { cp = 0xFFFDu; break; }                              // truncated sequence
         }
         cps[k++] = cp;
     }
 }
 
-hipError_t launch_utf8_count(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t* counts, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_utf8_count, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, u8, byte_off, n_str, counts);
+__global__ void k_utf8_cp_offsets(const uint8_t* __restrict__ u8, int64_t total, const int64_t* __restrict__ byte_off,
+                                  int64_t n_str, const int64_t* __restrict__ block_base,
+                                  const uint16_t* __restrict__ chunk_pref, int64_t total_cps,
+                                  int64_t* __restrict__ cp_off) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_str) return;
+    const int64_t p = byte_off[s];
+    if (p >= total) { cp_off[s] = total_cps; return; }
+    const int64_t chunk = p / kU8Chunk;
+    const uint32_t leads = utf8_lead_mask16(utf8_load16(u8, chunk * kU8Chunk, total));
+    const int within = (int)(p - chunk * kU8Chunk);
+    cp_off[s] = block_base[chunk / kU8Threads] + chunk_pref[chunk] + __popc(leads & ((1u << within) - 1u));
+}
+
+int64_t utf8_blocks(int64_t total_bytes) { return total_bytes > 0 ? (total_bytes + kU8Block - 1) / kU8Block : 1; }
+
+hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st) {
+    hipLaunchKernelGGL(k_utf8_block_counts, dim3((unsigned)utf8_blocks(total)), dim3(kU8Threads), 0, st, u8, total, block_cnt);
     return hipGetLastError();
 }
-hipError_t launch_utf8_decode(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, const int64_t* cp_off,
-                              uint32_t* cps, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_utf8_decode, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, u8, byte_off, n_str, cp_off, cps);
+hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,
+                              const int64_t* block_base, uint16_t* chunk_pref, int64_t total_cps, uint32_t* cps,
+                              int64_t* cp_off, hipStream_t st) {
+    hipLaunchKernelGGL(k_utf8_decode_chunks, dim3((unsigned)utf8_blocks(total)), dim3(kU8Threads), 0, st, u8, total,
+                       block_base, chunk_pref, cps);
+    hipLaunchKernelGGL(k_utf8_cp_offsets, dim3((unsigned)((n_str + 1 + 255) / 256)), dim3(256), 0, st, u8, total, byte_off,
+                       n_str, block_base, chunk_pref, total_cps, cp_off);
     return hipGetLastError();
 }
 

@@ -79,9 +79,11 @@ hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, co
                                  const int64_t* out_base, int64_t* spans4, int64_t n_tok, int64_t* tok_sid,
                                  const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
                                  int8_t* features, hipStream_t st);
-hipError_t launch_utf8_count(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t* counts, hipStream_t st);
-hipError_t launch_utf8_decode(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, const int64_t* cp_off,
-                              uint32_t* cps, hipStream_t st);
+int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
+hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
+hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,
+                              const int64_t* block_base, uint16_t* chunk_pref, int64_t total_cps, uint32_t* cps,
+                              int64_t* cp_off, hipStream_t st);
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
 hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);

@@ -411,6 +411,8 @@ def test_utf8_ingest(gpu, oracle):
     assert np.array_equal(c1, c2) and np.array_equal(o1, o2)
     exp = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
     assert np.array_equal(o1, np.concatenate(exp))
+    mb, mrow = batch.split_mask_utf8_csr(u8, boff)
+    assert np.array_equal(mrow, want_row) and np.array_equal(mb, batch.split_mask_batch(want_cps, want_row))
     t1, s1 = batch.token_spans_utf8_csr(u8, boff)
     t2, s2 = batch.token_spans_csr(want_cps, want_row)
     assert np.array_equal(t1, t2) and np.array_equal(s1, s2)

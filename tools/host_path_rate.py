@@ -33,3 +33,8 @@ dt32 = (time.perf_counter() - t) / 3
 assert np.array_equal(o1, o2)
 print(f"host-pointer offsets: UTF-32 input {dt32 * 1e3:.1f} ms, UTF-8 input {dt8 * 1e3:.1f} ms per 1M-string batch "
       f"({cps.size / dt32 / 1e9:.2f} vs {cps.size / dt8 / 1e9:.2f} GB/s UTF-8, output copy of {o1.size} int64 offsets included)")
+t = time.perf_counter()
+for _ in range(5):
+    mb, mrow = batch.split_mask_utf8_csr(u8, row)
+dtm = (time.perf_counter() - t) / 5
+print(f"host-pointer split_mask from UTF-8: {dtm * 1e3:.2f} ms per batch = {cps.size / dtm / 1e9:.2f} GB/s UTF-8 (PCIe-inclusive)")

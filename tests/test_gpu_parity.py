@@ -421,3 +421,34 @@ def test_utf8_ingest(gpu, oracle):
     cps, row = batch.utf8_decode_csr(*batch.pack_utf8([t.encode("utf-8", "surrogatepass") for t in odd]))
     assert np.array_equal(cps, pack(odd)[0])
     assert batch.split_offsets_utf8_csr(np.zeros(0, np.uint8), np.zeros(1, np.int64))[1].size == 0
+
+
+def test_edge_aligned_patterns(gpu, oracle):
+    """Rule triggers, spaces, string starts / ends and empty strings placed exactly around word (64) and tile (4096)
+    boundaries of the packed buffer, where the cross-lane / cross-tile carries of the kernel live."""
+    rng = random.Random(4096)
+    specials = ["http://x.y/z", " #tag", "a@b.c", " .@user", " ", "  ", "", "X", "aB", "Ab", "a,", ", ", "://", "@", "#a #b",
+                "a@b@c@d e,f g,h", "\t", "x" * 70, "日本", "🤓"]
+    for trial in range(12):
+        texts, pos = [], 0
+        # filler strings whose lengths steer `pos` onto interesting offsets, followed by a special
+        targets = sorted(set([64 * k + d for k in (1, 2, 63, 64, 65, 127, 128) for d in (-3, -2, -1, 0, 1, 2)] +
+                             [4096 * k + d for k in (1, 2, 3) for d in (-66, -65, -64, -2, -1, 0, 1, 2, 63, 64, 65)]))
+        for tgt in targets:
+            gap = tgt - pos
+            if gap < 0:
+                continue
+            n_fill = rng.randint(1, 3)
+            cuts = sorted(rng.randint(0, gap) for _ in range(n_fill - 1))
+            prev = 0
+            for c in cuts + [gap]:
+                texts.append("".join(rng.choice("abc de,F") for _ in range(c - prev)))
+                prev = c
+            pos = tgt
+            sp = rng.choice(specials)
+            if rng.random() < 0.5:
+                texts.append(sp)                      # special as its own string, starting exactly at the target
+            else:
+                texts[-1] = texts[-1] + sp            # or glued to the filler, straddling the target
+            pos += len(sp)
+        _check_batch(oracle, texts)

@@ -76,7 +76,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, space, counts, bases, scan_tot, tok_sid, scalar, h_aux;
+    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, tok_sid, scalar, h_aux;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
@@ -236,7 +236,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -346,22 +346,28 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         d_cps = (const uint32_t*)g.h_cps.p;
         d_row = (const int64_t*)g.h_row.p;
     }
-    const size_t words = (size_t)((total + 63) / 64);
-    if ((rc = g.bits.ensure(words * 8 + 8))) return rc;
-    if (spans && (rc = g.space.ensure(words * 8 + 8))) return rc;
+    // word-parallel compaction (compact_kernels.hip): items per 64-bit word -> device scan -> per-string counts and scatter
+    const int64_t words = (total + 63) / 64;
+    if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = g.kept.ensure((size_t)words * 8 + 8))) return rc;
+    if ((rc = g.wcnt.ensure((size_t)words * 8 + 8))) return rc;
+    if ((rc = g.bases.ensure((size_t)words * 8 + 8))) return rc;
     if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
-    if ((rc = g.bases.ensure((size_t)n_str * 8))) return rc;
+    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(words) * 8))) return rc;
     uint64_t* d_bits = (uint64_t*)g.bits.p;
     uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
+    uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
+    const uint64_t* d_item_mask = spans ? d_kept : d_bits;
+    int64_t* d_rank = (int64_t*)g.bases.p;
     if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
                            nullptr, nullptr, d_space)))
         return rc;
-    int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
-    if (spans) HIP_TRY(latok::launch_count_spans(d_bits, d_space, d_row, n_str, d_counts, st));
-    else HIP_TRY(latok::launch_count_boundaries(d_bits, d_row, n_str, d_counts, st));
-    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(n_str) * 8))) return rc;   // block totals of the scan
-    HIP_TRY(latok::launch_exclusive_scan(d_counts, n_str, (int64_t*)g.bases.p, (int64_t*)g.scalar.p,
+    HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
+    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, (int64_t*)g.scalar.p,
                                          (int64_t*)g.scan_tot.p, st));
+    int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
+    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_row, n_str, total, (const int64_t*)g.scalar.p, d_counts, st));
     int64_t n_items = 0;
     HIP_TRY(hipMemcpyAsync(&n_items, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -381,14 +387,13 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
             d_feat = (int8_t*)g.h_aux.p;
         }
     }
-    if (feats) {
-        if ((rc = g.tok_sid.ensure((size_t)n_items * 8))) return rc;   // token -> string map between the two passes
-        HIP_TRY(latok::launch_write_features(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, n_items,
-                                             (int64_t*)g.tok_sid.p, d_cps, (const uint8_t*)g.t1.p,
-                                             (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p, d_feat, st));
-    }
-    else if (spans) HIP_TRY(latok::launch_write_spans(d_bits, d_space, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
-    else HIP_TRY(latok::launch_write_offsets(d_bits, d_row, n_str, (const int64_t*)g.bases.p, d_items, st));
+    if (feats && (rc = g.tok_sid.ensure((size_t)n_items * 8))) return rc;   // token -> string map between the two passes
+    HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total, d_row,
+                                       n_str, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
+    if (feats)
+        HIP_TRY(latok::launch_token_features(d_items, n_items, (const int64_t*)g.tok_sid.p, d_row, d_cps,
+                                             (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p,
+                                             d_feat, st));
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
         if (feats) HIP_TRY(hipMemcpyAsync(features_out, d_feat, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));

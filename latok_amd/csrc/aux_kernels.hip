@@ -103,81 +103,10 @@ hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t strid
     return hipGetLastError();
 }
 
-// ---- boundary offsets (np.nonzero per string) ---------------------------------------------------------------------
-// counts[s] = popcount of the mask bits in [row_off[s], row_off[s+1]); one thread per string (strings are short in the
-// batch configs; long documents are few).  Offsets are then scattered at the exclusive prefix sum of the counts.
-__device__ __forceinline__ uint64_t mask_word(const uint64_t* bits, int64_t w, int64_t lo, int64_t hi) {
-    // bits of word w restricted to char range [lo, hi)
-    uint64_t x = bits[w];
-    const int64_t base = w << 6;
-    if (lo > base) x &= ~0ull << (lo - base);
-    if (hi < base + 64) x &= (1ull << (hi - base)) - 1ull;
-    return x;
-}
-
-__global__ void k_count_boundaries(const uint64_t* __restrict__ bits, const int64_t* __restrict__ row_off,
-                                   int64_t n_str, int64_t* __restrict__ counts) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_str) return;
-    const int64_t lo = row_off[s], hi = row_off[s + 1];
-    int64_t c = 0;
-    if (hi > lo)
-        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) c += __popcll(mask_word(bits, w, lo, hi));
-    counts[s] = c;
-}
-
-__global__ void k_write_offsets(const uint64_t* __restrict__ bits, const int64_t* __restrict__ row_off, int64_t n_str,
-                                const int64_t* __restrict__ out_base, int64_t* __restrict__ offsets) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_str) return;
-    const int64_t lo = row_off[s], hi = row_off[s + 1];
-    int64_t k = out_base[s];
-    if (hi > lo)
-        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
-            uint64_t x = mask_word(bits, w, lo, hi);
-            while (x) {
-                const int b = __builtin_ctzll(x);
-                x &= x - 1;
-                offsets[k++] = (w << 6) + b - lo;
-            }
-        }
-}
-
-// ---- token spans (reference default_tokenizer.py:149-158: slice between consecutive boundaries, strip, drop empties) ---
-// A token is [a, e) between two consecutive boundaries of its string (the last one ends at the string end); strip()
-// removes SPACE-class chars at both ends (the reference's SPACE set equals Python's str.isspace set).
-// first position in [from, to) whose bit in `bits` is 0, or `to`
-__device__ __forceinline__ int64_t next_zero_bit(const uint64_t* bits, int64_t from, int64_t to) {
-    for (int64_t w = from >> 6; from < to; ++w) {
-        uint64_t x = ~bits[w];
-        const int64_t base = w << 6;
-        if (from > base) x &= ~0ull << (from - base);
-        if (x) {
-            const int64_t p = base + __builtin_ctzll(x);
-            return p < to ? p : to;
-        }
-        from = base + 64;
-    }
-    return to;
-}
-// last position in [from, to) whose bit is 0, plus one; `from` if none
-__device__ __forceinline__ int64_t prev_zero_end(const uint64_t* bits, int64_t from, int64_t to) {
-    for (int64_t w = (to - 1) >> 6; to > from; --w) {
-        uint64_t x = ~bits[w];
-        const int64_t base = w << 6;
-        if (to < base + 64) x &= (1ull << (to - base)) - 1ull;
-        if (x) {
-            const int64_t p = base + 63 - __builtin_clzll(x);
-            return p >= from ? p + 1 : from;
-        }
-        to = base;
-    }
-    return from;
-}
-
-// FEATURES: additionally the reference's per-token feature vector (featurize, default_tokenizer.py:163-191): the
-// sum of the 25 matrix columns over the UNSTRIPPED span between two boundaries (uint8 wrap-around like
-// _combine_matrix_rows' 1-D branch, latok.c:342-354), and spans become {raw_start, raw_end, strip_start, strip_end}.
+// ---- token feature vectors (featurize) --------------------------------------------------------------------------
+// The reference's per-token feature vector (featurize, default_tokenizer.py:163-191): the sum of the 25 matrix columns
+// over the UNSTRIPPED span between two boundaries, in uint8 wrap-around arithmetic like _combine_matrix_rows' 1-D
+// branch (latok.c:342-354).  Spans and owning strings come from compact_kernels.hip (k_word_scatter<2>).
 struct FeatTables {
     const uint32_t* cps;
     const uint8_t* t1;
@@ -186,42 +115,6 @@ struct FeatTables {
     int8_t* features;   // [n_tokens][25]
     int64_t* tok_sid;   // [n_tokens] scratch: string id of every token (pass 1 -> pass 2)
 };
-
-template <bool WRITE, bool FEATURES>
-__global__ void k_token_spans(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
-                              const int64_t* __restrict__ row_off, int64_t n_str, int64_t* __restrict__ counts,
-                              const int64_t* __restrict__ out_base, int64_t* __restrict__ spans, FeatTables F) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_str) return;
-    const int64_t lo = row_off[s], hi = row_off[s + 1];
-    int64_t n = 0, k = WRITE ? out_base[s] : 0;
-    int64_t a = -1;   // start of the open token (the previous boundary)
-    auto emit = [&](int64_t from, int64_t to) {
-        const int64_t a2 = next_zero_bit(space, from, to);
-        if (a2 >= to) return;                         // whitespace only: dropped like the reference's `if token:`
-        const int64_t e2 = prev_zero_end(space, a2, to);
-        if (WRITE && !FEATURES) { spans[2 * k] = a2 - lo; spans[2 * k + 1] = e2 - lo; }
-        if (WRITE && FEATURES) {   // pass 1 of featurize: spans + owning string; the sums are done one thread per token
-            spans[4 * k] = from - lo; spans[4 * k + 1] = to - lo; spans[4 * k + 2] = a2 - lo; spans[4 * k + 3] = e2 - lo;
-            F.tok_sid[k] = s;
-        }
-        ++k;
-        ++n;
-    };
-    if (hi > lo) {
-        for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
-            uint64_t x = mask_word(bits, w, lo, hi);
-            while (x) {
-                const int64_t e = (w << 6) + __builtin_ctzll(x);
-                x &= x - 1;
-                if (a >= 0) emit(a, e);
-                a = e;
-            }
-        }
-        if (a >= 0) emit(a, hi);                      // the last token runs to the end of the string
-    }
-    if (!WRITE) counts[s] = n;
-}
 
 // pass 2 of featurize: one thread per token sums the 25 feature bits of every char of the token's raw span
 __global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_tok, const int64_t* __restrict__ row_off,
@@ -249,28 +142,11 @@ __global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_t
     for (int c = 0; c < 25; ++c) dst[c] = (int8_t)acc[c];
 }
 
-hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                              int64_t* counts, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_token_spans<false, false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
-                       row_off, n_str, counts, nullptr, nullptr, FeatTables{});
-    return hipGetLastError();
-}
-hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                              const int64_t* out_base, int64_t* spans, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL((k_token_spans<true, false>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
-                       row_off, n_str, nullptr, out_base, spans, FeatTables{});
-    return hipGetLastError();
-}
-hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                                 const int64_t* out_base, int64_t* spans4, int64_t n_tok, int64_t* tok_sid,
+hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
                                  const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
                                  int8_t* features, hipStream_t st) {
-    if (n_str <= 0 || n_tok <= 0) return hipSuccess;
-    FeatTables F{cps, t1, t2cls, cw, features, tok_sid};
-    hipLaunchKernelGGL((k_token_spans<true, true>), dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, space,
-                       row_off, n_str, nullptr, out_base, spans4, F);
+    if (n_tok <= 0) return hipSuccess;
+    FeatTables F{cps, t1, t2cls, cw, features, const_cast<int64_t*>(tok_sid)};
     hipLaunchKernelGGL(k_token_features, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, st, spans4, n_tok, row_off, F);
     return hipGetLastError();
 }
@@ -350,13 +226,6 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ o
         if (base + j < n) out[base + j] += add;
 }
 
-hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
-                                   hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_count_boundaries, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, row_off,
-                       n_str, counts);
-    return hipGetLastError();
-}
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
                                  hipStream_t st) {
     const int64_t n_blocks = scan_blocks(n);
@@ -366,13 +235,6 @@ hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int
     return hipGetLastError();
 }
 int64_t scan_blocks(int64_t n) { return n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1; }
-hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
-                                int64_t* offsets, hipStream_t st) {
-    if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, bits, row_off, n_str,
-                       out_base, offsets);
-    return hipGetLastError();
-}
 
 // ---- UTF-8 ingest: decode a CSR batch of UTF-8 strings to packed UTF-32 on the device --------------
 // The reference never sees UTF-8: it reads CPython's PEP-393 buffer (latok.c:53-55,79).  Feeding the GPU path from

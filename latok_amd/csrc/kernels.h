@@ -64,19 +64,18 @@ hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1
                                const uint16_t* cw, int8_t* out, hipStream_t st);
 hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
                                int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
-hipError_t launch_count_boundaries(const uint64_t* bits, const int64_t* row_off, int64_t n_str, int64_t* counts,
-                                   hipStream_t st);
 int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_tot`
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
                                  hipStream_t st);
-hipError_t launch_write_offsets(const uint64_t* bits, const int64_t* row_off, int64_t n_str, const int64_t* out_base,
-                                int64_t* offsets, hipStream_t st);
-hipError_t launch_count_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                              int64_t* counts, hipStream_t st);
-hipError_t launch_write_spans(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                              const int64_t* out_base, int64_t* spans, hipStream_t st);
-hipError_t launch_write_features(const uint64_t* bits, const uint64_t* space, const int64_t* row_off, int64_t n_str,
-                                 const int64_t* out_base, int64_t* spans4, int64_t n_tok, int64_t* tok_sid,
+// compact_kernels.hip: word-parallel compaction (offsets / token spans / featurize spans)
+hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
+                              uint64_t* kept, int64_t* cnt, hipStream_t st);
+hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, const int64_t* row_off, int64_t n_str,
+                                int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
+hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
+                               const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
+                               int64_t n_str, int64_t* out, int64_t* tok_sid, hipStream_t st);
+hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
                                  const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
                                  int8_t* features, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder

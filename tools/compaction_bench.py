@@ -8,6 +8,8 @@ lib = _lib.ensure_init()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 model = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 lo, hi = (64, 192) if model == 0 else (128, 384)
+if len(sys.argv) > 4:
+    lo, hi = int(sys.argv[3]), int(sys.argv[4])
 row = np.zeros(n + 1, np.int64)
 lib.latok_corpus_offsets(0x1A70C0DE + model, 0, n, lo, hi, row.ctypes.data)
 total = int(row[-1])

@@ -144,25 +144,34 @@ struct lk_local {
 // B  = string-start bits of this word; Bn = bits 0..1 = string-start bits of the next two chars after the word.
 // Edge conventions (latok.c:69-73,114-134): at a string start PREV_SPACE=1 and the other PREV_* are 0; at a string
 // end NEXT_SPACE=1 and the other NEXT_* are 0; AFTER_NEXT_* are 0 for the last two chars.
+// single-character decode of a split code (same layout as lk_decode) for the three halo chars: 32-bit, bit 0 only
+struct lk_feat1 {
+    uint32_t S, Y, L, AN, A, AT, SL;
+};
+LATOK_HD lk_feat1 lk_decode1(uint32_t c) {
+    lk_feat1 f;
+    f.S = c & 1u;
+    f.Y = (c >> 1) & 1u;
+    f.L = (c >> 2) & 1u;
+    f.AN = (c >> 4) & 1u;
+    f.A = (c >> 5) & ~(c >> 1) & 1u;
+    f.AT = (c >> 5) & (c >> 6) & 1u;
+    f.SL = (c >> 7) & (c >> 5) & 1u;
+    return f;
+}
+
 LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
-    lk_u64 pc[8], n0[8], n1[8];
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        pc[b] = (h.prev >> b) & 1u;
-        n0[b] = (h.next0 >> b) & 1u;
-        n1[b] = (h.next1 >> b) & 1u;
-    }
-    const lk_feat fp = lk_decode(pc), f0 = lk_decode(n0), f1 = lk_decode(n1);
+    const lk_feat1 fp = lk_decode1(h.prev), f0 = lk_decode1(h.next0), f1 = lk_decode1(h.next1);
 
     const lk_u64 E = (B >> 1) | ((Bn & 1ull) << 63);               // last char of a string
     const lk_u64 E2 = E | (B >> 2) | ((Bn & 3ull) << 62);          // last or second-to-last char
     const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
 
-#define LK_PREV(X) ((((f.X) << 1) | (fp.X & 1ull)) & nB)
-#define LK_NEXT(X) ((((f.X) >> 1) | ((f0.X & 1ull) << 63)) & nE)
-#define LK_ANEXT(X) ((((f.X) >> 2) | ((f0.X & 1ull) << 62) | ((f1.X & 1ull) << 63)) & nE2)
-    const lk_u64 prevS = ((f.S << 1) | (fp.S & 1ull)) | B;
-    const lk_u64 nextS = ((f.S >> 1) | ((f0.S & 1ull) << 63)) | E;
+#define LK_PREV(X) ((((f.X) << 1) | (lk_u64)fp.X) & nB)
+#define LK_NEXT(X) ((((f.X) >> 1) | ((lk_u64)f0.X << 63)) & nE)
+#define LK_ANEXT(X) ((((f.X) >> 2) | ((lk_u64)f0.X << 62) | ((lk_u64)f1.X << 63)) & nE2)
+    const lk_u64 prevS = ((f.S << 1) | (lk_u64)fp.S) | B;
+    const lk_u64 nextS = ((f.S >> 1) | ((lk_u64)f0.S << 63)) | E;
     const lk_u64 prevY = LK_PREV(Y), prevL = LK_PREV(L), prevAN = LK_PREV(AN), prevA = LK_PREV(A);
     const lk_u64 nextL = LK_NEXT(L), nextA = LK_NEXT(A), nextAN = LK_NEXT(AN), nextAT = LK_NEXT(AT),
                  nextSL = LK_NEXT(SL);

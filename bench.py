@@ -192,6 +192,11 @@ def main():
     ms_tiles, n_fix = C.c_float(0), C.c_int64(0)
     _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, args.steps, None, C.byref(ms_tiles),
                                           C.byref(n_fix)))
+    # ---- streaming-read ceiling of this box on the same buffer, also outside the timed region ----------
+    ms_read = C.c_float(0)
+    read_bytes = (total * 4 // 16384) * 16384
+    if rank == 0 and read_bytes > 0:
+        _lib.check(lib.latok_bench_stream_read(d_cps, read_bytes, 3, 20, C.byref(ms_read)))
     for p in (d_row, d_cps, d_bits):
         lib.latok_dev_free(p)
 
@@ -199,6 +204,7 @@ def main():
         alg_read = 4 * total + 8 * (n_str + 1)          # 4 B/code point + 8 B/string row offset
         t_kernel = ms_tiles.value / args.steps / 1e3     # s per launch
         achieved = alg_read / t_kernel / 1e9
+        measured_read = (read_bytes / (ms_read.value / 20 / 1e3) / 1e9) if ms_read.value > 0 else None
         traffic = None
         try:  # HBM bytes per launch from the committed PMC pass of the same workload, if any (else null)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
@@ -222,7 +228,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_read, "kernel_ms": t_kernel * 1e3,
-                         "pipeline_frac": alg_read / (ms_events.value / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS},
+                         "pipeline_frac": alg_read / (ms_events.value / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS,
+                         "measured_stream_read": measured_read,
+                         "frac_of_measured_read": (achieved / measured_read) if measured_read else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             line.update(cpu_baselines(args.workload, min(args.cpu_strings, n_str)))

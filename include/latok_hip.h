@@ -151,6 +151,23 @@ int latok_corpus_fill_device(uint64_t seed, int model, uint64_t sid0, int64_t n_
 /* total UTF-8 encoded size of n code points (device pointers when LATOK_DEVICE_PTRS); result to a host int64 */
 int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int flags);
 
+/* ---- runtime rule tables ------------------------------------------------------------------------------------------
+ * The reference's extension point (latok/core/default_tokenizer.py:9-30,108-110): other C_SPLIT / C_MASK / C_SYM
+ * matrices built with build_combo_matrix (latok/core/latok_utils.py:27-56) over the 25 feature columns
+ * (latok/core/offsets.py:24-49), combined as gen_split_mask does (default_tokenizer.py:113-134):
+ *     splits = combine(C_SPLIT) * block_mask(combine(C_MASK), SPACE) + combine(C_SYM);  splits[0] = 1
+ * with combine = _combine_matrix_rows (latok.c:275-370).  After latok_set_rules every bitmask-based entry point
+ * (latok_split_mask_batch, latok_split_offsets_batch, latok_token_spans_batch, latok_token_features_batch and the
+ * UTF-8 forms) evaluates the caller's tables inside the fused kernel; boundaries are bit-exact with the reference
+ * recipe run on the same tables.  Each table is a row-major int8 [rows x cols] matrix of column ids, -1 padding short
+ * rows; limits: <= 16 rows per table, ids 0..24, a row must not START with -1 (the reference would reuse the previous
+ * row's product there).  rows = 0 gives the all-zero vector.  latok_split_values_batch refuses to run while custom
+ * tables are installed (per-term values exist for the built-in tables only).  Process-wide state, like the device. */
+int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const int8_t* c_mask, int mask_rows,
+                    int mask_cols, const int8_t* c_sym, int sym_rows, int sym_cols);
+int latok_reset_rules(void);   /* back to the built-in default_tokenizer.py tables */
+int latok_rules_active(void);  /* 1 while custom tables are installed */
+
 /* ---- measurement ----------------------------------------------------------------------------------------------- */
 /* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
  * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
@@ -160,6 +177,11 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
                            int64_t* n_fix_tiles_out);
+
+/* Streaming-read ceiling of this GPU: time `iters` launches of a kernel that only reads `bytes` (a multiple of 16 KiB
+ * is used; device pointer, 16-byte aligned) with the tile kernel's load pattern.  ms_out = elapsed ms of the `iters`
+ * launches after `warmup` untimed ones.  Measurement aid for SURVEY.md 8(d) ("vs. a measured streaming-read kernel"). */
+int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,10 @@ SIGNATURES = {
     "latok_utf8_bytes": (ci, [vp, i64, C.POINTER(i64), ci]),
     "latok_bench_split_mask": (ci, [vp, vp, i64, i64, vp, ci, ci, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(i64)]),
+    "latok_set_rules": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci]),
+    "latok_reset_rules": (ci, []),
+    "latok_rules_active": (ci, []),
+    "latok_bench_stream_read": (ci, [vp, i64, ci, ci, C.POINTER(C.c_float)]),
 }
 
 

@@ -228,3 +228,41 @@ def tokenize_batch(texts):
         out.append([text[a:b] for a, b in spans[k:k + n].tolist()])
         k += n
     return out
+
+
+# ---- runtime rule tables (the reference's extension point, default_tokenizer.py:9-30,108-110) ------------------------
+def _rule_table(name, idx):
+    """A combo matrix as build_combo_matrix returns it -> C-contiguous int8 [rows, cols].  A 1-D index vector means
+    "sum of those feature rows" to _combine_matrix_rows (latok.c:340-353): one single-column row per entry."""
+    a = np.asarray(idx)
+    if a.size and not np.issubdtype(a.dtype, np.integer):
+        raise ValueError(f"{name}: feature ids must be integers")
+    a = a.astype(np.int8)
+    if a.ndim == 1:
+        a = a[a != -1].reshape(-1, 1)
+    if a.ndim != 2:
+        raise ValueError(f"{name}: must be a 1-D or 2-D index matrix")
+    if a.shape[0] and a.shape[1] == 0:
+        raise ValueError(f"{name}: rows have no columns")
+    return np.ascontiguousarray(a)
+
+
+def set_rules(c_split, c_mask, c_sym):
+    """Install custom C_SPLIT / C_MASK / C_SYM combo matrices: every batch entry point (and ``tokenize`` / ``featurize``
+    of latok_amd.core.default_tokenizer) then evaluates them inside the fused kernel, bit-exact with the reference's
+    ``gen_split_mask`` recipe (default_tokenizer.py:113-134) run on the same tables.  ``reset_rules()`` restores the
+    built-in tables."""
+    lib = _lib.ensure_init()
+    t = [_rule_table(n, m) for n, m in (("C_SPLIT", c_split), ("C_MASK", c_mask), ("C_SYM", c_sym))]
+    args = []
+    for a in t:
+        args += [_ptr(a) if a.size else None, a.shape[0], a.shape[1] if a.shape[0] else 0]
+    _lib.check(lib.latok_set_rules(*args))
+
+
+def reset_rules():
+    _lib.check(_lib.ensure_init().latok_reset_rules())
+
+
+def rules_active() -> bool:
+    return bool(_lib.ensure_init().latok_rules_active())

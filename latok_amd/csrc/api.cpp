@@ -72,7 +72,10 @@ struct Ctx {
     int device = -1, n_cu = 0;
     hipStream_t stream = nullptr;
     // tables
-    DevBuf t1, t2code, t2cls, cw;
+    DevBuf t1, t1rule, t2code, t2cls, cw;
+    // runtime rule tables (latok_set_rules); off = the built-in default_tokenizer.py tables
+    bool rules_on = false;
+    lk_rule_tables rules;
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
@@ -101,6 +104,11 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
+    if (g.rules_on) {
+        if (mode == latok::kModeValues)
+            return fail(LATOK_ERR_INVALID, "split VALUES are defined for the built-in rule tables only; call latok_reset_rules()");
+        if (mode == latok::kModeBits) mode = latok::kModeRules;
+    }
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     int rc = ensure_workspace(n_tiles);
     if (rc) return rc;
@@ -111,8 +119,11 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.total = total;
     P.n_tiles = n_tiles;
     latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
-    P.t1 = (const uint8_t*)g.t1.p;
-    P.t2 = (const uint8_t*)g.t1.p + latok::kStage1Pad;
+    const uint8_t* tables = (const uint8_t*)(mode == latok::kModeRules ? g.t1rule.p : g.t1.p);
+    P.t1 = tables;
+    P.t2 = tables + latok::kStage1Pad;
+    if (mode == latok::kModeRules) P.rules = g.rules;
+    else memset(&P.rules, 0, sizeof(P.rules));
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
@@ -219,7 +230,12 @@ int latok_init(int device) {
     std::vector<uint8_t> t2code(latok::kStage2Len);
     for (int i = 0; i < latok::kStage2Len; ++i) t2code[i] = kClassCode[kStage2[i]];
     int rc;
+    std::vector<uint8_t> t2rule(latok::kStage2Len);
+    for (int i = 0; i < latok::kStage2Len; ++i) t2rule[i] = kClassRuleCode[kStage2[i]];
     if ((rc = g.t1.ensure(t1.size() + t2code.size()))) return rc;   // [stage1 | stage2 codes], contiguous like in LDS
+    if ((rc = g.t1rule.ensure(t1.size() + t2rule.size()))) return rc;   // same with rule codes (runtime rule tables)
+    HIP_TRY(hipMemcpy(g.t1rule.p, t1.data(), t1.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char*)g.t1rule.p + t1.size(), t2rule.data(), t2rule.size(), hipMemcpyHostToDevice));
     if ((rc = g.t2cls.ensure(sizeof(kStage2)))) return rc;
     if ((rc = g.cw.ensure(sizeof(kClassWord)))) return rc;
     if ((rc = g.scalar.ensure(64))) return rc;
@@ -236,7 +252,8 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
-    for (DevBuf* b : {&g.t1, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
+    g.rules_on = false;
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -257,6 +274,56 @@ int latok_reserve(int64_t max_chars, int64_t max_strings) {
     if (max_chars < 0 || max_strings < 0) return fail(LATOK_ERR_INVALID, "negative size");
     return ensure_workspace((max_chars + latok::kTile - 1) / latok::kTile);
 }
+
+// one rule table: row-major int8 [rows x cols] as build_combo_matrix returns it -> per-row column sets
+static int pack_rule_table(const char* name, const int8_t* idx, int rows, int cols, uint32_t* row_sets) {
+    if (rows < 0 || rows > LK_MAX_RULE_ROWS)
+        return fail(LATOK_ERR_INVALID, "%s: %d rows (0..%d supported)", name, rows, LK_MAX_RULE_ROWS);
+    if (rows > 0 && (!idx || cols < 1)) return fail(LATOK_ERR_INVALID, "%s: NULL table or no columns", name);
+    for (int r = 0; r < rows; ++r) {
+        uint32_t set = 0;
+        for (int c = 0; c < cols; ++c) {
+            const int v = idx[r * cols + c];
+            if (v == -1) {
+                // the reference seeds a row's product from its FIRST entry (latok.c:329-338); a row that starts with
+                // the -1 pad would multiply into the previous row's product there -- refuse instead of guessing
+                if (c == 0) return fail(LATOK_ERR_INVALID, "%s: row %d starts with -1", name, r);
+                continue;
+            }
+            if (v < 0 || v >= LK_N_FEATURES)
+                return fail(LATOK_ERR_INVALID, "%s: feature id %d in row %d is outside 0..%d", name, v, r, LK_N_FEATURES - 1);
+            set |= 1u << v;
+        }
+        row_sets[r] = set;
+    }
+    return LATOK_OK;
+}
+
+int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const int8_t* c_mask, int mask_rows,
+                    int mask_cols, const int8_t* c_sym, int sym_rows, int sym_cols) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    lk_rule_tables R;
+    memset(&R, 0, sizeof(R));
+    if ((rc = pack_rule_table("C_SPLIT", c_split, split_rows, split_cols, R.row[0]))) return rc;
+    if ((rc = pack_rule_table("C_MASK", c_mask, mask_rows, mask_cols, R.row[1]))) return rc;
+    if ((rc = pack_rule_table("C_SYM", c_sym, sym_rows, sym_cols, R.row[2]))) return rc;
+    R.n_rows[0] = split_rows;
+    R.n_rows[1] = mask_rows;
+    R.n_rows[2] = sym_rows;
+    g.rules = R;
+    g.rules_on = true;
+    return LATOK_OK;
+}
+
+int latok_reset_rules(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.rules_on = false;
+    return LATOK_OK;
+}
+
+int latok_rules_active(void) { return g.rules_on ? 1 : 0; }
 
 int latok_split_mask_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_bits_out, int flags, void* stream) {
@@ -690,6 +757,24 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
     HIP_TRY(hipMemcpyAsync(&t, g.scalar.p, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     *bytes_out = (int64_t)t;
+    return LATOK_OK;
+}
+
+int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    if (!buf_dev || !ms_out || bytes < 16384 || iters <= 0 || warmup < 0)
+        return fail(LATOK_ERR_INVALID, "stream_read: need a device buffer of >= 16 KiB, iters > 0");
+    if (((uintptr_t)buf_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device pointer must be 16-byte aligned");
+    hipStream_t st = g.stream;
+    uint32_t* sink = (uint32_t*)g.scalar.p + 8;
+    for (int i = 0; i < warmup; ++i) HIP_TRY(latok::launch_stream_read(buf_dev, bytes, sink, g.n_cu, st));
+    HIP_TRY(hipEventRecord(g.ev[0], st));
+    for (int i = 0; i < iters; ++i) HIP_TRY(latok::launch_stream_read(buf_dev, bytes, sink, g.n_cu, st));
+    HIP_TRY(hipEventRecord(g.ev[1], st));
+    HIP_TRY(hipEventSynchronize(g.ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms_out, g.ev[0], g.ev[1]));
     return LATOK_OK;
 }
 

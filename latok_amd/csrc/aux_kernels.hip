@@ -400,6 +400,35 @@ hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n
     return hipGetLastError();
 }
 
+// ---- streaming-read ceiling (measurement only) -------------------------------------------------------------------
+// The tile kernel's own load pattern (16 non-temporal 16-byte loads per lane and step, one wave per 16 KiB) with
+// nothing else attached: what a pure HBM read of the same buffer costs on this box.  bench.py reports it beside the
+// 8 TB/s spec figure.
+typedef uint32_t stream_u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(512) k_stream_read(const stream_u32x4* __restrict__ src, int64_t n_steps,
+                                                     uint32_t* __restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    for (int64_t t = wave; t < n_steps; t += n_waves) {
+        const stream_u32x4* p = src + t * 1024 + lane;
+        stream_u32x4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(p + 64 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;   // keeps the loads alive; practically never taken
+}
+
+hipError_t launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int n_cu, hipStream_t st) {
+    const int64_t n_steps = bytes / 16384;
+    if (n_steps <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_stream_read, dim3((unsigned)(n_cu * 2)), dim3(512), 0, st, (const stream_u32x4*)src, n_steps, sink);
+    return hipGetLastError();
+}
+
 __global__ void k_utf8_bytes(const uint32_t* __restrict__ cps, int64_t n, unsigned long long* __restrict__ total) {
     long long local = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "split_code.h"
+
 namespace latok {
 
 // ---- geometry ------------------------------------------------------------------------------------------------
@@ -19,6 +21,8 @@ constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo 
 constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;
 constexpr int kModeBlockMask = 2;        // compat _gen_block_mask: planes from caller byte arrays, byte mask out
+constexpr int kModeRules = 3;            // kModeBits with caller-supplied C_SPLIT / C_MASK / C_SYM (SplitParams::rules)
+constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules; }
 
 constexpr long long kNegInf64 = -(1ll << 60);
 constexpr int kWPB = 12;                 // waves per workgroup: 768 threads -> 168 VGPRs per lane, one workgroup per CU
@@ -51,6 +55,8 @@ struct SplitParams {
     const int8_t* bm_a1;        // "starts" bytes [total]
     const int8_t* bm_a2;        // "spaces" bytes [total]
     const int* bm_flags;        // {any(a1), any(a2)}
+    // kModeRules only (t2 then points at the rule-code table)
+    lk_rule_tables rules;
 };
 
 
@@ -85,6 +91,7 @@ hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* b
                               int64_t* cp_off, hipStream_t st);
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
+hipError_t launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int n_cu, hipStream_t st);
 hipError_t launch_utf8_bytes(const uint32_t* cps, int64_t n, unsigned long long* total, hipStream_t st);
 
 }  // namespace latok

@@ -197,6 +197,112 @@ LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Runtime rule tables: the reference's extension point (default_tokenizer.py:9-30) lets a user build other
+// C_SPLIT / C_MASK / C_SYM matrices with build_combo_matrix (latok_utils.py:27-56) over the 25 feature columns.
+// _combine_matrix_rows (latok.c:318-354) is "sum over rows of the product over the row's columns"; on a 0/1 feature
+// matrix with fewer than 256 rows, "!= 0" of that sum is the OR over rows of the AND over the row's columns, which is
+// what is evaluated here on whole 64-char planes.  A row is stored as the SET of its columns (bit k = column k of
+// offsets.py:24-49); -1 padding simply is not in the set.
+// ---------------------------------------------------------------------------------------------------------------
+// (struct lk_rule_tables lives in split_code.h)
+
+// the 25 planes of one word, selectable by a (wave-uniform) column id
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t lk_v32x32 __attribute__((ext_vector_type(32)));
+struct lk_planes {
+    lk_v32x32 lo, hi;   // kept as two register vectors so that a uniform dynamic index becomes an indexed register move
+};
+#define LK_PLANE_SET(P, k, v) do { const lk_u64 v_ = (v); (P).lo[k] = (uint32_t)v_; (P).hi[k] = (uint32_t)(v_ >> 32); } while (0)
+#define LK_PLANE_GET(P, k) ((lk_u64)(P).lo[k] | ((lk_u64)(P).hi[k] << 32))
+#else
+struct lk_planes {
+    lk_u64 v[32];
+};
+#define LK_PLANE_SET(P, k, val) ((P).v[k] = (val))
+#define LK_PLANE_GET(P, k) ((P).v[k])
+#endif
+
+// 12-bit base feature word (bit i = reference column i, offsets.py:24-35) of ONE rule code (gen_unicode_tables.py:
+// rule_code): bit0 S, bit1 Y, bit2 L, bit3 U, bit4 AN; Y=0: bit5 A, bit6 N; Y=1: bits 5..7 = symbol sub-type
+LATOK_HD uint32_t lk_base_word1(uint32_t c) {
+    const uint32_t y = (c >> 1) & 1u, b5 = (c >> 5) & 1u, b6 = (c >> 6) & 1u, b7 = (c >> 7) & 1u;
+    return (b5 & ~y & 1u) | (((c >> 4) & 1u) << 1) | ((b6 & ~y & 1u) << 2) | (((c >> 2) & 1u) << 3) |
+           (((c >> 3) & 1u) << 4) | ((c & 1u) << 5) | (y << 6) | ((b5 & y & ~b7 & 1u) << 7) | ((b5 & b6 & y) << 8) |
+           ((b7 & ~b6 & ~b5 & 1u) << 9) | ((b7 & b5) << 10) | ((b7 & b6) << 11);
+}
+
+// all 25 columns of _gen_parse_matrix (latok.c:87-134) for one word, from the bit-sliced rule codes
+LATOK_HD void lk_feature_planes(const lk_u64 p[8], lk_halo h, lk_u64 B, lk_u64 Bn, lk_planes& F) {
+    const lk_u64 Y = p[LK_BIT_SYMBOL], nY = ~Y;
+    lk_u64 b[12];
+    b[0] = p[5] & nY;                 // ALPHA
+    b[1] = p[LK_BIT_ALNUM];           // ALPHA_NUM
+    b[2] = p[6] & nY;                 // NUM
+    b[3] = p[LK_BIT_LOWER];
+    b[4] = p[LK_BIT_UPPER];
+    b[5] = p[LK_BIT_SPACE];
+    b[6] = Y;                         // SYMBOL
+    b[7] = p[5] & Y & ~p[7];          // TWITTER
+    b[8] = p[5] & p[6] & Y;           // CHAR_AT
+    b[9] = p[7] & ~p[6] & ~p[5];      // CHAR_COLON
+    b[10] = p[7] & p[5];              // CHAR_SLASH
+    b[11] = p[7] & p[6];              // CHAR_PERIOD
+    const uint32_t wp = lk_base_word1(h.prev), w0 = lk_base_word1(h.next0), w1 = lk_base_word1(h.next1);
+    const lk_u64 E = (B >> 1) | ((Bn & 1ull) << 63);
+    const lk_u64 E2 = E | (B >> 2) | ((Bn & 3ull) << 62);
+    const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
+#define LK_GPREV(i) ((((b[i]) << 1) | (lk_u64)((wp >> (i)) & 1u)) & nB)
+#define LK_GNEXT(i) ((((b[i]) >> 1) | ((lk_u64)((w0 >> (i)) & 1u) << 63)) & nE)
+#define LK_GANEXT(i) ((((b[i]) >> 2) | ((lk_u64)((w0 >> (i)) & 1u) << 62) | ((lk_u64)((w1 >> (i)) & 1u) << 63)) & nE2)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) LK_PLANE_SET(F, i, b[i]);
+    LK_PLANE_SET(F, 12, LK_GPREV(0));          // PREV_ALPHA
+    LK_PLANE_SET(F, 13, LK_GNEXT(0));          // NEXT_ALPHA
+    LK_PLANE_SET(F, 14, LK_GPREV(1));          // PREV_ALPHA_NUM
+    LK_PLANE_SET(F, 15, LK_GNEXT(1));          // NEXT_ALPHA_NUM
+    LK_PLANE_SET(F, 16, LK_GPREV(3));          // PREV_LOWER
+    LK_PLANE_SET(F, 17, LK_GNEXT(3));          // NEXT_LOWER
+    LK_PLANE_SET(F, 18, LK_GPREV(5) | B);      // PREV_SPACE: 1 at a string start (latok.c:116)
+    LK_PLANE_SET(F, 19, LK_GNEXT(5) | E);      // NEXT_SPACE: 1 at a string end (latok.c:122-130)
+    LK_PLANE_SET(F, 20, LK_GPREV(6));          // PREV_SYMBOL
+    LK_PLANE_SET(F, 21, LK_GNEXT(8));          // NEXT_AT
+    LK_PLANE_SET(F, 22, LK_GNEXT(10));         // NEXT_SLASH
+    LK_PLANE_SET(F, 23, LK_GANEXT(0));         // AFTER_NEXT_ALPHA
+    LK_PLANE_SET(F, 24, LK_GANEXT(10));        // AFTER_NEXT_SLASH
+#undef LK_GPREV
+#undef LK_GNEXT
+#undef LK_GANEXT
+}
+
+// "_combine_matrix_rows(m.T, table) != 0" on one word
+LATOK_HD lk_u64 lk_combine_rows(const lk_planes& F, const uint32_t* rows, int n_rows) {
+    lk_u64 acc = 0;
+    for (int r = 0; r < n_rows; ++r) {
+        uint32_t m = rows[r];
+        lk_u64 x = ~0ull;
+        while (m) {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            x &= LK_PLANE_GET(F, k);
+        }
+        acc |= x;
+    }
+    return acc;
+}
+
+LATOK_HD lk_local lk_rules_generic(const lk_u64 p[8], lk_halo h, lk_u64 B, lk_u64 Bn, const lk_rule_tables& R) {
+    lk_planes F;
+    lk_feature_planes(p, h, B, Bn, F);
+    lk_local r;
+    r.S = p[LK_BIT_SPACE];
+    r.raw = lk_combine_rows(F, R.row[0], R.n_rows[0]);
+    r.start = lk_combine_rows(F, R.row[1], R.n_rows[1]);
+    r.sym = lk_combine_rows(F, R.row[2], R.n_rows[2]);
+    r.t_space = r.t_sym = r.t_prevsym = r.t_camel_next = r.t_camel_prev = 0;   // per-term values exist for the default tables only
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Block mask, forward half: which block-closing events zero their block.
 //
 // Events inside a word, in position order; at one position: (1) B: the previous string ends (a virtual space that
@@ -258,7 +364,8 @@ LATOK_HD lk_fwd lk_forward(lk_u64 St, lk_u64 S, lk_u64 B) {
             }
             if (St & bit) ++q;
             if (S & bit) {
-                if (q > 0) { zs |= bit; --q; } else if (!seenB) idle |= bit;
+                // (a space that is also a string's first char closes an EMPTY block: it consumes, nothing to clear)
+                if (q > 0) { if (!(B & bit)) zs |= bit; --q; } else if (!seenB) idle |= bit;
             }
         }
         r.zs = zs; r.zb = zb; r.idle = idle; r.q0 = q;

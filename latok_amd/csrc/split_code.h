@@ -13,11 +13,23 @@
 // tools/gen_unicode_tables.py emits kClassCode[] with exactly this layout; lane_math.h:lk_decode() undoes it.
 #ifndef LATOK_SPLIT_CODE_H
 #define LATOK_SPLIT_CODE_H
+#include <stdint.h>
 
 #define LK_BIT_SPACE 0
 #define LK_BIT_SYMBOL 1
 #define LK_BIT_LOWER 2
 #define LK_BIT_UPPER 3
 #define LK_BIT_ALNUM 4
+
+// Rule code (runtime rule tables): the split code with NUM added in bit 6 for non-symbols, so that all 12 base
+// features can be decoded from the byte (tools/gen_unicode_tables.py:rule_code, lane_math.h:lk_feature_planes).
+// Runtime rule tables: each row of C_SPLIT / C_MASK / C_SYM is the SET of feature columns it multiplies
+// (bit k = column k of reference latok/core/offsets.py:24-49).
+#define LK_N_FEATURES 25
+#define LK_MAX_RULE_ROWS 16
+struct lk_rule_tables {
+    uint32_t row[3][LK_MAX_RULE_ROWS];   // [0] C_SPLIT, [1] C_MASK, [2] C_SYM
+    int32_t n_rows[3];
+};
 
 #endif

@@ -261,8 +261,12 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
         lk_bitslice64(d, plane);
-        const lk_feat f = lk_decode(plane);
-        loc = lk_rules(f, h, B, Bn);
+        if (MODE == kModeRules) {
+            loc = lk_rules_generic(plane, h, B, Bn, P.rules);
+        } else {
+            const lk_feat f = lk_decode(plane);
+            loc = lk_rules(f, h, B, Bn);
+        }
     }
     LATOK_STAMP(4);
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
@@ -333,7 +337,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         const int64_t remain = total - base;
         const lk_u64 valid = remain >= 64 ? ~0ull : ((1ull << remain) - 1ull);
         const lk_u64 keep = ~cleared;
-        if (MODE == kModeBits) {
+        if (mode_writes_bits(MODE)) {
             out_word = ((loc.raw & keep) | loc.sym | B) & valid;
             if (!DEFER) P.bits_out[base >> 6] = out_word;
             if (P.space_out) P.space_out[base >> 6] = loc.S & valid;   // token-span mode only
@@ -637,7 +641,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     // (b) the tiles
     // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
     // One 512-byte store per 16 KiB tile, interleaved with the read stream, costs ~5 % of HBM throughput.
-    constexpr bool kDefer = MODE == kModeBits;
+    constexpr bool kDefer = mode_writes_bits(MODE);
     lk_u64 obuf[8];
     int slot = 0, k_first = wave;   // buffered tiles are k_first, k_first + kWPB, ...
     const int64_t n_words = (P.total + 63) >> 6;
@@ -851,6 +855,7 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
     if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
+    else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
@@ -859,6 +864,7 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
     if (mode == kModeBits) hipLaunchKernelGGL((k_resolve_fix<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues>), grid, block, 0, st, P);
+    else if (mode == kModeRules) hipLaunchKernelGGL((k_resolve_fix<kModeRules>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }

@@ -29,11 +29,12 @@ struct TileSummary {
     int c_rel, p_rel, head_sym, tail_keep, tail_sym;
 };
 
-inline uint32_t classify(uint32_t cp) {
+inline uint32_t classify(uint32_t cp, bool rule_codes = false) {
     uint32_t hi = cp >> LATOK_TBL_SHIFT;
     if (hi > LATOK_TBL_STAGE1_LEN - 1) hi = LATOK_TBL_STAGE1_LEN - 1;
     uint32_t blk = kStage1[hi];
-    return kClassCode[kStage2[(blk << LATOK_TBL_SHIFT) | (cp & ((1u << LATOK_TBL_SHIFT) - 1))]];
+    const unsigned cls = kStage2[(blk << LATOK_TBL_SHIFT) | (cp & ((1u << LATOK_TBL_SHIFT) - 1))];
+    return rule_codes ? kClassRuleCode[cls] : kClassCode[cls];
 }
 
 struct Model {
@@ -47,6 +48,7 @@ struct Model {
     const int8_t* bm_a1 = nullptr;   // block-mask mode (compat _gen_block_mask): planes from byte arrays
     const int8_t* bm_a2 = nullptr;
     int8_t* bm_out = nullptr;
+    const lk_rule_tables* rules = nullptr;   // runtime rule tables (kModeRules of the HIP kernel)
     int64_t n_fix = 0, n_patch = 0;
 
     void clear_range(int64_t lo, int64_t hi, int64_t limit, int keep_first, int keep_last) {
@@ -64,7 +66,7 @@ struct Model {
         }
     }
 
-    uint32_t code_at(int64_t p) const { return (cps && p >= 0 && p < total) ? classify(cps[p]) : 0u; }
+    uint32_t code_at(int64_t p) const { return (cps && p >= 0 && p < total) ? classify(cps[p], rules != nullptr) : 0u; }
 
     // stage 0: tile_first[t] = first string index s with row_off[s] >= t*kTile
     void build_tile_index() {
@@ -100,7 +102,6 @@ struct Model {
             }
             lk_u64 plane[8];
             lk_bitslice64(d, plane);
-            lk_feat f = lk_decode(plane);
             lk_halo h;
             h.prev = code_at(base - 1);
             h.next0 = code_at(base + 64);
@@ -114,8 +115,11 @@ struct Model {
                 }
                 loc[j] = lk_local();
                 loc[j].start = st; loc[j].S = sp; loc[j].raw = ~0ull; loc[j].sym = 0;
-            } else
-            loc[j] = lk_rules(f, h, Bw[j], Bw[j + 1] & 3ull);
+            } else if (rules) {
+                loc[j] = lk_rules_generic(plane, h, Bw[j], Bw[j + 1] & 3ull, *rules);
+            } else {
+                loc[j] = lk_rules(lk_decode(plane), h, Bw[j], Bw[j + 1] & 3ull);
+            }
             fw[j] = lk_forward(loc[j].start, loc[j].S, Bw[j]);
         }
         // "wave" exclusive scan of the q transfer functions
@@ -212,7 +216,7 @@ struct Model {
             const int tz0 = summ[(size_t)t].b > 0;
             if (q_in[(size_t)t] != 0 || tz[(size_t)t] != tz0) {
                 const TileSummary& sm = summ[(size_t)t];
-                if (bits && !values && !bm_out && sm.has_closing && q_in[(size_t)t] <= 1 &&
+                if (bits && !values && !bm_out && !rules && sm.has_closing && q_in[(size_t)t] <= 1 &&
                     (q_in[(size_t)t] == 0 || sm.head_starts == 0)) {
                     // patch in place (mirrors k_scan_resolve)
                     const int64_t t0 = t * kTile, t_end = std::min<int64_t>(t0 + kTile, total);
@@ -247,6 +251,31 @@ extern "C" int fused_split_batch(const uint32_t* cps, const int64_t* row_off, in
 }
 
 // compat _gen_block_mask through the same pipeline (mirrors kModeBlockMask of the HIP kernel)
+// runtime rule tables: rows[3][LK_MAX_RULE_ROWS] column sets, n_rows[3] (same packing as the C ABI keeps internally)
+extern "C" int fused_split_batch_rules(const uint32_t* cps, const int64_t* row_off, int64_t n_str, const uint32_t* rows,
+                                       const int32_t* n_rows, uint64_t* bits_out, int64_t* n_fix_out) {
+    if (n_str < 0) return -1;
+    lk_rule_tables R;
+    memset(&R, 0, sizeof(R));
+    for (int t = 0; t < 3; ++t) {
+        if (n_rows[t] < 0 || n_rows[t] > LK_MAX_RULE_ROWS) return -1;
+        R.n_rows[t] = n_rows[t];
+        for (int r = 0; r < n_rows[t]; ++r) R.row[t][r] = rows[t * LK_MAX_RULE_ROWS + r];
+    }
+    Model m;
+    m.cps = cps;
+    m.row_off = row_off;
+    m.n_str = n_str;
+    m.total = n_str > 0 ? row_off[n_str] : 0;
+    m.n_tiles = (m.total + kTile - 1) / kTile;
+    m.values = nullptr;
+    m.bits = bits_out;
+    m.rules = &R;
+    m.run();
+    if (n_fix_out) *n_fix_out = m.n_fix + m.n_patch;
+    return 0;
+}
+
 extern "C" int fused_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out) {
     if (n <= 0) return 0;
     const int64_t row[2] = {0, n};

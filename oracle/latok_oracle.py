@@ -110,6 +110,20 @@ def gen_split_mask(m: np.ndarray) -> np.ndarray:
     return out
 
 
+def split_values_rules(text, c_split, c_mask, c_sym) -> np.ndarray:
+    """gen_split_mask (default_tokenizer.py:113-134) with caller-supplied combo matrices, composed from the restated
+    C functions exactly as the reference composes its own."""
+    m = gen_parse_matrix(text)
+    if m.shape[0] == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    mt = m.T
+    splits = combine_matrix_rows(mt, np.asarray(c_split, np.int8)) * gen_block_mask(
+        combine_matrix_rows(mt, np.asarray(c_mask, np.int8)), mt[5])
+    splits += combine_matrix_rows(mt, np.asarray(c_sym, np.int8))
+    splits[0] = 1
+    return splits
+
+
 def split_values(text) -> np.ndarray:
     cps = to_cps(text)
     if len(cps) == 0:
@@ -178,11 +192,12 @@ class RefGlue:
     def gen_parse_matrix(self, text: str):
         return self.ext._gen_parse_matrix(text)
 
-    def gen_split_mask(self, m):
+    def gen_split_mask(self, m, tables=None):
+        c_split, c_mask, c_sym = tables if tables is not None else (self.C_SPLIT, self.C_MASK, self.C_SYM)
         mt = m.T
-        splits = (self.ext._combine_matrix_rows(mt, self.C_SPLIT) *
-                  self.ext._gen_block_mask(self.ext._combine_matrix_rows(mt, self.C_MASK), mt[self.SPACE_IDX]))
-        splits += self.ext._combine_matrix_rows(mt, self.C_SYM)
+        splits = (self.ext._combine_matrix_rows(mt, c_split) *
+                  self.ext._gen_block_mask(self.ext._combine_matrix_rows(mt, c_mask), mt[self.SPACE_IDX]))
+        splits += self.ext._combine_matrix_rows(mt, c_sym)
         splits[0] = 1
         return splits
 

@@ -69,3 +69,68 @@ def pack(texts):
 
 def bits_to_bool(bits: np.ndarray, total: int) -> np.ndarray:
     return np.unpackbits(bits.view(np.uint8), bitorder="little")[:total].astype(bool)
+
+
+# ---- runtime rule tables (reference extension point: default_tokenizer.py:9-30) ---------------------------------------
+DEFAULT_RULES = (
+    np.array([[5, -1], [6, -1], [20, -1], [4, 17], [4, 16]], np.int8),                               # C_SPLIT :49-55
+    np.array([[7, 18, 13, -1], [11, 18, 21, 23], [8, 14, 15, -1], [9, 22, 24, 12]], np.int8),     # C_MASK  :80-91
+    np.array([[6, 19]], np.int8),                                                                   # C_SYM   :100-102
+)
+
+# hand-written variations that break assumptions the built-in tables happen to satisfy
+RULE_SETS = {
+    "default": DEFAULT_RULES,
+    # every symbol keeps its own boundary even inside a masked block; digits split; starts may sit ON a space
+    "sym_everywhere": (np.array([[5, -1], [2, -1], [4, 17]], np.int8), np.array([[5, 13], [8, -1]], np.int8),
+                       np.array([[6]], np.int8)),
+    # no masking at all, split on case changes only
+    "no_mask": (np.array([[4, 16, -1], [3, 14, 15]], np.int8), np.zeros((0, 1), np.int8), np.zeros((0, 1), np.int8)),
+    # everything is a start (maximum pressure on the pending-start queue), split everywhere
+    "all_starts": (np.array([[0], [5], [6], [2]], np.int8), np.array([[1], [6]], np.int8), np.array([[6, 19]], np.int8)),
+    # uses every context column at least once, 1-D table for C_SYM (sum of rows, latok.c:340-353)
+    "all_columns": (np.array([[12, 13], [14, 15], [16, 17], [18, 19], [20, 21], [22, 23], [24, 0], [1, 2], [3, 4], [5, 6],
+                              [7, 8], [9, -1], [10, -1], [11, -1]], np.int8),
+                    np.array([[10, 22, 24], [9, 12, 22], [7, 18, -1]], np.int8), np.array([11, 9, -1], np.int8)),
+}
+
+
+def random_rule_tables(rng: random.Random):
+    def table(max_rows, max_cols, empty_ok):
+        rows = rng.randint(0 if empty_ok else 1, max_rows)
+        cols = rng.randint(1, max_cols)
+        t = np.full((rows, cols), -1, np.int8)
+        for r in range(rows):
+            k = rng.randint(1, cols)
+            t[r, :k] = [rng.randrange(25) for _ in range(k)]
+        return t
+    return table(8, 3, False), table(5, 4, True), table(3, 3, True)
+
+
+def rule_row_sets(tables):
+    """(C_SPLIT, C_MASK, C_SYM) -> (uint32[3*16] column sets, int32[3] row counts): the packing the kernel interprets."""
+    rows = np.zeros(3 * 16, np.uint32)
+    n_rows = np.zeros(3, np.int32)
+    for t, tab in enumerate(tables):
+        a = np.asarray(tab, np.int8)
+        if a.ndim == 1:
+            a = a[a != -1].reshape(-1, 1)
+        n_rows[t] = a.shape[0]
+        for r in range(a.shape[0]):
+            for v in a[r]:
+                if v != -1:
+                    rows[t * 16 + r] |= np.uint32(1) << np.uint32(v)
+    return rows, n_rows
+
+
+def oracle_rule_bits(oracle, texts, tables):
+    """boundary bitmask of a batch under custom tables, from the reference-shaped oracle, string by string"""
+    total = sum(len(t) for t in texts)
+    flags = np.zeros(total, bool)
+    k = 0
+    for t in texts:
+        if len(t):
+            flags[k:k + len(t)] = oracle.split_values_rules(t, *tables) != 0
+        k += len(t)
+    bits = np.packbits(np.concatenate([flags, np.zeros((-total) % 64, bool)]), bitorder="little").view(np.uint64)
+    return bits

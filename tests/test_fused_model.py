@@ -78,3 +78,26 @@ def test_model_block_mask(model, oracle):
         out = np.zeros(n, np.int8)
         model.fused_block_mask(a1.ctypes.data, a2.ctypes.data, n, out.ctypes.data)
         assert np.array_equal(out, oracle.gen_block_mask(a1, a2)), (n, p1, p2)
+
+
+@pytest.mark.parametrize("name", ["default", "sym_everywhere", "no_mask", "all_starts", "all_columns", "random"])
+def test_model_runtime_rule_tables(model, oracle, name):
+    """kModeRules: caller-supplied C_SPLIT / C_MASK / C_SYM interpreted over the 25 feature planes (lane_math.h:
+    lk_rules_generic) against the reference recipe run on the same tables by the oracle."""
+    from conftest import RULE_SETS, oracle_rule_bits, random_rule_tables, rule_row_sets
+    model.fused_split_batch_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+    rng = random.Random(hash(name) & 0xFFFF)
+    for rep in range(6 if name == "random" else 3):
+        tables = random_rule_tables(rng) if name == "random" else RULE_SETS[name]
+        rows, n_rows = rule_row_sets(tables)
+        for kind, n, lo, hi in [("mixed", 120, 0, 60), ("starts", 20, 0, 400), ("mixed", 2, 4000, 9000),
+                                ("rare_space_at", 2, 5000, 9000)]:
+            texts = random_strings(rng, rng.randint(1, n), lo, hi, ALPHABETS[kind])
+            cps, row = pack(texts)
+            bits = np.zeros((int(row[-1]) + 63) // 64, np.uint64)
+            assert model.fused_split_batch_rules(cps.ctypes.data, row.ctypes.data, len(row) - 1, rows.ctypes.data,
+                                                 n_rows.ctypes.data, bits.ctypes.data, None) == 0
+            assert np.array_equal(bits, oracle_rule_bits(oracle, texts, tables)), (name, rep, kind)
+            if name == "default":
+                assert np.array_equal(bits, oracle.split_batch(cps, row, want_values=False)[1])

@@ -452,3 +452,58 @@ def test_edge_aligned_patterns(gpu, oracle):
                 texts[-1] = texts[-1] + sp            # or glued to the filler, straddling the target
             pos += len(sp)
         _check_batch(oracle, texts)
+
+
+@pytest.mark.parametrize("name", ["default", "sym_everywhere", "no_mask", "all_starts", "all_columns", "random"])
+def test_runtime_rule_tables(gpu, oracle, name):
+    """latok_set_rules: the reference's extension point (other C_SPLIT / C_MASK / C_SYM combo matrices,
+    default_tokenizer.py:9-30,108-134) evaluated inside the fused kernel, against the reference recipe run on the same
+    tables by the oracle; bitmask, offsets and token spans."""
+    from conftest import RULE_SETS, oracle_rule_bits, random_rule_tables
+    from latok_amd import batch
+    rng = random.Random(hash(name) & 0xFFFF)
+    try:
+        for rep in range(5 if name == "random" else 2):
+            tables = random_rule_tables(rng) if name == "random" else RULE_SETS[name]
+            batch.set_rules(*tables)
+            assert batch.rules_active()
+            for kind, n, lo, hi in [("mixed", 300, 0, 60), ("starts", 40, 0, 400), ("mixed", 3, 4000, 20000),
+                                    ("rare_space_at", 3, 5000, 30000), ("words", 100, 0, 200)]:
+                texts = random_strings(rng, rng.randint(1, n), lo, hi, ALPHABETS[kind])
+                cps, row = pack(texts)
+                total = int(row[-1])
+                want = oracle_rule_bits(oracle, texts, tables)
+                got = batch.split_mask_batch(cps, row)
+                assert np.array_equal(got, want), (name, rep, kind)
+                counts, offs = batch.split_offsets_csr(cps, row)
+                flags = bits_to_bool(want, total)
+                exp = [np.nonzero(flags[row[s]:row[s + 1]])[0] for s in range(len(texts))]
+                assert np.array_equal(counts, [len(e) for e in exp])
+                assert np.array_equal(offs, np.concatenate(exp))
+                # token spans = the reference's slice / strip / drop-empty loop over those offsets
+                toks = batch.tokenize_batch(texts[:50])
+                for t, e, g in zip(texts[:50], exp, toks):
+                    cut = [int(x) for x in e] + [len(t)]
+                    assert g == [w for w in (t[a:b].strip() for a, b in zip(cut, cut[1:])) if w]
+                if name == "default":
+                    batch.reset_rules()
+                    assert np.array_equal(batch.split_mask_batch(cps, row), want)
+                    batch.set_rules(*tables)
+            with pytest.raises(ValueError):
+                batch.split_values_batch(*pack(["abc"]))   # per-term values exist for the built-in tables only
+    finally:
+        batch.reset_rules()
+    assert not batch.rules_active()
+    cps, row = pack([G1])
+    assert np.array_equal(batch.split_mask_batch(cps, row), oracle.split_batch(cps, row, want_values=False)[1])
+
+
+def test_runtime_rule_tables_are_validated(gpu):
+    from conftest import DEFAULT_RULES
+    from latok_amd import batch
+    s, m, y = DEFAULT_RULES
+    for bad in [(np.array([[25]], np.int8), m, y), (s, np.array([[-1, 3]], np.int8), y), (s, m, np.array([[-2]], np.int8)),
+                (np.zeros((17, 1), np.int8), m, y)]:
+        with pytest.raises(ValueError):
+            batch.set_rules(*bad)
+        assert not batch.rules_active()

@@ -68,6 +68,25 @@ def split_code(w: int) -> int:
     return c
 
 
+# Rule code (runtime rule tables, kModeRules): the split code plus NUM in bit 6 for non-symbols, so that all 12 base
+# features of a character can be recovered from one byte (lane_math.h:lk_feature_planes).
+def rule_code(w: int) -> int:
+    c = split_code(w)
+    if not (w >> Y) & 1:
+        c |= ((w >> N) & 1) << 6
+    return c
+
+
+def rule_code_word(c: int) -> int:
+    """Inverse of rule_code (what the kernel decodes); used to check that the byte loses nothing."""
+    b = lambda i: (c >> i) & 1  # noqa: E731
+    y = b(1)
+    w = (b(5) & (1 - y)) << A | b(4) << AN | (b(6) & (1 - y)) << N | b(2) << L | b(3) << U | b(0) << S | y << Y
+    w |= (b(5) & y & (1 - b(7))) << T | (b(5) & b(6) & y) << AT | (b(7) & (1 - b(6)) & (1 - b(5))) << CO
+    w |= (b(7) & b(5)) << SL | (b(7) & b(6)) << PE
+    return w
+
+
 def sweep_reference() -> np.ndarray:
     ext = ref_loader.load_ref_ext()
     words = np.zeros(N_CP, np.uint16)
@@ -112,6 +131,9 @@ def main():
     assert zero_block is not None
     assert stage1[0] == 0, "ASCII block must be block 0 (fused kernel fast path)"
     codes = [split_code(w) for w in classes]
+    rcodes = [rule_code(w) for w in classes]
+    for w, c in zip(classes, rcodes):
+        assert rule_code_word(c) == w, (w, c)
 
     dev = [
         "// GENERATED by tools/gen_unicode_tables.py -- do not edit.",
@@ -127,6 +149,8 @@ def main():
         c_array("kClassWord", "unsigned short", classes),
         "/* 8-bit sparse split code per class (split_code.h) */",
         c_array("kClassCode", "unsigned char", codes),
+        "/* 8-bit rule code per class: split code + NUM in bit 6 for non-symbols (runtime rule tables) */",
+        c_array("kClassRuleCode", "unsigned char", rcodes),
         "",
     ]
     with open(os.path.join(ROOT, "latok_amd", "csrc", "unicode_tables.inc"), "w") as f:

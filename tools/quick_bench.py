@@ -31,6 +31,11 @@ def main():
     print(f"device fill s={time.time() - t:.3f}", flush=True)
     n8 = C.c_int64(0)
     _lib.check(lib.latok_utf8_bytes(d_cps, total, C.byref(n8), _lib.DEVICE_PTRS))
+    if len(sys.argv) > 4 and sys.argv[4] == "rules":   # the built-in tables, but interpreted at run time (kModeRules)
+        from latok_amd import batch
+        from latok_amd.core import default_tokenizer as dt
+        batch.set_rules(dt.C_SPLIT, dt.C_MASK, dt.C_SYM)
+        print("runtime rule tables installed", flush=True)
     ms_total, ms_tiles, nfix = C.c_float(0), C.c_float(0), C.c_int64(0)
     _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 3, iters, C.byref(ms_total),
                                           C.byref(ms_tiles), C.byref(nfix)))

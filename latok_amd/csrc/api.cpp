@@ -67,6 +67,37 @@ struct DevBuf {
     }
 };
 
+// pinned, device-mapped host memory: small host-pointer calls stage their inputs here and have the kernels read and
+// write it in place over the bus, so that a call costs launches + ONE synchronisation instead of five blocking copies
+struct PinBuf {
+    void* h = nullptr;   // host address
+    void* d = nullptr;   // the same memory as the device sees it
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return LATOK_OK;
+        release();
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+            release();
+            return fail(LATOK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return LATOK_OK;
+    }
+    void release() {
+        if (h) (void)hipHostFree(h);
+        h = d = nullptr;
+        cap = 0;
+    }
+};
+
+// host-pointer calls up to this size take the pinned zero-copy path (inputs are then read over the bus, including the
+// binary searches over row_off, so it only pays for small batches; larger ones amortise their copies)
+constexpr int64_t kSmallChars = 16384;
+constexpr int64_t kSmallStrings = 512;
+
 struct Ctx {
     bool inited = false;
     int device = -1, n_cu = 0;
@@ -80,6 +111,7 @@ struct Ctx {
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, tok_sid, scalar, h_aux;
+    PinBuf pin;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
@@ -181,6 +213,21 @@ int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int
     if (total == 0) return LATOK_OK;
     if (!cps || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
     const size_t out_bytes = mode == latok::kModeBits ? (size_t)((total + 63) / 64) * 8 : (size_t)total;
+    if (total <= kSmallChars && n_str <= kSmallStrings) {
+        // small batch: stage in pinned mapped memory, kernels work on it in place, one synchronisation
+        const size_t o_row = ((size_t)total * 4 + 15) & ~(size_t)15, o_out = o_row + (size_t)(n_str + 1) * 8;
+        if ((rc = g.pin.ensure(o_out + ((out_bytes + 15) & ~(size_t)15)))) return rc;
+        memcpy(g.pin.h, cps, (size_t)total * 4);
+        memcpy((char*)g.pin.h + o_row, row_off, (size_t)(n_str + 1) * 8);
+        char* d = (char*)g.pin.d;
+        rc = run_pipeline((const uint32_t*)d, (const int64_t*)(d + o_row), n_str, total,
+                          mode == latok::kModeBits ? (uint64_t*)(d + o_out) : nullptr,
+                          mode == latok::kModeValues ? (uint8_t*)(d + o_out) : nullptr, mode, st);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        memcpy(out, (char*)g.pin.h + o_out, out_bytes);
+        return LATOK_OK;
+    }
     if ((rc = g.h_cps.ensure((size_t)total * 4))) return rc;
     if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
     if ((rc = g.h_out.ensure(out_bytes))) return rc;
@@ -252,6 +299,7 @@ int latok_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
+    g.pin.release();
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
@@ -405,7 +453,23 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     }
     if (n_str == 0) return LATOK_OK;
     if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
-    if (!dev && !utf8) {
+    // small host batch: inputs and every output live in pinned mapped memory; nothing is copied by the runtime and the
+    // call synchronises once (a string of ~100 chars: ~110 us of blocking copies otherwise)
+    const bool small = !dev && !utf8 && total > 0 && total <= kSmallChars && n_str <= kSmallStrings;
+    const size_t item_bytes = feats ? 32 : (spans ? 16 : 8);
+    size_t po_row = 0, po_n = 0, po_counts = 0, po_items = 0, po_feat = 0;
+    if (small) {
+        po_row = ((size_t)total * 4 + 15) & ~(size_t)15;
+        po_n = po_row + (size_t)(n_str + 1) * 8;
+        po_counts = po_n + 16;
+        po_items = po_counts + (size_t)n_str * 8;
+        po_feat = po_items + (size_t)total * item_bytes;      // at most one item per char
+        if ((rc = g.pin.ensure(po_feat + (feats ? (size_t)total * LATOK_FEATURE_COUNT : 0) + 64))) return rc;
+        memcpy(g.pin.h, cps, (size_t)total * 4);
+        memcpy((char*)g.pin.h + po_row, row_off, (size_t)(n_str + 1) * 8);
+        d_cps = (const uint32_t*)g.pin.d;
+        d_row = (const int64_t*)((char*)g.pin.d + po_row);
+    } else if (!dev && !utf8) {
         if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
         if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
         if (total > 0) HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
@@ -431,10 +495,32 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
                            nullptr, nullptr, d_space)))
         return rc;
     HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
-    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, (int64_t*)g.scalar.p,
-                                         (int64_t*)g.scan_tot.p, st));
-    int64_t* d_counts = dev ? counts_out : (int64_t*)g.counts.p;
-    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_row, n_str, total, (const int64_t*)g.scalar.p, d_counts, st));
+    int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
+    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, d_total, (int64_t*)g.scan_tot.p, st));
+    int64_t* d_counts = dev ? counts_out : (small ? (int64_t*)((char*)g.pin.d + po_counts) : (int64_t*)g.counts.p);
+    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_row, n_str, total, d_total, d_counts, st));
+    if (small) {
+        // the scatter cannot overrun: the pinned item area holds one item per char, the most there can be
+        int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
+        int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
+        if (feats && (rc = g.tok_sid.ensure((size_t)total * 8))) return rc;
+        HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total,
+                                           d_row, n_str, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
+        if (feats)
+            HIP_TRY(latok::launch_token_features_n(d_items, d_total, total, (const int64_t*)g.tok_sid.p, d_row, d_cps,
+                                                   (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p,
+                                                   (const uint16_t*)g.cw.p, d_feat, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int64_t n_small = *(const int64_t*)((char*)g.pin.h + po_n);
+        *n_items_out = n_small;
+        memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * 8);
+        if (n_small > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_small);
+        if (n_small == 0) return LATOK_OK;
+        if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
+        memcpy(items_out, (char*)g.pin.h + po_items, (size_t)n_small * item_bytes);
+        if (feats) memcpy(features_out, (char*)g.pin.h + po_feat, (size_t)n_small * LATOK_FEATURE_COUNT);
+        return LATOK_OK;
+    }
     int64_t n_items = 0;
     HIP_TRY(hipMemcpyAsync(&n_items, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -443,7 +529,6 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
     if (n_items == 0) return LATOK_OK;
     if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
-    const size_t item_bytes = feats ? 32 : (spans ? 16 : 8);
     int64_t* d_items = items_out;
     int8_t* d_feat = features_out;
     if (!dev) {

@@ -117,9 +117,10 @@ struct FeatTables {
 };
 
 // pass 2 of featurize: one thread per token sums the 25 feature bits of every char of the token's raw span
-__global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_tok, const int64_t* __restrict__ row_off,
-                                 FeatTables F) {
+__global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_tok, const int64_t* __restrict__ n_tok_dev,
+                                 const int64_t* __restrict__ row_off, FeatTables F) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_tok_dev) n_tok = *n_tok_dev;   // count still on the device (small-batch path: no host round trip)
     if (k >= n_tok) return;
     const int64_t s = F.tok_sid[k];
     const int64_t lo = row_off[s], hi = row_off[s + 1];
@@ -147,7 +148,19 @@ hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int
                                  int8_t* features, hipStream_t st) {
     if (n_tok <= 0) return hipSuccess;
     FeatTables F{cps, t1, t2cls, cw, features, const_cast<int64_t*>(tok_sid)};
-    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, st, spans4, n_tok, row_off, F);
+    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, st, spans4, n_tok,
+                       (const int64_t*)nullptr, row_off, F);
+    return hipGetLastError();
+}
+
+// same, with the token count read from device memory; the grid covers max_tok
+hipError_t launch_token_features_n(const int64_t* spans4, const int64_t* n_tok_dev, int64_t max_tok, const int64_t* tok_sid,
+                                   const int64_t* row_off, const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls,
+                                   const uint16_t* cw, int8_t* features, hipStream_t st) {
+    if (max_tok <= 0) return hipSuccess;
+    FeatTables F{cps, t1, t2cls, cw, features, const_cast<int64_t*>(tok_sid)};
+    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, spans4, (int64_t)0,
+                       n_tok_dev, row_off, F);
     return hipGetLastError();
 }
 

@@ -84,6 +84,9 @@ hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* s
 hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
                                  const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
                                  int8_t* features, hipStream_t st);
+hipError_t launch_token_features_n(const int64_t* spans4, const int64_t* n_tok_dev, int64_t max_tok, const int64_t* tok_sid,
+                                   const int64_t* row_off, const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls,
+                                   const uint16_t* cw, int8_t* features, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

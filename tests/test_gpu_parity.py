@@ -507,3 +507,27 @@ def test_runtime_rule_tables_are_validated(gpu):
         with pytest.raises(ValueError):
             batch.set_rules(*bad)
         assert not batch.rules_active()
+
+
+def test_small_batch_path_thresholds(gpu, oracle):
+    """Host-pointer calls up to 16 384 chars / 512 strings run on pinned mapped memory in place (api.cpp: kSmallChars,
+    kSmallStrings); the results must not depend on which side of the thresholds a batch falls."""
+    from latok_amd import batch
+    rng = random.Random(4242)
+    for total, n_str in [(16384, 1), (16385, 1), (16384, 512), (16384, 513), (16000, 512), (100, 513), (1, 1), (4096, 7)]:
+        cuts = sorted(rng.sample(range(1, total), min(n_str - 1, total - 1))) if n_str > 1 else []
+        cuts += [total] * (n_str - 1 - len(cuts))   # not enough room for distinct cuts: the rest are empty strings
+        blob = "".join(rng.choice(ALPHABETS["mixed"]) for _ in range(total))
+        texts = [blob[a:b] for a, b in zip([0] + cuts, cuts + [total])]
+        assert len(texts) == n_str and sum(map(len, texts)) == total
+        _check_batch(oracle, texts)
+        got = batch.tokenize_batch(texts)
+        assert got == [oracle.tokenize(t) if t else [] for t in texts]
+        feats = batch.featurize_batch(texts[:40])
+        for t, toks in zip(texts[:40], feats):
+            if not t:
+                assert toks == []
+                continue
+            m = oracle.gen_parse_matrix(t)
+            for tok in toks:
+                assert np.array_equal(tok.features, m[tok.start_idx:tok.end_idx].sum(axis=0, dtype=np.int8))

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Measurement of the SURVEY 8(f) rows on device-resident data: one JSON line per path.
+
+  mask            latok_split_mask_batch            (the north-star path; here for reference, bench.py is the contract)
+  offsets         latok_split_offsets_batch         (8f-1: np.nonzero per string)
+  spans           latok_token_spans_batch           (8f-1: slice / strip / drop-empty)
+  features        latok_token_features_batch        (8f-2: featurize)
+  utf8_mask       latok_split_mask_utf8_batch       (8f-3: UTF-8 in, code-point row offsets + mask out)
+  utf8_offsets    latok_split_offsets_utf8_batch
+  utf8_spans      latok_token_spans_utf8_batch
+  rules_mask      latok_split_mask_batch after latok_set_rules(built-in tables)   (8f-4)
+
+Every line carries: ms per call (wall clock around `--iters` blocking calls, inputs and outputs in HBM; the
+compaction calls contain one 8-byte blocking read of the item total), the UTF-8 GB/s of the corpus through that path,
+the path's ALGORITHMIC bytes (inputs that must be read + outputs that must be written, stated per line) and their rate
+as a fraction of the 8 TB/s HBM peak.  `--cpu N` adds the reference's own C functions + its Python glue (oracle/_ref,
+test infrastructure, timed here as the baseline only) on the first N strings for offsets and tokens.
+
+usage: tools/path_bench.py [--workload C2|C3] [--strings N] [--iters K] [--cpu N]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from latok_amd import _lib  # noqa: E402
+
+HBM_PEAK = 8000.0
+WORKLOADS = {"C2": (_lib.CORPUS_ASCII, 0x1A70C0DE, 64, 192), "C3": (_lib.CORPUS_UNICODE, 0x1A70C0DF, 128, 384)}
+
+
+def utf8_of(cps, row):
+    """packed UTF-32 -> (utf8 bytes uint8[], byte offsets int64[n+1]) on the host (setup, not timed)."""
+    lens = 1 + (cps >= 0x80).astype(np.int64) + (cps >= 0x800) + (cps >= 0x10000)
+    pref = np.zeros(cps.size + 1, np.int64)
+    np.cumsum(lens, out=pref[1:])
+    boff = pref[row]
+    if int(pref[-1]) == cps.size:
+        u8 = cps.astype(np.uint8)
+    else:
+        u8 = np.frombuffer(cps.astype("<u4").tobytes().decode("utf-32-le", "surrogatepass").encode("utf-8", "surrogatepass"),
+                           np.uint8)
+    assert u8.size == int(pref[-1])
+    return np.ascontiguousarray(u8), np.ascontiguousarray(boff)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--strings", type=int, default=1_000_000)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
+    ap.add_argument("--paths", default="mask,offsets,spans,features,utf8_mask,utf8_offsets,utf8_spans,rules_mask")
+    args = ap.parse_args()
+    lib = _lib.ensure_init()
+    model, seed, lo, hi = WORKLOADS[args.workload]
+    n = args.strings
+    row = np.zeros(n + 1, np.int64)
+    _lib.check(lib.latok_corpus_offsets(seed, 0, n, lo, hi, row.ctypes.data))
+    total = int(row[-1])
+    words = (total + 63) // 64
+    d_row = lib.latok_dev_alloc(row.nbytes)
+    d_cps = lib.latok_dev_alloc(total * 4)
+    _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
+    _lib.check(lib.latok_corpus_fill_device(seed, model, 0, n, d_row, d_cps, None))
+    cps = np.empty(total, np.uint32)
+    _lib.check(lib.latok_memcpy_d2h(cps.ctypes.data, d_cps, total * 4))
+    u8, boff = utf8_of(cps, row)
+    n8 = int(u8.size)
+    d_u8 = lib.latok_dev_alloc(n8 + 64)
+    d_boff = lib.latok_dev_alloc(boff.nbytes)
+    _lib.check(lib.latok_memcpy_h2d(d_u8, u8.ctypes.data, n8))
+    _lib.check(lib.latok_memcpy_h2d(d_boff, boff.ctypes.data, boff.nbytes))
+    cap = total // 2 + 4096
+    d_bits = lib.latok_dev_alloc(words * 8 + 8)
+    d_counts = lib.latok_dev_alloc(n * 8)
+    d_items = lib.latok_dev_alloc(cap * 32)
+    d_feat = lib.latok_dev_alloc(cap * 25)
+    d_cprow = lib.latok_dev_alloc((n + 1) * 8)
+    for p in (d_row, d_cps, d_u8, d_boff, d_bits, d_counts, d_items, d_feat, d_cprow):
+        if not p:
+            raise RuntimeError(_lib.last_error())
+    nout, tcp = C.c_int64(0), C.c_int64(0)
+    D = _lib.DEVICE_PTRS
+    csr = 8 * (n + 1)
+
+    def run(name, fn, alg, note):
+        _lib.check(fn())
+        _lib.check(lib.latok_sync())
+        t = time.perf_counter()
+        for _ in range(args.iters):
+            _lib.check(fn())
+        _lib.check(lib.latok_sync())
+        dt = (time.perf_counter() - t) / args.iters
+        a = alg()
+        print(json.dumps({"path": name, "workload": args.workload, "strings": n, "chars": total, "utf8_bytes": n8,
+                          "items": nout.value, "ms_per_call": dt * 1e3, "utf8_GBps": n8 / dt / 1e9,
+                          "alg_bytes": a, "alg_GBps": a / dt / 1e9, "frac_of_hbm_peak": a / dt / 1e9 / HBM_PEAK,
+                          "alg_bytes_are": note}), flush=True)
+
+    paths = args.paths.split(",")
+    if "mask" in paths:
+        run("mask", lambda: lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None),
+            lambda: 4 * total + csr + words * 8, "4 B/char + 8 B/string read, 1 bit/char written")
+    if "offsets" in paths:
+        run("offsets", lambda: lib.latok_split_offsets_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: 4 * total + csr + 8 * n + 8 * nout.value, "4 B/char + 8 B/string read; 8 B/string counts + 8 B/boundary written")
+    if "spans" in paths:
+        run("spans", lambda: lib.latok_token_spans_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: 4 * total + csr + 8 * n + 16 * nout.value, "4 B/char + 8 B/string read; 8 B/string counts + 16 B/token written")
+    if "features" in paths:
+        run("features", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D, None),
+            lambda: 2 * 4 * total + csr + 8 * n + (32 + 25) * nout.value,
+            "4 B/char read twice (mask, then per-token sums) + 8 B/string; 8 B/string + 57 B/token written")
+    if "utf8_mask" in paths:
+        nout.value = 0
+        run("utf8_mask", lambda: lib.latok_split_mask_utf8_batch(d_u8, d_boff, n, n8, d_bits, words + 1, d_cprow, C.byref(tcp), D, None),
+            lambda: n8 + csr + words * 8 + csr, "UTF-8 bytes + 8 B/string read; 1 bit/char + 8 B/string cp offsets written")
+        assert tcp.value == total
+    if "utf8_offsets" in paths:
+        run("utf8_offsets", lambda: lib.latok_split_offsets_utf8_batch(d_u8, d_boff, n, n8, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: n8 + csr + 8 * n + 8 * nout.value, "UTF-8 bytes + 8 B/string read; 8 B/string + 8 B/boundary written")
+    if "utf8_spans" in paths:
+        run("utf8_spans", lambda: lib.latok_token_spans_utf8_batch(d_u8, d_boff, n, n8, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: n8 + csr + 8 * n + 16 * nout.value, "UTF-8 bytes + 8 B/string read; 8 B/string + 16 B/token written")
+    if "rules_mask" in paths:
+        from latok_amd import batch
+        from latok_amd.core import default_tokenizer as dt
+        batch.set_rules(dt.C_SPLIT, dt.C_MASK, dt.C_SYM)
+        nout.value = 0
+        try:
+            run("rules_mask", lambda: lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None),
+                lambda: 4 * total + csr + words * 8, "as mask; tables interpreted at run time")
+        finally:
+            batch.reset_rules()
+
+    if args.cpu > 0:   # baseline only: the reference's own C (oracle/_ref) under its restated glue, one string at a time
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import latok_oracle as orc
+        m = min(args.cpu, n)
+        text = cps[:row[m]].astype("<u4").tobytes().decode("utf-32-le", "surrogatepass")
+        strs = [text[row[i]:row[i + 1]] for i in range(m)]
+        b8 = int(boff[m])
+        try:
+            glue = orc.RefGlue()
+            kind = "reference"
+            offsets = lambda s: np.nonzero(glue.split_values(s))[0]  # noqa: E731
+        except Exception:
+            kind = "port"
+            offsets = orc.split_offsets
+        t = time.perf_counter()
+        for s in strs:
+            offsets(s)
+        dt_off = time.perf_counter() - t
+        t = time.perf_counter()
+        for s in strs:
+            nz = offsets(s)
+            a, b, toks = int(nz[0]), 0, []
+            for b in nz[1:]:
+                b = int(b)
+                w = s[a:b].strip()
+                if w:
+                    toks.append(w)
+                a = b
+            w = s[b:].strip()
+            if w:
+                toks.append(w)
+        dt_tok = time.perf_counter() - t
+        for name, dt_ in (("offsets", dt_off), ("tokens", dt_tok)):
+            print(json.dumps({"cpu_baseline": name, "kind": kind, "cores": 1, "strings": m, "utf8_bytes": b8,
+                              "seconds": dt_, "utf8_GBps": b8 / dt_ / 1e9}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

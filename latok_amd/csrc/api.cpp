@@ -110,7 +110,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, tok_sid, scalar, h_aux;
+    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, tok_sid, scalar, h_aux, tile_first;
     PinBuf pin;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -134,7 +134,7 @@ int need_init() {
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
-                 const int* bm_flags = nullptr, uint64_t* d_space = nullptr) {
+                 const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (g.rules_on) {
         if (mode == latok::kModeValues)
@@ -159,6 +159,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
+    P.tile_first = d_tile_first;
     P.summ = (int4*)g.summ.p;
     P.seg_fn = (latok::Fn64*)g.seg_agg.p;
     P.seg_hd = (latok::Hd64*)((char*)g.seg_agg.p + (size_t)P.n_segs * sizeof(latok::Fn64));
@@ -301,7 +302,7 @@ int latok_shutdown(void) {
     (void)hipStreamSynchronize(g.stream);
     g.pin.release();
     g.rules_on = false;
-    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -491,8 +492,10 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
     const uint64_t* d_item_mask = spans ? d_kept : d_bits;
     int64_t* d_rank = (int64_t*)g.bases.p;
+    if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
+    int64_t* d_tile_first = (int64_t*)g.tile_first.p;
     if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space)))
+                           nullptr, nullptr, d_space, d_tile_first)))
         return rc;
     HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
     int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
@@ -505,7 +508,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
         if (feats && (rc = g.tok_sid.ensure((size_t)total * 8))) return rc;
         HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total,
-                                           d_row, n_str, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
+                                           d_row, n_str, d_tile_first, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
         if (feats)
             HIP_TRY(latok::launch_token_features_n(d_items, d_total, total, (const int64_t*)g.tok_sid.p, d_row, d_cps,
                                                    (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p,
@@ -541,7 +544,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     }
     if (feats && (rc = g.tok_sid.ensure((size_t)n_items * 8))) return rc;   // token -> string map between the two passes
     HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total, d_row,
-                                       n_str, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
+                                       n_str, d_tile_first, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
     if (feats)
         HIP_TRY(latok::launch_token_features(d_items, n_items, (const int64_t*)g.tok_sid.p, d_row, d_cps,
                                              (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p,

@@ -65,40 +65,48 @@ __device__ __forceinline__ int64_t prev_zero_end(const uint64_t* __restrict__ bi
     return from;
 }
 
-// the token that starts at boundary p: [p, e) with e = next boundary (every string start is one) or the end of the
-// batch; stripped extent [a2, e2); kept iff a2 < e
-struct Token {
-    int64_t e, a2, e2;
-    bool kept;
-};
-__device__ __forceinline__ Token token_at(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
-                                          int64_t p, int64_t total) {
-    Token t;
-    t.e = next_set_bit(bits, p + 1, total);
-    t.a2 = next_zero_bit(space, p, t.e);
-    t.kept = t.a2 < t.e;
-    t.e2 = t.kept ? prev_zero_end(space, t.a2, t.e) : t.a2;
-    return t;
-}
-
 // ---- pass 1 --------------------------------------------------------------------------------------------------------
 // SPANS = false: items = boundary bits.  SPANS = true: items = boundaries whose token is kept; the kept-mask word is
-// stored for the later passes.
+// stored for the later passes.  A token is kept iff it holds a non-SPACE char; for all but the last boundary of a
+// word that is a mask test inside the word, the last one looks ahead until the next boundary (normally the next word).
+__device__ __forceinline__ uint64_t valid_mask(int64_t w, int64_t total) {
+    const int64_t remain = total - (w << 6);
+    return remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
+}
+
+__device__ __forceinline__ bool tail_has_nonspace(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                                                  int64_t w, int64_t n_words, int64_t total) {
+    for (int64_t v = w + 1; v < n_words; ++v) {
+        const uint64_t xb = bits[v];
+        const uint64_t nn = ~space[v] & valid_mask(v, total);
+        if (xb) return (nn & ((xb & (~xb + 1ull)) - 1ull)) != 0;
+        if (nn) return true;
+    }
+    return false;
+}
+
 template <bool SPANS>
 __global__ void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, int64_t n_words,
                               int64_t total, uint64_t* __restrict__ kept_out, int64_t* __restrict__ cnt) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
-    uint64_t x = bits[w];
+    const uint64_t x = bits[w];
     if (!SPANS) {
         cnt[w] = __popcll(x);
         return;
     }
-    uint64_t kept = 0;
-    while (x) {
-        const int b = __builtin_ctzll(x);
-        x &= x - 1;
-        if (token_at(bits, space, (w << 6) + b, total).kept) kept |= 1ull << b;
+    const uint64_t nn = ~space[w] & valid_mask(w, total);   // non-SPACE chars of the word
+    uint64_t kept = 0, rest = x;
+    while (rest) {
+        const int b = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        const uint64_t from_b = ~0ull << b;
+        if (rest) {   // the token ends at the next boundary of this word
+            const uint64_t seg = from_b & ((rest & (~rest + 1ull)) - 1ull);
+            if (nn & seg) kept |= 1ull << b;
+        } else if ((nn & from_b) || tail_has_nonspace(bits, space, w, n_words, total)) {
+            kept |= 1ull << b;
+        }
     }
     kept_out[w] = kept;
     cnt[w] = __popcll(kept);
@@ -120,50 +128,183 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 }
 
 // ---- pass 3 --------------------------------------------------------------------------------------------------------
-// index of the string that contains packed position p (the last string that starts at or before p)
-__device__ __forceinline__ int64_t string_of(const int64_t* __restrict__ row_off, int64_t n_str, int64_t p) {
-    int64_t lo = 0, hi = n_str;   // answer s in [lo, hi): row_off[s] <= p < row_off[s+1] (skipping empty strings)
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (row_off[mid] <= p) lo = mid; else hi = mid;
+// One wave per 64 consecutive words (4096 chars).  The wave
+//   (a) finds the string that contains the first char of each of its words: one k-ary search over row_off for the
+//       4096-char window, then the starts inside the window go through an LDS max + a prefix max over the lanes
+//       (empty strings share a start: the max keeps the last, i.e. the one that owns the chars);
+//   (b) lane = word: walks the items of its word (all mask arithmetic inside the word; only a token that runs past the
+//       word's end follows the masks further) and puts the records into an LDS window at their rank inside the wave;
+//   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
+// KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
+// KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end}, tok_sid[k] = string id (featurize pass).
+constexpr int kScatterWaves = 4;                 // waves per workgroup
+constexpr int kScatterWin = 1024;                // int64 slots of one wave's LDS window (8 KiB)
+
+__device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
+                                                       int lane) {
+    int64_t lo = 0, hi = n_entries;   // smallest s with row_off[s] >= c, 64 probes per round
+    while (hi > lo) {
+        const int64_t len = hi - lo;
+        const int64_t step = (len + 63) / 64;
+        const int64_t p = lo + (int64_t)lane * step;
+        const bool pred = p < hi && row_off[p] >= c;
+        const unsigned long long m = __ballot(pred);
+        if (!m) {
+            const int64_t n_valid = (len + step - 1) / step;
+            lo = min(lo + (n_valid - 1) * step + 1, hi);
+        } else {
+            const int f = __builtin_ctzll(m);
+            hi = lo + (int64_t)f * step;
+            if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
+        }
     }
     return lo;
 }
 
-// KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
-// KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end}, tok_sid[k] = string id (featurize pass).
 template <int KIND>
-__global__ void k_word_scatter(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
-                               const uint64_t* __restrict__ item_mask, const int64_t* __restrict__ word_rank,
-                               int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
-                               int64_t* __restrict__ out, int64_t* __restrict__ tok_sid) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    uint64_t x = item_mask[w];
-    if (!x) return;
-    int64_t k = word_rank[w];
-    int64_t s = string_of(row_off, n_str, (w << 6) + __builtin_ctzll(x));
-    int64_t lo = row_off[s], hi = row_off[s + 1];
-    while (x) {
-        const int64_t p = (w << 6) + __builtin_ctzll(x);
-        x &= x - 1;
-        while (p >= hi) { ++s; lo = hi; hi = row_off[s + 1]; }   // next (non-empty) string
-        if (KIND == 0) {
-            out[k] = p - lo;
-        } else {
-            const Token t = token_at(bits, space, p, total);
-            if (KIND == 1) {
-                out[2 * k] = t.a2 - lo;
-                out[2 * k + 1] = t.e2 - lo;
-            } else {
-                out[4 * k] = p - lo;
-                out[4 * k + 1] = t.e - lo;
-                out[4 * k + 2] = t.a2 - lo;
-                out[4 * k + 3] = t.e2 - lo;
-                tok_sid[k] = s;
-            }
+__global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
+    const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
+    const int64_t* __restrict__ word_rank, int64_t n_words, int64_t total, const int64_t* __restrict__ row_off,
+    int64_t n_str, const int64_t* __restrict__ tile_first, int64_t* __restrict__ out, int64_t* __restrict__ tok_sid) {
+    constexpr int kVals = KIND == 0 ? 1 : (KIND == 1 ? 2 : 4);      // int64 values per item
+    constexpr int kWin = KIND == 2 ? kScatterWin : kScatterWin;     // int64 slots of one wave's window
+    constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
+    __shared__ int64_t win_s[kScatterWaves][kWin];
+    __shared__ int64_t sid_s[kScatterWaves][KIND == 2 ? kCap : 1];
+    __shared__ long long smax_s[kScatterWaves][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
+    if (w0 >= n_words) return;                                      // whole wave (no block-wide barrier is used below)
+    const int64_t w = w0 + lane;
+    const uint64_t x = w < n_words ? item_mask[w] : 0ull;
+    const int cnt = __popcll(x);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const int n_wave = __shfl(inc, 63);
+    if (n_wave == 0) return;
+    const int off = inc - cnt;                                      // rank of my first item inside the wave
+    const int64_t base_out = __shfl(w < n_words ? word_rank[w] : 0, 0);   // lane 0's word always exists
+    int64_t* win = win_s[wave];
+    int64_t* sidw = sid_s[wave];
+    long long* smax = smax_s[wave];
+
+    // (a) string that contains the first char of every word
+    const int64_t t0 = w0 << 6;
+    // first string starting at or after t0: published by the tile kernel (one wave = one tile), else searched
+    int64_t idx0 = tile_first ? tile_first[w0 >> 6] : scatter_lower_bound(row_off, n_str, t0, lane);
+    if (idx0 > n_str) idx0 = n_str;
+    smax[lane] = -1;
+    if (lane == 0) smax[64] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t i0 = idx0; i0 < n_str; i0 += 64) {
+        const int64_t sidx = i0 + lane;
+        const int64_t ro = sidx < n_str ? row_off[sidx] : INT64_MAX;
+        const int64_t rel = ro - t0;
+        if (rel < 4096) atomicMax(&smax[(rel + 63) >> 6], (long long)sidx);   // first word that begins at or after it
+        if (__shfl(ro, 63) >= t0 + 4096) break;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    long long sid = smax[lane];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(sid, d);
+        if (lane >= d && o > sid) sid = o;
+    }
+    if (sid < idx0 - 1) sid = idx0 - 1;                             // a string that began before the window
+
+    // (b) + (c), window by window
+    const int64_t base = w << 6;
+    const uint64_t xb = w < n_words ? bits[w] : 0ull;               // all boundaries of the word (item_mask is a subset)
+    const uint64_t nn = (KIND != 0 && w < n_words) ? (~space[w] & valid_mask(w, total)) : 0ull;
+    // the next word's masks (a token that crosses the word's end normally ends there): from the neighbour lane
+    uint64_t xb1 = 0, nn1 = 0;
+    if (KIND != 0) {
+        xb1 = __shfl_down(xb, 1);
+        nn1 = __shfl_down(nn, 1);
+        if (lane == 63) {
+            const bool has = w + 1 < n_words;
+            xb1 = has ? bits[w + 1] : 0ull;
+            nn1 = has ? (~space[w + 1] & valid_mask(w + 1, total)) : 0ull;
         }
-        ++k;
+    }
+    int64_t s = sid, lo = 0, hi = 0;
+    if (x) { lo = row_off[s]; hi = row_off[s + 1]; }
+    uint64_t rest = x;
+    int k = off;                                                    // wave rank of my next item
+    for (int win0 = 0; win0 < n_wave; win0 += kCap) {
+        while (rest && k < win0 + kCap) {
+            const int b = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            const int64_t p = base + b;
+            while (p >= hi) { ++s; lo = hi; hi = row_off[s + 1]; }   // next (non-empty) string
+            int64_t* rec = win + (k - win0) * kVals;
+            if (KIND == 0) {
+                rec[0] = p - lo;
+            } else {
+                // token [p, e): e = next boundary; stripped extent [a2, e2)
+                const uint64_t above = xb & (~1ull << b);
+                int64_t e, a2, e2;
+                if (above) {                                        // everything inside this word
+                    const int eb = __builtin_ctzll(above);
+                    const uint64_t seg = nn & (~0ull << b) & ((1ull << eb) - 1ull);   // kept => seg != 0
+                    e = base + eb;
+                    a2 = base + __builtin_ctzll(seg);
+                    e2 = base + 64 - __builtin_clzll(seg);
+                } else if (xb1) {                                   // ends at the first boundary of the next word
+                    const int eb = __builtin_ctzll(xb1);
+                    const uint64_t seg0 = nn & (~0ull << b);
+                    const uint64_t seg1 = nn1 & ((1ull << eb) - 1ull);           // eb < 64: bit eb is set in xb1
+                    e = base + 64 + eb;
+                    a2 = seg0 ? base + __builtin_ctzll(seg0) : base + 64 + __builtin_ctzll(seg1);
+                    e2 = seg1 ? base + 128 - __builtin_clzll(seg1) : base + 64 - __builtin_clzll(seg0);
+                } else {
+                    e = next_set_bit(bits, base + 64, total);
+                    const uint64_t seg = nn & (~0ull << b);
+                    a2 = seg ? base + __builtin_ctzll(seg) : next_zero_bit(space, base + 64, e);
+                    e2 = prev_zero_end(space, a2, e);
+                }
+                if (KIND == 1) {
+                    rec[0] = a2 - lo;
+                    rec[1] = e2 - lo;
+                } else {
+                    rec[0] = p - lo;
+                    rec[1] = e - lo;
+                    rec[2] = a2 - lo;
+                    rec[3] = e2 - lo;
+                    sidw[k - win0] = s;
+                }
+            }
+            ++k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n_here = min(kCap, n_wave - win0);
+        int64_t* dst = out + (base_out + win0) * kVals;
+        {   // 16 bytes per lane and store; the output is written once and not read back by this pipeline
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const int n_val = n_here * kVals;
+            const int head = (KIND == 0 && (((uintptr_t)dst >> 3) & 1)) ? 1 : 0;   // odd 8-byte slot: one scalar first
+            if (head && lane == 0) __builtin_nontemporal_store((long long)win[0], (long long*)dst);
+            const int n_pair = (n_val - head) >> 1;
+            for (int i = lane; i < n_pair; i += 64) {
+                ll2 v;
+                v.x = win[head + 2 * i];
+                v.y = win[head + 2 * i + 1];
+                __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(dst + head) + i);
+            }
+            if (((n_val - head) & 1) && lane == 0)
+                __builtin_nontemporal_store((long long)win[n_val - 1], (long long*)dst + n_val - 1);
+        }
+        if (KIND == 2)
+            for (int i = lane; i < n_here; i += 64) tok_sid[base_out + win0 + i] = sidw[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -187,18 +328,19 @@ hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, 
 
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, int64_t* out, int64_t* tok_sid, hipStream_t st) {
+                               int64_t n_str, const int64_t* tile_first, int64_t* out, int64_t* tok_sid, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_words + 255) / 256)), block(256);
+    const int64_t per_block = (int64_t)kScatterWaves * 64;
+    const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(kScatterWaves * 64);
     if (kind == 0)
         hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, out, tok_sid);
+                           row_off, n_str, tile_first, out, tok_sid);
     else if (kind == 1)
         hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, out, tok_sid);
+                           row_off, n_str, tile_first, out, tok_sid);
     else
         hipLaunchKernelGGL((k_word_scatter<2>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, out, tok_sid);
+                           row_off, n_str, tile_first, out, tok_sid);
     return hipGetLastError();
 }
 

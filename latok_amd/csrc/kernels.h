@@ -47,6 +47,7 @@ struct SplitParams {
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
     uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
+    int64_t* tile_first;        // optional [n_tiles]: first string that starts at or after each tile's first char
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
     Fn64* seg_fn;               // [n_segs] segment aggregates
     Hd64* seg_hd;               // [n_segs]
@@ -80,7 +81,7 @@ hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, 
                                 int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, int64_t* out, int64_t* tok_sid, hipStream_t st);
+                               int64_t n_str, const int64_t* tile_first, int64_t* out, int64_t* tok_sid, hipStream_t st);
 hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
                                  const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
                                  int8_t* features, hipStream_t st);

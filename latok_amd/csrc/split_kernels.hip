@@ -638,6 +638,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         }
     }
     __syncthreads();   // tables (first segment) and tf are in place
+    if (P.tile_first && tid < n_seg) P.tile_first[T0 + tid] = s_lo + tf[tid];   // the compaction passes reuse the index
     // (b) the tiles
     // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
     // One 512-byte store per 16 KiB tile, interleaved with the read stream, costs ~5 % of HBM throughput.

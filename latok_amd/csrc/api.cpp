@@ -110,7 +110,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, tok_sid, scalar, h_aux, tile_first;
+    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -302,7 +302,7 @@ int latok_shutdown(void) {
     (void)hipStreamSynchronize(g.stream);
     g.pin.release();
     g.rules_on = false;
-    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tok_sid, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -428,6 +428,26 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
     return LATOK_OK;
 }
 
+// featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
+static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
+                            const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_first, int8_t* d_feat,
+                            hipStream_t st) {
+    latok::FeatParams F;
+    F.cps = d_cps;
+    F.row_off = d_row;
+    F.n_str = n_str;
+    F.total = total;
+    F.n_tiles = (total + latok::kTile - 1) / latok::kTile;
+    F.t1 = (const uint8_t*)g.t1rule.p;
+    F.bits = d_bits;
+    F.kept = d_kept;
+    F.word_rank = d_rank;
+    F.tile_first = d_tile_first;
+    F.features = d_feat;
+    HIP_TRY(latok::launch_features_tiles(F, g.n_cu, st));
+    return LATOK_OK;
+}
+
 // shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
 static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
@@ -506,13 +526,10 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         // the scatter cannot overrun: the pinned item area holds one item per char, the most there can be
         int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
-        if (feats && (rc = g.tok_sid.ensure((size_t)total * 8))) return rc;
         HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total,
-                                           d_row, n_str, d_tile_first, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
-        if (feats)
-            HIP_TRY(latok::launch_token_features_n(d_items, d_total, total, (const int64_t*)g.tok_sid.p, d_row, d_cps,
-                                                   (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p,
-                                                   (const uint16_t*)g.cw.p, d_feat, st));
+                                           d_row, n_str, d_tile_first, d_items, nullptr, st));
+        if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
+            return rc;
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t n_small = *(const int64_t*)((char*)g.pin.h + po_n);
         *n_items_out = n_small;
@@ -542,13 +559,10 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
             d_feat = (int8_t*)g.h_aux.p;
         }
     }
-    if (feats && (rc = g.tok_sid.ensure((size_t)n_items * 8))) return rc;   // token -> string map between the two passes
     HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total, d_row,
-                                       n_str, d_tile_first, d_items, feats ? (int64_t*)g.tok_sid.p : nullptr, st));
-    if (feats)
-        HIP_TRY(latok::launch_token_features(d_items, n_items, (const int64_t*)g.tok_sid.p, d_row, d_cps,
-                                             (const uint8_t*)g.t1.p, (const uint8_t*)g.t2cls.p, (const uint16_t*)g.cw.p,
-                                             d_feat, st));
+                                       n_str, d_tile_first, d_items, nullptr, st));
+    if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
+        return rc;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
         if (feats) HIP_TRY(hipMemcpyAsync(features_out, d_feat, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));

@@ -103,67 +103,6 @@ hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t strid
     return hipGetLastError();
 }
 
-// ---- token feature vectors (featurize) --------------------------------------------------------------------------
-// The reference's per-token feature vector (featurize, default_tokenizer.py:163-191): the sum of the 25 matrix columns
-// over the UNSTRIPPED span between two boundaries, in uint8 wrap-around arithmetic like _combine_matrix_rows' 1-D
-// branch (latok.c:342-354).  Spans and owning strings come from compact_kernels.hip (k_word_scatter<2>).
-struct FeatTables {
-    const uint32_t* cps;
-    const uint8_t* t1;
-    const uint8_t* t2cls;
-    const uint16_t* cw;
-    int8_t* features;   // [n_tokens][25]
-    int64_t* tok_sid;   // [n_tokens] scratch: string id of every token (pass 1 -> pass 2)
-};
-
-// pass 2 of featurize: one thread per token sums the 25 feature bits of every char of the token's raw span
-__global__ void k_token_features(const int64_t* __restrict__ spans4, int64_t n_tok, const int64_t* __restrict__ n_tok_dev,
-                                 const int64_t* __restrict__ row_off, FeatTables F) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_tok_dev) n_tok = *n_tok_dev;   // count still on the device (small-batch path: no host round trip)
-    if (k >= n_tok) return;
-    const int64_t s = F.tok_sid[k];
-    const int64_t lo = row_off[s], hi = row_off[s + 1];
-    const int64_t from = lo + spans4[4 * k], to = lo + spans4[4 * k + 1];
-    uint8_t acc[25];
-#pragma unroll
-    for (int c = 0; c < 25; ++c) acc[c] = 0;
-    uint32_t p = from > lo ? base_word(F.t1, F.t2cls, F.cw, F.cps[from - 1]) : 0u;
-    uint32_t w = base_word(F.t1, F.t2cls, F.cw, F.cps[from]);
-    uint32_t x = from + 1 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[from + 1]) : 0u;
-    for (int64_t i = from; i < to; ++i) {
-        const uint32_t y = i + 2 < hi ? base_word(F.t1, F.t2cls, F.cw, F.cps[i + 2]) : 0u;
-        const uint32_t r = feature_row_bits(w, p, x, y, i == lo, i + 1 == hi);
-#pragma unroll
-        for (int c = 0; c < 25; ++c) acc[c] = (uint8_t)(acc[c] + ((r >> c) & 1u));
-        p = w; w = x; x = y;
-    }
-    int8_t* dst = F.features + k * 25;
-#pragma unroll
-    for (int c = 0; c < 25; ++c) dst[c] = (int8_t)acc[c];
-}
-
-hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
-                                 const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
-                                 int8_t* features, hipStream_t st) {
-    if (n_tok <= 0) return hipSuccess;
-    FeatTables F{cps, t1, t2cls, cw, features, const_cast<int64_t*>(tok_sid)};
-    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((n_tok + 255) / 256)), dim3(256), 0, st, spans4, n_tok,
-                       (const int64_t*)nullptr, row_off, F);
-    return hipGetLastError();
-}
-
-// same, with the token count read from device memory; the grid covers max_tok
-hipError_t launch_token_features_n(const int64_t* spans4, const int64_t* n_tok_dev, int64_t max_tok, const int64_t* tok_sid,
-                                   const int64_t* row_off, const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls,
-                                   const uint16_t* cw, int8_t* features, hipStream_t st) {
-    if (max_tok <= 0) return hipSuccess;
-    FeatTables F{cps, t1, t2cls, cw, features, const_cast<int64_t*>(tok_sid)};
-    hipLaunchKernelGGL(k_token_features, dim3((unsigned)((max_tok + 255) / 256)), dim3(256), 0, st, spans4, (int64_t)0,
-                       n_tok_dev, row_off, F);
-    return hipGetLastError();
-}
-
 // ---- device-wide exclusive scan of int64 counts: per-block scan + scan of the block totals + fix-up -----------------
 constexpr int kScanBlock = 1024;
 constexpr int kScanItems = 4;                       // elements per thread

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
                     rec[1] = e - lo;
                     rec[2] = a2 - lo;
                     rec[3] = e2 - lo;
-                    sidw[k - win0] = s;
+                    if (tok_sid) sidw[k - win0] = s;
                 }
             }
             ++k;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
             if (((n_val - head) & 1) && lane == 0)
                 __builtin_nontemporal_store((long long)win[n_val - 1], (long long*)dst + n_val - 1);
         }
-        if (KIND == 2)
+        if (KIND == 2 && tok_sid)
             for (int i = lane; i < n_here; i += 64) tok_sid[base_out + win0 + i] = sidw[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

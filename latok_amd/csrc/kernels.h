@@ -61,6 +61,20 @@ struct SplitParams {
 };
 
 
+// featurize on the tile grid (split_kernels.hip: k_features_tiles)
+struct FeatParams {
+    const uint32_t* cps;
+    const int64_t* row_off;
+    int64_t n_str, total, n_tiles;
+    const uint8_t* t1;            // [stage-1 | stage-2 rule codes], contiguous (global memory)
+    const uint64_t* bits;         // final boundary bitmask
+    const uint64_t* kept;         // boundaries whose token is kept (k_word_counts<true>)
+    const int64_t* word_rank;     // exclusive scan of popcount(kept): index of a word's first token
+    const int64_t* tile_first;    // per tile: first string that starts at or after its first char
+    int8_t* features;             // [n_tokens][25]
+};
+hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
+
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs);
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st);
@@ -82,12 +96,6 @@ hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, 
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
                                int64_t n_str, const int64_t* tile_first, int64_t* out, int64_t* tok_sid, hipStream_t st);
-hipError_t launch_token_features(const int64_t* spans4, int64_t n_tok, const int64_t* tok_sid, const int64_t* row_off,
-                                 const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
-                                 int8_t* features, hipStream_t st);
-hipError_t launch_token_features_n(const int64_t* spans4, const int64_t* n_tok_dev, int64_t max_tok, const int64_t* tok_sid,
-                                   const int64_t* row_off, const uint32_t* cps, const uint8_t* t1, const uint8_t* t2cls,
-                                   const uint16_t* cw, int8_t* features, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

@@ -834,6 +834,305 @@ hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// featurize: per-token sums of the 25 feature columns (reference default_tokenizer.py:163-191), one wave
+// per tile like the split kernel.  The tile's chars are classified into rule codes and bit-sliced exactly as above,
+// all 25 feature planes of a word are built in registers (lk_feature_planes), and the sum of column c over a token is
+// popcount(plane_c & token_span): the work per word is proportional to its tokens, not its chars, and the n x 25
+// matrix never exists.  A token that runs past its word takes the "head" sums (chars before the first boundary) of the
+// following words from the neighbour lanes; one that runs past the tile is finished char by char (rare).  The 25
+// bytes of a token are packed in 7 dwords (byte-wise wrap-around adds = the reference's uint8 arithmetic) and leave
+// through the wave's staging buffer as one contiguous stream.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t swar_add_u8(uint32_t a, uint32_t b) {
+    return ((a & 0x7F7F7F7Fu) + (b & 0x7F7F7F7Fu)) ^ ((a ^ b) & 0x80808080u);
+}
+struct FeatSums {
+    uint32_t v[7];   // byte c of the 28 = column c (bytes 25..27 unused)
+};
+__device__ __forceinline__ FeatSums feat_popc(const lk_planes& F, lk_u64 m) {
+    FeatSums r;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) r.v[j] = 0;
+#pragma unroll
+    for (int c = 0; c < LK_N_FEATURES; ++c)
+        r.v[c >> 2] |= (uint32_t)__popcll(LK_PLANE_GET(F, c) & m) << (8 * (c & 3));   // <= 64: no byte overflow
+    return r;
+}
+__device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint32_t x, uint32_t y, bool first, bool last) {
+    // 25 columns of one char from base words (aux_kernels.hip:feature_row_bits, same bit layout)
+    uint32_t r = w & 0xFFFu;
+    r |= ((p >> 0) & 1u) << 12; r |= ((x >> 0) & 1u) << 13; r |= ((p >> 1) & 1u) << 14; r |= ((x >> 1) & 1u) << 15;
+    r |= ((p >> 3) & 1u) << 16; r |= ((x >> 3) & 1u) << 17;
+    r |= (first ? 1u : (p >> 5) & 1u) << 18; r |= (last ? 1u : (x >> 5) & 1u) << 19;
+    r |= ((p >> 6) & 1u) << 20; r |= ((x >> 8) & 1u) << 21; r |= ((x >> 10) & 1u) << 22;
+    r |= ((y >> 0) & 1u) << 23; r |= ((y >> 10) & 1u) << 24;
+    return r;
+}
+
+// Lane = word while the sums are computed, but the output is token-major (all tokens of lane 0, then lane 1, ...), so
+// a tile's records have to meet in LDS before they can leave as a stream.  A window that only holds part of a tile
+// forces rounds in which most lanes idle (192-token rounds: 5x the instructions); writing the 25-byte records straight
+// to global memory costs +0.4 ms in scattered stores.  So this kernel trades waves for LDS: kFeatWaves waves per CU,
+// each with a window for kFeatRound tokens (a 4096-char tile of word-soup text has ~830), which doubles as the
+// code-byte staging buffer before the planes are built.
+constexpr int kFeatWaves = 4;
+constexpr int kFeatRound = 1024;
+constexpr int kFeatWaveLds = kFeatRound * 25 + 16 + 66 * 8;           // window | halo | string-start words
+constexpr int kFeatLdsTotal = kTablesLdsBytes + kFeatWaves * kFeatWaveLds;
+static_assert(kFeatRound * 25 >= kStageBytes, "the window doubles as the staging buffer");
+static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
+static_assert((kFeatRound * 25) % 16 == 0 && kFeatWaveLds % 16 == 0, "alignment");
+
+__device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds& L, int64_t t, int lane) {
+    const int64_t t0 = t * kTile;
+    const int64_t total = P.total;
+    const int64_t n_words = (total + 63) >> 6;
+    const int64_t w = t * 64 + lane;
+    const lk_u64 x = w < n_words ? P.kept[w] : 0ull;          // kept tokens that start in my word
+    const int cnt = lk_popc(x);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const int n_wave = __shfl(inc, 63);
+    if (n_wave == 0) return;
+    const int off = inc - cnt;
+    const int64_t base_out = lane_read64(w < n_words ? P.word_rank[w] : 0, 0);
+    const lk_u64 xb = w < n_words ? P.bits[w] : 0ull;         // all boundaries of my word
+
+    // ---- classify the tile into rule codes (mirror of process_tile phase 1) ---------------------------------------
+    const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);
+    int64_t idx0 = P.tile_first[t];
+    int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+    uint32_t halo_cp = 0xFFFFFFFFu;
+    if (lane < 3) {
+        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
+        if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
+    }
+    if (t0 + kTile <= total) {
+        u32x4 v[16];
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = classify4(L.t1, L.t2, v[i]);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int64_t p = t0 + 256 * i + 4 * lane;
+            u32x4 v;
+            v.x = p + 0 < total ? P.cps[p + 0] : 0xFFFFFFFFu;
+            v.y = p + 1 < total ? P.cps[p + 1] : 0xFFFFFFFFu;
+            v.z = p + 2 < total ? P.cps[p + 2] : 0xFFFFFFFFu;
+            v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = classify4(L.t1, L.t2, v);
+        }
+    }
+    if (lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
+    L.bw[lane] = 0;
+    if (lane < 2) L.bw[64 + lane] = 0;   // one word more than the split kernel: the first word of the next tile is needed
+    wave_lds_sync();
+    for (;;) {
+        const int64_t rel = ro - t0;
+        if (rel >= 0 && rel < kTile + 128) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
+        const int64_t last = lane_read64(ro, 63);
+        if (last >= t0 + kTile + 128) break;
+        idx0 += 64;
+        ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+    }
+    wave_lds_sync();
+
+    // ---- my word: the 25 planes ---------------------------------------------------------------------------------
+    const lk_u64 B = L.bw[lane];
+    const lk_u64 Bn = L.bw[lane + 1] & 3ull;
+    const int64_t base = t0 + 64 * (int64_t)lane;
+    const int64_t remain = total - base;
+    const lk_u64 valid = remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
+    lk_planes F;
+    {
+        uint32_t d[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 q = *reinterpret_cast<const uint4*>(L.stage + 80u * lane + 16u * k);
+            d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+        }
+        lk_halo h;
+        h.prev = lane > 0 ? L.stage[80u * lane - 17u] : L.halo[0];
+        h.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[1];
+        h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
+        lk_u64 plane[8];
+        lk_bitslice64(d, plane);
+        lk_feature_planes(plane, h, B, Bn, F);
+    }
+    const uint32_t prev65 = L.stage[80u * 63u + 63u];   // code of the tile's last char (stage_addr(4095))
+    wave_lds_sync();   // the staging buffer becomes the output window from here on
+
+    // ---- what a token that leaves my word collects from the following words -----------------------------------------
+    const lk_u64 head_mask = (xb ? ((xb & (~xb + 1ull)) - 1ull) : ~0ull) & valid;
+    const FeatSums H = feat_popc(F, head_mask);
+    const int full = xb == 0;
+    const int top = xb ? 63 - __builtin_clzll(xb) : 0;
+    const bool need_tail = xb != 0 && ((x >> top) & 1ull);     // my last boundary starts a kept token: it continues
+    FeatSums C;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) C.v[j] = 0;
+    bool open = need_tail;                                     // still collecting
+    for (int d = 1; d < 64; ++d) {
+        if (!__ballot(open && lane + d < 64)) break;
+        FeatSums Hs;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) Hs.v[j] = __shfl_down(H.v[j], d);
+        const int fs = __shfl_down(full, d);
+        if (open && lane + d < 64) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) C.v[j] = swar_add_u8(C.v[j], Hs.v[j]);
+            open = fs != 0;
+        }
+    }
+    if (__ballot(open)) {
+        // A token runs past the tile (the usual case for its last token): the whole wave builds the planes of the next
+        // tile's first word -- lane i classifies char t0 + 4096 + i, lanes 0..1 also the two chars after the word -- and
+        // the open lanes take its head sums.
+        const int64_t q0 = t0 + kTile;
+        const uint32_t c_me = q0 + lane < total ? classify1(L.t1, L.t2, P.cps[q0 + lane]) : 0u;
+        const uint32_t c_nx = (lane < 2 && q0 + 64 + lane < total) ? classify1(L.t1, L.t2, P.cps[q0 + 64 + lane]) : 0u;
+        uint32_t d65[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            d65[j] = (uint32_t)__shfl(c_me, 4 * j) | ((uint32_t)__shfl(c_me, 4 * j + 1) << 8) |
+                     ((uint32_t)__shfl(c_me, 4 * j + 2) << 16) | ((uint32_t)__shfl(c_me, 4 * j + 3) << 24);
+        lk_halo h65;
+        h65.prev = prev65;                         // code of the tile's last char
+        h65.next0 = (uint32_t)__shfl(c_nx, 0);
+        h65.next1 = (uint32_t)__shfl(c_nx, 1);
+        lk_u64 plane65[8];
+        lk_bitslice64(d65, plane65);
+        lk_planes F65;
+        const lk_u64 B65 = L.bw[64], Bn65 = L.bw[65] & 3ull;
+        lk_feature_planes(plane65, h65, B65, Bn65, F65);
+        const int64_t rem65 = total - q0;
+        const lk_u64 valid65 = rem65 >= 64 ? ~0ull : (rem65 <= 0 ? 0ull : ((1ull << rem65) - 1ull));
+        const lk_u64 xb65 = (q0 >> 6) < n_words ? P.bits[q0 >> 6] : 0ull;
+        const lk_u64 hm65 = (xb65 ? ((xb65 & (~xb65 + 1ull)) - 1ull) : ~0ull) & valid65;
+        const FeatSums H65 = feat_popc(F65, hm65);
+        if (open) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) C.v[j] = swar_add_u8(C.v[j], H65.v[j]);
+            open = xb65 == 0 && q0 + 64 < total;
+        }
+    }
+    if (open) {
+        // still open after the next tile's first word (a token of > 64 chars): finish it char by char from there
+        const int64_t from = t0 + kTile + 64;
+        if (from < total) {
+            int64_t e = from;   // next boundary at or after `from`
+            for (int64_t v = from >> 6; v < n_words; ++v) {
+                const lk_u64 b2 = P.bits[v];
+                if (b2) { e = (v << 6) + lk_ctz(b2); break; }
+                e = min((v + 1) << 6, total);
+            }
+            // the string that holds the token ends at the first row offset > from - 1 (tokens never cross strings)
+            int64_t lo_s = 0, hi_s = P.n_str;
+            while (hi_s - lo_s > 1) {
+                const int64_t mid = (lo_s + hi_s) >> 1;
+                if (P.row_off[mid] <= from - 1) lo_s = mid; else hi_s = mid;
+            }
+            const int64_t s_end = P.row_off[lo_s + 1];
+            uint32_t acc[25];
+#pragma unroll
+            for (int c = 0; c < 25; ++c) acc[c] = 0;
+            auto bw1 = [&](int64_t i) -> uint32_t { return i < s_end ? lk_base_word1(classify1(L.t1, L.t2, P.cps[i])) : 0u; };
+            uint32_t pw = lk_base_word1(classify1(L.t1, L.t2, P.cps[from - 1])), cw = bw1(from), nw = bw1(from + 1);
+            for (int64_t i = from; i < e; ++i) {
+                const uint32_t aw = bw1(i + 2);
+                const uint32_t r = feat_row_bits1(cw, pw, nw, aw, false, i + 1 == s_end);
+#pragma unroll
+                for (int c = 0; c < 25; ++c) acc[c] += (r >> c) & 1u;
+                pw = cw; cw = nw; nw = aw;
+            }
+#pragma unroll
+            for (int c = 0; c < 25; ++c) {
+                const uint32_t add = (acc[c] & 0xFFu) << (8 * (c & 3));
+                C.v[c >> 2] = swar_add_u8(C.v[c >> 2], add);
+            }
+        }
+    }
+
+    // ---- tokens of my word, round by round through the staging buffer -------------------------------------------------
+    uint8_t* win = L.stage;
+    lk_u64 rest = x;
+    int k = off;
+    for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
+        while (rest && k < win0 + kFeatRound) {
+            const int b = lk_ctz(rest);
+            rest &= rest - 1;
+            const lk_u64 above = xb & (~1ull << b);
+            lk_u64 seg = (~0ull << b) & valid;
+            if (above) seg &= (above & (~above + 1ull)) - 1ull;
+            FeatSums sum = feat_popc(F, seg);
+            if (!above) {
+#pragma unroll
+                for (int j = 0; j < 7; ++j) sum.v[j] = swar_add_u8(sum.v[j], C.v[j]);
+            }
+            uint8_t* rec = win + (k - win0) * 25;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) __builtin_memcpy(rec + 4 * j, &sum.v[j], 4);
+            rec[24] = (uint8_t)sum.v[6];
+            ++k;
+        }
+        wave_lds_sync();
+        const int n_bytes = min(kFeatRound, n_wave - win0) * 25;
+        uint8_t* dst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
+        const int head = (int)((4u - ((uintptr_t)dst & 3u)) & 3u);      // bytes up to the first aligned dword
+        const int hb = min(head, n_bytes);
+        if (lane < hb) dst[lane] = win[lane];
+        const int n_dw = (n_bytes - hb) >> 2;
+        for (int i = lane; i < n_dw; i += 64) {
+            uint32_t v;
+            __builtin_memcpy(&v, win + hb + 4 * i, 4);
+            *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
+        }
+        const int tail0 = hb + 4 * n_dw;
+        if (lane < n_bytes - tail0) dst[tail0 + lane] = win[tail0 + lane];
+        wave_lds_sync();
+    }
+}
+
+__global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kFeatLdsTotal];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {   // [stage-1 | stage-2 rule codes] -> LDS, same layout as the split kernel
+        constexpr int kVec = kTablesLdsBytes / 16;
+        const uint4* src = reinterpret_cast<const uint4*>(P.t1);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = tid; i < kVec; i += kFeatWaves * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    TileLds L;
+    L.t1 = lds;
+    L.t2 = lds + kStage1Pad;
+    uint8_t* mine = lds + kTablesLdsBytes + wave * kFeatWaveLds;
+    L.stage = mine;
+    L.halo = mine + kFeatRound * 25;
+    L.bw = reinterpret_cast<lk_u64*>(mine + kFeatRound * 25 + 16);
+    for (int64_t t = (int64_t)blockIdx.x * kFeatWaves + wave; t < P.n_tiles; t += (int64_t)gridDim.x * kFeatWaves)
+        feature_tile(P, L, t, lane);
+}
+
+hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st) {
+    if (P.n_tiles <= 0) return hipSuccess;
+    int64_t blocks = (P.n_tiles + kFeatWaves - 1) / kFeatWaves;
+    if (blocks > n_cu) blocks = n_cu;
+    hipLaunchKernelGGL(k_features_tiles, dim3((unsigned)blocks), dim3(kFeatWaves * 64), 0, st, P);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {

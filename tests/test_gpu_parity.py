@@ -531,3 +531,28 @@ def test_small_batch_path_thresholds(gpu, oracle):
             m = oracle.gen_parse_matrix(t)
             for tok in toks:
                 assert np.array_equal(tok.features, m[tok.start_idx:tok.end_idx].sum(axis=0, dtype=np.int8))
+
+
+def test_featurize_long_tokens_across_words_and_tiles(gpu, oracle):
+    """Token sums are popcounts of the feature planes per 64-char word; a token that leaves its word collects the
+    following words' head sums, one that leaves its 4096-char tile is finished char by char.  Masked URL / e-mail
+    blocks of 60 ... 10 000 chars placed so that they straddle word and tile boundaries, ASCII and non-ASCII, with the
+    uint8 wrap-around of sums beyond 255."""
+    from latok_amd import batch
+    rng = random.Random(99)
+    texts = []
+    for n in [60, 64, 65, 127, 128, 129, 200, 256, 300, 1000, 4090, 4096, 4100, 8192, 10000]:
+        for lead in [0, 1, 40, 63, 4000, 4095]:
+            body = "".join(rng.choice("abcXYZ9_/.:é日") for _ in range(n))
+            texts.append("x" * lead + " http://" + body + " end #tag a@" + body[:70] + ".org")
+    texts += ["a" * 5000, "a" * 4096 + " " + "b" * 4096, "@" + "q" * 9000, "é" * 700 + " " + "Ⅷ" * 300]
+    texts += random_strings(rng, 40, 3000, 9000, ALPHABETS["rare_space_at"])
+    got = batch.featurize_batch(texts)
+    for t, toks in zip(texts, got):
+        m = oracle.gen_parse_matrix(t).astype(np.uint8)
+        nz = oracle.split_offsets(t).tolist() + [len(t)]
+        want = [(a, b) for a, b in zip(nz[:-1], nz[1:]) if t[a:b].strip()]
+        assert [(x.start_idx, x.end_idx) for x in toks] == want, t[:60]
+        for tok, (a, b) in zip(toks, want):
+            f = m[a:b].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8)
+            assert np.array_equal(tok.features, f), (t[:40], a, b, tok.features, f)

@@ -10,6 +10,8 @@ Everything here is DATA: inputs and the outputs the reference itself produced fo
                              (its latok.c compiled into oracle/_ref + its own latok/core/*.py imported from /root/reference).
   * native_vectors.json   -- input/output vectors of the reference's _gen_block_mask and _combine_matrix_rows.
   * c1_paragraph.json     -- BASELINE config 1: one 1 KB ASCII paragraph with reference offsets / tokens.
+  * rules_strings.json    -- the reference's extension point: other C_SPLIT / C_MASK / C_SYM combo matrices installed as
+                             module globals of the REAL default_tokenizer, its own gen_split_mask run on sample strings.
   * corpus_samples.json   -- first 10 000 strings of the C2 / C3 synthetic corpora: SHA-256 of the code points, of the
                              offsets table and of the reference's boundary offsets, so a GPU box without the reference can
                              check generator + kernel end to end.
@@ -209,6 +211,31 @@ def golden_corpus(dt):
     dump("corpus_samples.json", out)
 
 
+def golden_rules(dt):
+    """Custom rule tables through the real reference: gen_split_mask reads the module globals C_SPLIT / C_MASK / C_SYM
+    (default_tokenizer.py:108-134), so installing other combo matrices there IS the reference's extension mechanism."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import RULE_SETS, random_rule_tables
+    rng = random.Random(424242)
+    sets = [(name, tabs) for name, tabs in RULE_SETS.items()] + [(f"random{i}", random_rule_tables(rng)) for i in range(6)]
+    texts = [t for t in sample_strings() if 0 < len(t) <= 140]
+    saved = (dt.C_SPLIT, dt.C_MASK, dt.C_SYM)
+    out = []
+    try:
+        for name, (c_split, c_mask, c_sym) in sets:
+            dt.C_SPLIT, dt.C_MASK, dt.C_SYM = (np.asarray(c_split, np.int8), np.asarray(c_mask, np.int8),
+                                               np.asarray(c_sym, np.int8))
+            items = []
+            for text in texts:
+                splits = dt.gen_split_mask(dt._gen_parse_matrix(text))
+                items.append({"cps": cps_of(text).tolist(), "splits": splits.astype(int).tolist()})
+            out.append({"name": name, "c_split": np.asarray(c_split).tolist(), "c_mask": np.asarray(c_mask).tolist(),
+                        "c_sym": np.asarray(c_sym).tolist(), "items": items})
+    finally:
+        dt.C_SPLIT, dt.C_MASK, dt.C_SYM = saved
+    dump("rules_strings.json", {"source": "real reference gen_split_mask with other combo matrices installed", "sets": out})
+
+
 def main():
     dt = ref_loader.load_ref_python()
     ext = ref_loader.load_ref_ext()
@@ -218,6 +245,7 @@ def main():
     golden_native(ext)
     golden_c1(dt)
     golden_corpus(dt)
+    golden_rules(dt)
 
 
 if __name__ == "__main__":

@@ -230,6 +230,21 @@ def test_golden_fixtures_on_gpu(gpu):
         assert ext._combine_matrix_rows(np.array(v["m"], np.int8), np.array(v["idx"], np.int8)).tolist() == v["out"]
 
 
+def test_golden_rule_tables_on_gpu(gpu):
+    """rules_strings.json: the REAL reference's gen_split_mask with other combo matrices installed; the fused kernel's
+    rule-table interpreter must reproduce its boundaries (no oracle involved)."""
+    from latok_amd import batch
+    try:
+        for rs in _golden("rules_strings.json")["sets"]:
+            batch.set_rules(np.array(rs["c_split"], np.int8), np.array(rs["c_mask"], np.int8), np.array(rs["c_sym"], np.int8))
+            texts = [_text_of(it["cps"]) for it in rs["items"]]
+            offs = batch.split_offsets_batch(texts)
+            for o, it in zip(offs, rs["items"]):
+                assert o.tolist() == np.nonzero(np.array(it["splits"]))[0].tolist(), rs["name"]
+    finally:
+        batch.reset_rules()
+
+
 def _device_corpus(lib, seed, model, n_str, lo, hi, sid0=0, prefix=None):
     """Generate a corpus on the device; optionally prepend one host-supplied string (shifts every tile boundary)."""
     from latok_amd import _lib

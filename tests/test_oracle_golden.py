@@ -143,3 +143,30 @@ print("ok")
 ''' % os.path.join(os.path.dirname(GOLDEN), "..", "oracle")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_reference_generated_rule_tables(oracle):
+    """Other C_SPLIT / C_MASK / C_SYM combo matrices: split values produced by the REAL reference's gen_split_mask with
+    those matrices installed (rules_strings.json) against the oracle's recipe, and the CPU model of the GPU's
+    rule-table interpreter on the non-zero pattern."""
+    import subprocess
+    from conftest import ROOT, pack, rule_row_sets
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fused"])
+    model = C.CDLL(os.path.join(ROOT, "oracle", "libfused_model.so"))
+    model.fused_split_batch_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+    sets = load("rules_strings.json")["sets"]
+    assert len(sets) >= 10
+    for rs in sets:
+        tables = (np.array(rs["c_split"], np.int8), np.array(rs["c_mask"], np.int8), np.array(rs["c_sym"], np.int8))
+        texts = [text_of(it["cps"]) for it in rs["items"]]
+        for text, it in zip(texts, rs["items"]):
+            assert oracle.split_values_rules(text, *tables).tolist() == it["splits"], (rs["name"], text)
+        rows, n_rows = rule_row_sets(tables)
+        cps, row = pack(texts)
+        bits = np.zeros((int(row[-1]) + 63) // 64, np.uint64)
+        assert model.fused_split_batch_rules(cps.ctypes.data, row.ctypes.data, len(texts), rows.ctypes.data,
+                                             n_rows.ctypes.data, bits.ctypes.data, None) == 0
+        want = np.concatenate([np.array(it["splits"]) != 0 for it in rs["items"]])
+        got = np.unpackbits(bits.view(np.uint8), bitorder="little")[:want.size].astype(bool)
+        assert np.array_equal(got, want), rs["name"]

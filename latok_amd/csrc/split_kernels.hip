@@ -145,75 +145,18 @@ struct TileLds {
 // idx0 = index of the first string that starts at or after the tile's first char.
 // With write_summary the tile summary is written to *summ_l (LDS copy of the segment).
 // Returns this lane's 64-bit boundary word (kModeBits); with DEFER the caller stores it later (write combining).
+// Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
+// words are in the wave's LDS buffer L.  (A separate function because a producer / consumer variant of the kernel ran
+// the two phases in different waves; see DESIGN.md, negative results.)
 template <int MODE, bool DEFER = false>
-__device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
-                                             int tail_zero, bool write_summary, int4* summ_l, int lane
+__device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
+                                            bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
-                                             , unsigned long long* stamp_acc = nullptr
+                                            , unsigned long long* stamp_acc, unsigned long long& stamp_prev
 #endif
-                                             ) {
-#ifdef LATOK_STAMPS
-    unsigned long long stamp_prev = 0, stamp_dummy[16];
-    if (!stamp_acc) stamp_acc = stamp_dummy;
-#endif
+                                            ) {
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
-    const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
-    LATOK_STAMP(0);
-
-    // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
-    // the next 64 strings and the three halo characters
-    int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
-    uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
-    if (MODE != kModeBlockMask && lane < 3) {
-        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
-        if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
-    }
-
-    // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
-    if (MODE == kModeBlockMask) {
-        // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
-    } else if (t0 + kTile <= total) {
-        u32x4 v[16];
-        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-        LATOK_STAMP(1);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t c = classify4(L.t1, L.t2, v[i]);
-            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
-        }
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < 16; ++i) {
-            const int64_t p = t0 + 256 * i + 4 * lane;
-            u32x4 v;
-            v.x = p + 0 < total ? P.cps[p + 0] : 0xFFFFFFFFu;   // out of range -> class 0 ("nothing")
-            v.y = p + 1 < total ? P.cps[p + 1] : 0xFFFFFFFFu;
-            v.z = p + 2 < total ? P.cps[p + 2] : 0xFFFFFFFFu;
-            v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
-            const uint32_t c = classify4(L.t1, L.t2, v);
-            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
-        }
-    }
-    // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
-    if (MODE != kModeBlockMask && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
-    L.bw[lane] = 0;
-    if (lane == 0) L.bw[64] = 0;
-    LATOK_STAMP(2);
-    wave_lds_sync();
-    for (;;) {
-        const int64_t rel = ro - t0;
-        if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
-        const int64_t last = lane_read64(ro, 63);
-        if (last >= t0 + kTile + 64) break;
-        idx0 += 64;
-        ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
-    }
-    wave_lds_sync();
-    LATOK_STAMP(3);
-
     // ---- phase 2: lane = one 64-char word ---------------------------------------------------------------------
     const lk_u64 B = L.bw[lane];
     const int64_t base = t0 + 64 * (int64_t)lane;
@@ -382,6 +325,82 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     return out_word;
 }
 
+template <int MODE, bool DEFER = false>
+__device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
+                                             int tail_zero, bool write_summary, int4* summ_l, int lane
+#ifdef LATOK_STAMPS
+                                             , unsigned long long* stamp_acc = nullptr
+#endif
+                                             ) {
+#ifdef LATOK_STAMPS
+    unsigned long long stamp_prev = 0, stamp_dummy[16];
+    if (!stamp_acc) stamp_acc = stamp_dummy;
+#endif
+    const int64_t t0 = t * kTile;
+    const int64_t total = P.total;
+    const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
+    LATOK_STAMP(0);
+
+    // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
+    // the next 64 strings and the three halo characters
+    int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+    uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
+    if (MODE != kModeBlockMask && lane < 3) {
+        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
+        if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
+    }
+
+    // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
+    if (MODE == kModeBlockMask) {
+        // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
+    } else if (t0 + kTile <= total) {
+        u32x4 v[16];
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        LATOK_STAMP(1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t c = classify4(L.t1, L.t2, v[i]);
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int64_t p = t0 + 256 * i + 4 * lane;
+            u32x4 v;
+            v.x = p + 0 < total ? P.cps[p + 0] : 0xFFFFFFFFu;   // out of range -> class 0 ("nothing")
+            v.y = p + 1 < total ? P.cps[p + 1] : 0xFFFFFFFFu;
+            v.z = p + 2 < total ? P.cps[p + 2] : 0xFFFFFFFFu;
+            v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
+            const uint32_t c = classify4(L.t1, L.t2, v);
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+        }
+    }
+    // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
+    if (MODE != kModeBlockMask && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
+    L.bw[lane] = 0;
+    if (lane == 0) L.bw[64] = 0;
+    LATOK_STAMP(2);
+    wave_lds_sync();
+    for (;;) {
+        const int64_t rel = ro - t0;
+        if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
+        const int64_t last = lane_read64(ro, 63);
+        if (last >= t0 + kTile + 64) break;
+        idx0 += 64;
+        ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+    }
+    wave_lds_sync();
+    LATOK_STAMP(3);
+
+    return tile_phase2<MODE, DEFER>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane
+#ifdef LATOK_STAMPS
+                                    , stamp_acc, stamp_prev
+#endif
+                                    );
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // stage 2: resolve, for every tile, (a) the number of pending starts entering it (forward scan of the tile transfer
 // functions) and (b) whether the block that is open at its end gets zeroed (needs the starts that follow before the
@@ -425,11 +444,14 @@ __device__ __forceinline__ Hd64 hd_identity() { Hd64 h; h.h = 0; h.c = 0; return
 // Ordered block-wide scans over kScanThreads elements (one per thread).  Returns, for this thread, the composition of
 // all EARLIER elements (fn: exclusive prefix) and of all LATER elements (hd: exclusive suffix); *tot_* get the
 // composition of the whole block.  Wave-level shuffles + 16 wave aggregates in LDS.
-struct ScanLds {
-    Fn64 fn_w[kScanWaves];
-    Hd64 hd_w[kScanWaves];
+template <int NW>
+struct ScanLdsT {
+    Fn64 fn_w[NW];
+    Hd64 hd_w[NW];
 };
-__device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLds& L, Fn64* excl_fn, Hd64* excl_hd, Fn64* tot_fn,
+typedef ScanLdsT<kScanWaves> ScanLds;
+template <int NW = kScanWaves>
+__device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLdsT<NW>& L, Fn64* excl_fn, Hd64* excl_hd, Fn64* tot_fn,
                                            Hd64* tot_hd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Fn64 fi = f;
@@ -450,21 +472,21 @@ __device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLds& L, Fn64* exc
     Hd64 eh; eh.h = __shfl_down(hi.h, 1); eh.c = __shfl_down(hi.c, 1);
     if (lane == 63) eh = hd_identity();
     // second level: every wave scans the 16 wave aggregates with shuffles (lanes 0..15), then picks its own entry
-    Fn64 wf = lane < kScanWaves ? L.fn_w[lane] : fn_identity();
-    Hd64 wh = lane < kScanWaves ? L.hd_w[lane] : hd_identity();
+    Fn64 wf = lane < NW ? L.fn_w[lane] : fn_identity();
+    Hd64 wh = lane < NW ? L.hd_w[lane] : hd_identity();
 #pragma unroll
-    for (int d = 1; d < kScanWaves; d <<= 1) {
+    for (int d = 1; d < NW; d <<= 1) {
         Fn64 o; o.a = __shfl_up(wf.a, d); o.b = __shfl_up(wf.b, d);
         if (lane >= d) wf = fn_then(o, wf);
         Hd64 oh; oh.h = __shfl_down(wh.h, d); oh.c = __shfl_down(wh.c, d);
-        if (lane + d < kScanWaves) wh = hd_then(wh, oh);
+        if (lane + d < NW) wh = hd_then(wh, oh);
     }
     // inclusive prefix of waves 0..lane in wf, inclusive suffix of waves lane..15 in wh
     Fn64 before; before.a = __shfl(wf.a, wave > 0 ? wave - 1 : 0); before.b = __shfl(wf.b, wave > 0 ? wave - 1 : 0);
     if (wave == 0) before = fn_identity();
-    Hd64 after; after.h = __shfl(wh.h, wave < kScanWaves - 1 ? wave + 1 : 0); after.c = __shfl(wh.c, wave < kScanWaves - 1 ? wave + 1 : 0);
-    if (wave == kScanWaves - 1) after = hd_identity();
-    Fn64 all_f; all_f.a = __shfl(wf.a, kScanWaves - 1); all_f.b = __shfl(wf.b, kScanWaves - 1);
+    Hd64 after; after.h = __shfl(wh.h, wave < NW - 1 ? wave + 1 : 0); after.c = __shfl(wh.c, wave < NW - 1 ? wave + 1 : 0);
+    if (wave == NW - 1) after = hd_identity();
+    Fn64 all_f; all_f.a = __shfl(wf.a, NW - 1); all_f.b = __shfl(wf.b, NW - 1);
     Hd64 all_h; all_h.h = __shfl(wh.h, 0); all_h.c = __shfl(wh.c, 0);
     *excl_fn = fn_then(before, ef);
     *excl_hd = hd_then(eh, after);

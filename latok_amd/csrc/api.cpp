@@ -111,7 +111,7 @@ struct Ctx {
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, scalar, h_aux, tile_first;
-    PinBuf pin;
+    PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 } g;
@@ -301,6 +301,7 @@ int latok_shutdown(void) {
     if (!g.inited) return LATOK_OK;
     (void)hipStreamSynchronize(g.stream);
     g.pin.release();
+    g.pin_tot.release();
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
@@ -417,10 +418,11 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
     int64_t* d_cnt = (int64_t*)g.u_cnt.p;
     int64_t* d_base = d_cnt + n_blocks;
     HIP_TRY(latok::launch_utf8_block_counts(d_u8, total_bytes, d_cnt, st));
-    HIP_TRY(latok::launch_exclusive_scan(d_cnt, n_blocks, d_base, (int64_t*)g.scalar.p, (int64_t*)g.scan_tot.p, st));
-    int64_t total_cps = 0;
-    HIP_TRY(hipMemcpyAsync(&total_cps, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
+    if ((rc = g.pin_tot.ensure(64))) return rc;
+    HIP_TRY(latok::launch_exclusive_scan(d_cnt, n_blocks, d_base, (int64_t*)g.scalar.p, (int64_t*)g.scan_tot.p, st,
+                                         (int64_t*)g.pin_tot.d));
     HIP_TRY(hipStreamSynchronize(st));
+    const int64_t total_cps = *(volatile const int64_t*)g.pin_tot.h;
     if ((rc = g.h_cps.ensure((size_t)total_cps * 4 + 16))) return rc;
     HIP_TRY(latok::launch_utf8_decode(d_u8, total_bytes, d_boff, n_str, d_base, (uint16_t*)g.u_pref.p, total_cps,
                                       (uint32_t*)g.h_cps.p, (int64_t*)g.u_row.p, st));
@@ -519,7 +521,9 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         return rc;
     HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
     int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
-    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, d_total, (int64_t*)g.scan_tot.p, st));
+    if ((rc = g.pin_tot.ensure(64))) return rc;
+    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, d_total, (int64_t*)g.scan_tot.p, st,
+                                         small ? nullptr : (int64_t*)g.pin_tot.d));
     int64_t* d_counts = dev ? counts_out : (small ? (int64_t*)((char*)g.pin.d + po_counts) : (int64_t*)g.counts.p);
     HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_row, n_str, total, d_total, d_counts, st));
     if (small) {
@@ -541,9 +545,8 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         if (feats) memcpy(features_out, (char*)g.pin.h + po_feat, (size_t)n_small * LATOK_FEATURE_COUNT);
         return LATOK_OK;
     }
-    int64_t n_items = 0;
-    HIP_TRY(hipMemcpyAsync(&n_items, g.scalar.p, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int64_t n_items = *(volatile const int64_t*)g.pin_tot.h;
     *n_items_out = n_items;
     if (!dev) HIP_TRY(hipMemcpy(counts_out, g.counts.p, (size_t)n_str * 8, hipMemcpyDeviceToHost));
     if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_local(const int64_t* __rest
 
 // exclusive scan of the block totals by one block (in place), grand total -> *total
 __global__ __launch_bounds__(kScanBlock) void k_scan_totals(int64_t* __restrict__ block_tot, int64_t n_blocks,
-                                                            int64_t* __restrict__ total) {
+                                                            int64_t* __restrict__ total, int64_t* __restrict__ total_host) {
     __shared__ long long lds[kScanBlock / 64];
     const int64_t per = (n_blocks + kScanBlock - 1) / kScanBlock;
     const int64_t lo = min((int64_t)threadIdx.x * per, n_blocks), hi = min(lo + per, n_blocks);
@@ -166,7 +166,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_totals(int64_t* __restrict_
         block_tot[i] = run;
         run += v;
     }
-    if (threadIdx.x == 0) *total = tot;
+    if (threadIdx.x == 0) {
+        *total = tot;
+        if (total_host) *total_host = tot;   // pinned, device-mapped: the host reads it after the stream drains, no copy
+    }
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ out, int64_t n,
@@ -179,10 +182,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ o
 }
 
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
-                                 hipStream_t st) {
+                                 hipStream_t st, int64_t* total_host) {
     const int64_t n_blocks = scan_blocks(n);
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, in, n, out, block_tot);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, st, block_tot, n_blocks, total);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, st, block_tot, n_blocks, total, total_host);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, out, n, block_tot);
     return hipGetLastError();
 }

@@ -87,7 +87,7 @@ hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t strid
                                int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
 int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_tot`
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
-                                 hipStream_t st);
+                                 hipStream_t st, int64_t* total_host = nullptr);
 // compact_kernels.hip: word-parallel compaction (offsets / token spans / featurize spans)
 hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
                               uint64_t* kept, int64_t* cnt, hipStream_t st);

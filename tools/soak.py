@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised differential soak of the HIP path against the oracle (test infrastructure; not part of pytest).
+
+Worker processes build random batches from adversarial alphabets in several shape regimes (many tiny strings, tweets,
+multi-tile documents, no-whitespace documents with starts, dense starts) and compute the oracle's split values / bitmask on
+the CPU; the main process runs the same batch through the C ABI (values, bitmask, offsets, token spans, and the bitmask
+under run-time rule tables) and compares bit for bit.  Stops after --seconds.
+
+usage: tools/soak.py [--seconds 120] [--workers 12] [--seed 1]
+"""
+import argparse
+import multiprocessing as mp
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+REGIMES = [
+    # (alphabet, n_strings range, length range)
+    ("mixed", (1, 3000), (0, 12)), ("mixed", (1, 400), (0, 200)), ("words", (1, 300), (0, 400)),
+    ("starts", (1, 200), (0, 600)), ("mixed", (1, 4), (3000, 30000)), ("nospace_at", (1, 4), (4000, 40000)),
+    ("rare_space_at", (1, 4), (4000, 40000)), ("starts", (500, 4000), (1, 3)), ("words", (1, 6), (8000, 20000)),
+]
+
+
+def make_batch(seed):
+    import latok_oracle as orc
+    from conftest import ALPHABETS, DEFAULT_RULES, RULE_SETS, pack, random_rule_tables, random_strings
+    rng = random.Random(seed)
+    kind, (n_lo, n_hi), (l_lo, l_hi) = rng.choice(REGIMES)
+    texts = random_strings(rng, rng.randint(n_lo, n_hi), l_lo, l_hi, ALPHABETS[kind])
+    if rng.random() < 0.3:   # shift every tile boundary by an odd prefix
+        texts.insert(0, "x" * rng.randint(1, 5000))
+    cps, row = pack(texts)
+    vals, bits = orc.split_batch(cps, row)
+    # space flags for the span check
+    uniq, inv = np.unique(cps, return_inverse=True)
+    space = np.array([(orc.base_word(int(c)) >> 5) & 1 for c in uniq], bool)[inv] if cps.size else np.zeros(0, bool)
+    rules = None
+    rule_bits = None
+    if rng.random() < 0.25 and cps.size < 60000:
+        name = rng.choice(sorted(RULE_SETS) + ["random"])
+        rules = random_rule_tables(rng) if name == "random" else RULE_SETS[name]
+        flags = np.zeros(cps.size, bool)
+        k = 0
+        for t in texts:
+            if len(t):
+                flags[k:k + len(t)] = orc.split_values_rules(t, *rules) != 0
+            k += len(t)
+        rule_bits = np.packbits(np.concatenate([flags, np.zeros((-cps.size) % 64, bool)]), bitorder="little").view(np.uint64)
+    return seed, kind, cps, row, vals, bits, space, rules, rule_bits
+
+
+def spans_from(vals, space, row):
+    """reference tokenize() slicing on arrays: spans between consecutive boundaries, stripped, empty dropped"""
+    out, counts = [], []
+    for s in range(len(row) - 1):
+        a, b = int(row[s]), int(row[s + 1])
+        nz = np.nonzero(vals[a:b])[0].tolist() + [b - a]
+        c = 0
+        for p, e in zip(nz[:-1], nz[1:]):
+            seg = ~space[a + p:a + e]
+            if seg.any():
+                idx = np.nonzero(seg)[0]
+                out.append((p + int(idx[0]), p + int(idx[-1]) + 1))
+                c += 1
+        counts.append(c)
+    return np.array(counts, np.int64), np.array(out, np.int64).reshape(-1, 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--workers", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    from latok_amd import batch
+    t_end = time.time() + args.seconds
+    n_batches = n_chars = n_rules = n_spans = 0
+    seed = args.seed * 1_000_003
+    last = time.time()
+    with mp.Pool(args.workers) as pool:
+        pending = [pool.apply_async(make_batch, (seed + i,)) for i in range(args.workers * 2)]
+        seed += len(pending)
+        while pending:
+            sd, kind, cps, row, vals, bits, space, rules, rule_bits = pending.pop(0).get()
+            if time.time() < t_end:
+                pending.append(pool.apply_async(make_batch, (seed,)))
+                seed += 1
+            tag = f"seed {sd} kind {kind} n_str {len(row) - 1} chars {cps.size}"
+            gv = batch.split_values_batch(cps, row)
+            assert np.array_equal(gv, vals), "values differ: " + tag
+            gb = batch.split_mask_batch(cps, row)
+            assert np.array_equal(gb, bits), "bitmask differs: " + tag
+            counts, offs = batch.split_offsets_csr(cps, row)
+            exp = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(row) - 1)]
+            assert np.array_equal(counts, [len(e) for e in exp]), "offset counts differ: " + tag
+            assert np.array_equal(offs, np.concatenate(exp) if exp else np.zeros(0, np.int64)), "offsets differ: " + tag
+            if cps.size < 20000:
+                wc, ws = spans_from(vals, space, row)
+                gc, gs = batch.token_spans_csr(cps, row)
+                assert np.array_equal(gc, wc) and np.array_equal(gs, ws), "token spans differ: " + tag
+                n_spans += 1
+            if rules is not None:
+                batch.set_rules(*rules)
+                try:
+                    rb = batch.split_mask_batch(cps, row)
+                finally:
+                    batch.reset_rules()
+                assert np.array_equal(rb, rule_bits), "rule-table bitmask differs: " + tag
+                n_rules += 1
+            n_batches += 1
+            n_chars += cps.size
+            if time.time() - last > 30:
+                last = time.time()
+                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks ... ok",
+                      flush=True)
+    print(f"soak passed: {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
+          f"{args.seconds:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

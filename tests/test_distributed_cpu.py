@@ -40,6 +40,18 @@ def _worker(rank, world, port, q):
         total_chars = bench.reduce_sum_int(dist, int(row[-1]))
         total_bound = bench.reduce_sum_int(dist, int(np.count_nonzero(vals)))
         slowest = bench.reduce_max_seconds(dist, 0.25 * (rank + 1))
+        # product sharding helper: rank r tokenizes its char-balanced slice of one common batch; the shards' boundary
+        # counts add up to the whole batch's (no exchange on the data path, only this reduction for the check)
+        from latok_amd import shard
+        m_row = np.zeros(801, np.int64)
+        lib.latok_corpus_offsets(seed, 0, 800, lo, hi, m_row.ctypes.data)
+        m_cps = np.zeros(int(m_row[-1]), np.uint32)
+        lib.latok_corpus_fill_host(seed, model, 0, 800, m_row.ctypes.data, m_cps.ctypes.data)
+        c_r, row_r, _ = shard.take_shard(m_cps, m_row, rank, world)
+        v_r, _ = orc.split_batch(np.ascontiguousarray(c_r), np.ascontiguousarray(row_r), want_bits=False)
+        shard_bound = bench.reduce_sum_int(dist, int(np.count_nonzero(v_r)))
+        whole_bound = int(np.count_nonzero(orc.split_batch(m_cps, m_row, want_bits=False)[0]))
+        assert shard_bound == whole_bound, (shard_bound, whole_bound)
         dist.barrier()
         q.put((rank, sid0, int(row[-1]), total_chars, total_bound, slowest, cps[:8].tolist()))
     finally:

@@ -138,3 +138,24 @@ def test_install_as_latok_aliases_reference_import_names():
             "import latok_amd.core.default_tokenizer as d; assert tokenize is d.tokenize and oft.FEATURE_COUNT == 25; print('ok')") % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+def test_shard_bounds_balance_and_cover():
+    """latok_amd.shard: contiguous string ranges balanced by chars; shards concatenate back to the batch."""
+    import random
+    from latok_amd import shard
+    rng = random.Random(3)
+    for n_str, world in [(1, 1), (1, 8), (7, 8), (1000, 8), (1000, 3), (50, 2), (0, 4)]:
+        lens = np.array([rng.choice([0, 1, 5, 128, 4000, 100000]) for _ in range(n_str)], np.int64)
+        row = np.zeros(n_str + 1, np.int64)
+        np.cumsum(lens, out=row[1:])
+        cps = np.arange(int(row[-1]), dtype=np.uint32)
+        b = shard.shard_bounds(row, world)
+        assert b[0] == 0 and b[-1] == n_str and len(b) == world + 1 and np.all(np.diff(b) >= 0)
+        parts = [shard.take_shard(cps, row, r, world) for r in range(world)]
+        assert np.array_equal(np.concatenate([p[0] for p in parts]) if parts else cps, cps)
+        for (c, ro, s0), r in zip(parts, range(world)):
+            assert ro[0] == 0 and ro[-1] == c.size and s0 == b[r]
+        if n_str >= 8 * world and row[-1] > 0:
+            sizes = np.array([p[0].size for p in parts])
+            assert sizes.max() - sizes.min() <= 2 * lens.max()      # balanced up to one string per cut

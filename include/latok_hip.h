@@ -105,6 +105,26 @@ int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, i
                                  int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                                  int flags, void* stream);
 
+/* ---- UTF-8 in BYTE space (fused ingest) -----------------------------------------------------------------------------
+ * Same tokenization, but nothing is decoded to UTF-32: the tile kernel reads the UTF-8 bytes themselves (1 byte per
+ * ASCII char from HBM instead of 4) and every position it reports is a BYTE position in the caller's buffer:
+ *   mask     bit i = byte i of the packed buffer; set at the LEAD byte of every char the reference marks as a boundary
+ *            (np.nonzero(gen_split_mask(...)), default_tokenizer.py:148), mapped from code-point to byte positions
+ *   offsets  byte offsets relative to the start of each string
+ *   spans    [start, end) byte ranges of the stripped, non-empty tokens: utf8[byte_off[s] + start : byte_off[s] + end]
+ *            is the UTF-8 encoding of the token the reference yields
+ * Input must be valid UTF-8 ("surrogatepass" forms are accepted as they decode); a truncated sequence counts as
+ * U+FFFD, stray continuation bytes belong to no char.  With LATOK_DEVICE_PTRS the byte buffer must be 16-byte aligned.
+ * Run-time rule tables (latok_set_rules) are not available in byte space. */
+int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                      uint64_t* mask_bits_out, int flags, void* stream);
+int latok_split_offsets_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                         int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
+                                         int64_t* n_offsets_out, int flags, void* stream);
+int latok_token_spans_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                       int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                       int flags, void* stream);
+
 /* Token feature vectors: reference featurize() (default_tokenizer.py:163-191) for a whole batch without the n x 25
  * matrix.  Per kept token k: spans4_out[4k..4k+3] = {raw_start, raw_end, strip_start, strip_end} (LaToken.start_idx /
  * end_idx are the raw span, LaToken.text is text[strip_start:strip_end]); features_out[25k..25k+24] = sum of the 25

@@ -198,6 +198,60 @@ def token_spans_utf8_csr(utf8, byte_off):
     return counts, spans[:n_tok.value].copy()
 
 
+# byte-space forms: the tile kernel reads the UTF-8 bytes itself; every position is a BYTE position in `utf8`
+def split_mask_utf8_bytes_csr(utf8, byte_off) -> np.ndarray:
+    """uint64 bitmask over the BYTES of the batch: bit i set = byte i is the lead byte of a boundary char."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    bits = np.zeros((total + 63) // 64, np.uint64)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_mask_utf8_bytes_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(bits), 0, None))
+    return bits
+
+
+def split_offsets_utf8_bytes_csr(utf8, byte_off):
+    """(counts, offsets): boundary BYTE offsets relative to each string's first byte."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    offsets = np.empty(max(total, 1), np.int64)
+    n_off = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_offsets_utf8_bytes_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts),
+                                                        _ptr(offsets), offsets.size, C.byref(n_off), 0, None))
+    return counts, offsets[:n_off.value].copy()
+
+
+def token_spans_utf8_bytes_csr(utf8, byte_off):
+    """(counts, spans[n_tokens, 2]): [start, end) BYTE ranges of the stripped, non-empty tokens of each string."""
+    utf8, byte_off = _csr_u8(utf8, byte_off)
+    n_str = byte_off.size - 1
+    total = int(byte_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    spans = np.empty((max(total, 1), 2), np.int64)
+    n_tok = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_token_spans_utf8_bytes_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(spans),
+                                                      spans.shape[0], C.byref(n_tok), 0, None))
+    return counts, spans[:n_tok.value].copy()
+
+
+def tokenize_utf8_batch(blobs):
+    """list[bytes] (UTF-8) -> list[list[bytes]]: the reference's tokens of every string, as UTF-8 slices of the input
+    (byte-space path: nothing is transcoded on the host or on the device)."""
+    if len(blobs) == 0:
+        return []
+    utf8, byte_off = pack_utf8(blobs)
+    counts, spans = token_spans_utf8_bytes_csr(utf8, byte_off)
+    out, k = [], 0
+    for blob, n in zip(blobs, counts.tolist()):
+        out.append([blob[a:b] for a, b in spans[k:k + n].tolist()])
+        k += n
+    return out
+
+
 def spans_from_offsets(text, nz):
     """Token strings of one text from its boundary offsets, as the reference's loop builds them
     (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""

@@ -134,8 +134,15 @@ int need_init() {
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
-                 const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr) {
+                 const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
+                 const uint8_t* d_u8 = nullptr) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
+    if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes
+        if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
+        if (g.rules_on) return fail(LATOK_ERR_INVALID, "run-time rule tables are not available in byte space; use the code-point UTF-8 entry points");
+        if (((uintptr_t)d_u8 & 15) != 0) return fail(LATOK_ERR_INVALID, "device UTF-8 pointer must be 16-byte aligned");
+        mode = latok::kModeBytes;
+    }
     if (g.rules_on) {
         if (mode == latok::kModeValues)
             return fail(LATOK_ERR_INVALID, "split VALUES are defined for the built-in rule tables only; call latok_reset_rules()");
@@ -146,6 +153,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     if (rc) return rc;
     latok::SplitParams P;
     P.cps = d_cps;
+    P.u8 = d_u8;
     P.row_off = d_row;
     P.n_str = n_str;
     P.total = total;
@@ -389,10 +397,18 @@ int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_
 
 // UTF-8 ingest: decode a CSR batch of UTF-8 strings into the library's device buffers (g.h_cps = packed code points,
 // g.u_row = code-point row offsets).  Inputs are host or device pointers per `dev`.  One blocking 8-byte read.
+// With `bytes_route`: when the batch has no continuation byte at all (pure ASCII, the common case) byte positions ARE
+// code-point positions, so nothing is decoded; *bytes_route = the device pointers for the byte-space tile kernel, whose
+// results are then valid in code-point units as they are.
+struct BytesRoute {
+    const uint8_t* d_u8 = nullptr;
+    const int64_t* d_boff = nullptr;
+};
 static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
-                                    bool dev, hipStream_t st, int64_t* total_cps_out) {
+                                    bool dev, hipStream_t st, int64_t* total_cps_out, BytesRoute* bytes_route = nullptr) {
     int rc;
     *total_cps_out = 0;
+    if (bytes_route) *bytes_route = BytesRoute();
     const uint8_t* d_u8 = u8;
     const int64_t* d_boff = byte_off;
     if (dev) {
@@ -423,6 +439,12 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
                                          (int64_t*)g.pin_tot.d));
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t total_cps = *(volatile const int64_t*)g.pin_tot.h;
+    if (bytes_route && total_cps == total_bytes && ((uintptr_t)d_u8 & 15) == 0 && !g.rules_on) {
+        bytes_route->d_u8 = d_u8;
+        bytes_route->d_boff = d_boff;
+        *total_cps_out = total_cps;
+        return LATOK_OK;
+    }
     if ((rc = g.h_cps.ensure((size_t)total_cps * 4 + 16))) return rc;
     HIP_TRY(latok::launch_utf8_decode(d_u8, total_bytes, d_boff, n_str, d_base, (uint16_t*)g.u_pref.p, total_cps,
                                       (uint32_t*)g.h_cps.p, (int64_t*)g.u_row.p, st));
@@ -453,7 +475,8 @@ static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t
 // shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
 static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
-                          void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr) {
+                          void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
+                          bool byte_space = false) {
     const bool feats = features_out != nullptr;
     int rc = need_init();
     if (rc) return rc;
@@ -463,10 +486,34 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
-    if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
-        if ((rc = decode_utf8_to_workspace(utf8, row_off, n_str, total, dev, st, &total))) return rc;
-        d_cps = (const uint32_t*)g.h_cps.p;
-        d_row = (const int64_t*)g.u_row.p;
+    const uint8_t* d_u8 = nullptr;   // byte space: the tile kernel reads the UTF-8 bytes itself, results are byte offsets
+    if (utf8 && byte_space) {
+        if (dev) {
+            if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
+            d_u8 = utf8;
+        } else {
+            if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
+            if (n_str > 0) {
+                if ((rc = g.u_bytes.ensure((size_t)total + 16))) return rc;
+                if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+                if (total > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(g.u_boff.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+                d_u8 = (const uint8_t*)g.u_bytes.p;
+                d_row = (const int64_t*)g.u_boff.p;
+            }
+        }
+        d_cps = nullptr;
+    } else if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
+        BytesRoute br;
+        if ((rc = decode_utf8_to_workspace(utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
+        if (br.d_u8) {   // no multi-byte char in the batch: byte space == code-point space, skip the decode
+            d_u8 = br.d_u8;
+            d_row = br.d_boff;
+            d_cps = nullptr;
+        } else {
+            d_cps = (const uint32_t*)g.h_cps.p;
+            d_row = (const int64_t*)g.u_row.p;
+        }
     } else if (dev) {
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
         if (total > 0 && ((uintptr_t)cps & 15) != 0)
@@ -517,7 +564,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
     int64_t* d_tile_first = (int64_t*)g.tile_first.p;
     if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first)))
+                           nullptr, nullptr, d_space, d_tile_first, d_u8)))
         return rc;
     HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
     int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
@@ -621,7 +668,8 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
     hipStream_t st = stream ? (hipStream_t)stream : g.stream;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total = 0;
-    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total))) return rc;
+    BytesRoute br;
+    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total, &br))) return rc;
     *total_cps_out = total;
     if (n_str == 0) return LATOK_OK;
     const int64_t words = (total + 63) / 64;
@@ -632,12 +680,18 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
         if ((rc = g.h_out.ensure((size_t)words * 8 + 8))) return rc;
         d_bits = (uint64_t*)g.h_out.p;
     }
-    if ((rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.u_row.p, n_str, total, d_bits, nullptr,
-                           latok::kModeBits, st)))
+    if (br.d_u8) {   // no multi-byte char: the byte-space kernel on the bytes, code-point offsets = byte offsets
+        if ((rc = run_pipeline(nullptr, br.d_boff, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, br.d_u8)))
+            return rc;
+    } else if ((rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.u_row.p, n_str, total, d_bits, nullptr,
+                                  latok::kModeBits, st))) {
         return rc;
+    }
     const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (!dev && words > 0) HIP_TRY(hipMemcpyAsync(mask_bits_out, d_bits, (size_t)words * 8, kind, st));
-    HIP_TRY(hipMemcpyAsync(cp_row_off_out, g.u_row.p, (size_t)(n_str + 1) * 8, kind, st));
+    HIP_TRY(hipMemcpyAsync(cp_row_off_out, br.d_u8 ? (const void*)br.d_boff : (const void*)g.u_row.p, (size_t)(n_str + 1) * 8,
+                           kind, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LATOK_OK;
 }
@@ -658,6 +712,56 @@ int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, i
     static const uint8_t empty = 0;
     return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
                           flags, stream, nullptr, utf8 ? utf8 : &empty);
+}
+
+/* byte-space UTF-8 entry points: the tile kernel reads the bytes (1 B/char for ASCII), all positions are byte offsets */
+int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                      uint64_t* mask_bits_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = need_init();
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    if (flags & LATOK_DEVICE_PTRS) {
+        if ((rc = resolve_total_device(byte_off, n_str, &total_bytes, st))) return rc;
+        if (total_bytes == 0) return LATOK_OK;
+        if (!utf8 || !mask_bits_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+        return run_pipeline(nullptr, byte_off, n_str, total_bytes, mask_bits_out, nullptr, latok::kModeBits, st, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, utf8);
+    }
+    if ((rc = check_csr_host(byte_off, n_str, &total_bytes))) return rc;
+    if (total_bytes == 0) return LATOK_OK;
+    if (!utf8 || !mask_bits_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    const size_t out_bytes = (size_t)((total_bytes + 63) / 64) * 8;
+    if ((rc = g.u_bytes.ensure((size_t)total_bytes + 16))) return rc;
+    if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+    if ((rc = g.h_out.ensure(out_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+    if ((rc = run_pipeline(nullptr, (const int64_t*)g.u_boff.p, n_str, total_bytes, (uint64_t*)g.h_out.p, nullptr,
+                           latok::kModeBits, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           (const uint8_t*)g.u_bytes.p)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(mask_bits_out, g.h_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LATOK_OK;
+}
+
+int latok_split_offsets_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                         int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
+                                         int64_t* n_offsets_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    static const uint8_t empty = 0;
+    return compact_common(false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
+                          n_offsets_out, flags, stream, nullptr, utf8 ? utf8 : &empty, true);
+}
+
+int latok_token_spans_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+                                       int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                       int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    static const uint8_t empty = 0;
+    return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
+                          flags, stream, nullptr, utf8 ? utf8 : &empty, true);
 }
 
 int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,

@@ -9,6 +9,7 @@
 
 #include "corpus_gen.h"
 #include "kernels.h"
+#include "utf8_decode.h"
 
 namespace latok {
 
@@ -220,12 +221,6 @@ __device__ __forceinline__ uint4 utf8_load16(const uint8_t* __restrict__ u8, int
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
 }
-// bit i of the result = byte i of the dword is a lead byte ((b & 0xC0) != 0x80)
-__device__ __forceinline__ uint32_t utf8_lead_nibble(uint32_t w) {
-    const uint32_t cont = (w & 0x80808080u) & ~((w << 1) & 0x80808080u);   // top bits "10"
-    const uint32_t lead = (~cont) & 0x80808080u;
-    return (((lead >> 7) * 0x00204081u) >> 21) & 0xFu;
-}
 __device__ __forceinline__ uint32_t utf8_lead_mask16(uint4 v) {
     return utf8_lead_nibble(v.x) | (utf8_lead_nibble(v.y) << 4) | (utf8_lead_nibble(v.z) << 8) | (utf8_lead_nibble(v.w) << 12);
 }
@@ -259,28 +254,6 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_block_counts(const uint8_t*
     int tot;
     (void)block_exclusive_scan_int(c, &tot, lds);
     if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
-}
-
-// decode the sequence whose lead byte is byte I of the 19 bytes {w0..w3, 3 bytes of w4}; all indices are static
-template <int I>
-__device__ __forceinline__ uint32_t utf8_decode_at(const uint32_t (&w)[5]) {
-    auto byte_at = [&](int j) -> uint32_t { return (w[j >> 2] >> (8 * (j & 3))) & 0xFFu; };
-    const uint32_t b0 = byte_at(I);
-    if (b0 < 0x80u) return b0;
-    uint32_t cp = b0;
-    int extra = 0;
-    if (b0 >= 0xF0u) { cp = b0 & 0x07u; extra = 3; }
-    else if (b0 >= 0xE0u) { cp = b0 & 0x0Fu; extra = 2; }
-    else if (b0 >= 0xC0u) { cp = b0 & 0x1Fu; extra = 1; }
-#pragma unroll
-    for (int j = 1; j <= 3; ++j) {
-        if (j <= extra) {
-            const uint32_t b = byte_at(I + j);
-            if ((b & 0xC0u) == 0x80u) cp = (cp << 6) | (b & 0x3Fu);
-            else { cp = 0xFFFDu; extra = 0; }                          // truncated sequence
-        }
-    }
-    return cp;
 }
 
 // The block's code points are collected in LDS at their rank inside the block and then streamed out, so that the 4

@@ -22,7 +22,9 @@ constexpr int kModeBits = 0;
 constexpr int kModeValues = 1;
 constexpr int kModeBlockMask = 2;        // compat _gen_block_mask: planes from caller byte arrays, byte mask out
 constexpr int kModeRules = 3;            // kModeBits with caller-supplied C_SPLIT / C_MASK / C_SYM (SplitParams::rules)
-constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules; }
+constexpr int kModeBytes = 4;            // kModeBits in BYTE space: input = UTF-8 bytes (SplitParams::u8), row_off = byte
+                                         // offsets, bit i of the mask = byte i (set at the lead byte of a boundary char)
+constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules || mode == kModeBytes; }
 
 constexpr long long kNegInf64 = -(1ll << 60);
 constexpr int kWPB = 12;                 // waves per workgroup: 768 threads -> 168 VGPRs per lane, one workgroup per CU
@@ -38,6 +40,7 @@ struct Hd64 {        // head descriptor of a run of tiles: starts before its fir
 
 struct SplitParams {
     const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
+    const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); cps is unused
     const int64_t* row_off;     // [n_str + 1]
     int64_t n_str, total, n_tiles;
     int seg_tiles;              // tiles per segment (16..1024)

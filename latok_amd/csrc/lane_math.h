@@ -197,6 +197,87 @@ LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// UTF-8 in byte space (fused UTF-8 ingest).  Positions are BYTES: a char lives at its lead byte; its continuation
+// bytes carry the same ("smeared") code in the code planes and are marked in the plane C.  String starts, boundaries
+// and the block mask are all expressed at lead-byte positions, so the rest of the pipeline is unchanged and the
+// results are byte offsets into the UTF-8 buffer.  What changes is "the next char": it is no longer one position away.
+//   PREV_X[i]  = X of the char that owns byte i-1            -> one shift of the smeared planes, as before
+//   NL(X)[j]   = X at the first lead byte at or after j (a char has <= 3 continuation bytes)
+//   NEXT_X[i]  = NL(X)[i+1],  AFTER_NEXT_X[i] = NL(NEXT_X at leads)[i+1]
+//   E[i]       = lead i whose next lead starts a string (or is the end sentinel); E2 = E or "next lead is in E"
+// For a word without continuation bytes every NL is the identity and the formulas collapse to lk_rules.
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_halo_bytes {
+    uint32_t prev;         // smeared code of byte base-1 (0 when it does not exist)
+    lk_u64 next_codes;     // smeared codes of bytes base+64 .. base+71 (byte k of the word = byte base+64+k)
+    uint32_t next_cont;    // bit k: byte base+64+k is a continuation byte
+    uint32_t next_B;       // bit k: a string starts at byte base+64+k (k = 0..15)
+};
+
+// NL over one word: m0 = C, m1 = C & C>>1, m2 = m1 & C>>2 (shifts pulling from the next word); Xn = X of the next word
+LATOK_HD lk_u64 lk_nl(lk_u64 X, lk_u64 Xn, lk_u64 m0, lk_u64 m1, lk_u64 m2) {
+    return X | (m0 & ((X >> 1) | (Xn << 63))) | (m1 & ((X >> 2) | (Xn << 62))) | (m2 & ((X >> 3) | (Xn << 61)));
+}
+
+// p = bit-sliced SMEARED code planes of the word, C = its continuation bytes.  *Ss_out = smeared SPACE plane (a byte of
+// a SPACE char), which is what token stripping needs in byte space.
+LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
+    const lk_feat fs = lk_decode(p);                 // smeared features
+    const lk_u64 Lead = ~C;
+    // the next 8 byte positions as a mini word (only its low bits matter)
+    const lk_u64 Cn = (lk_u64)(h.next_cont & 0xFFu);
+    const lk_u64 Tn = lk_transpose8(h.next_codes);
+    const lk_u64 Ln = ~Cn & 0xFFull;
+#define LK_PN(b) ((Tn >> (8 * (b))) & 0xFFull)
+    const lk_u64 Sn = LK_PN(0) & Ln, Lwn = LK_PN(2) & Ln, ANn = LK_PN(4) & Ln, An = LK_PN(5) & ~LK_PN(1) & Ln,
+                 ATn = LK_PN(5) & LK_PN(6) & Ln, SLn = LK_PN(7) & LK_PN(5) & Ln;
+#undef LK_PN
+    const lk_u64 Bn = (lk_u64)(h.next_B & 0xFFFFu);
+    const lk_u64 n0 = Cn, n1 = Cn & (Cn >> 1), n2 = n1 & (Cn >> 2);
+    // masks of the main word
+    const lk_u64 C1 = (C >> 1) | (Cn << 63), C2 = (C >> 2) | (Cn << 62);
+    const lk_u64 m0 = C, m1 = C & C1, m2 = m1 & C2;
+    // lead-only features of the word
+    const lk_u64 S = fs.S & Lead, Lw = fs.L & Lead, AN = fs.AN & Lead, A = fs.A & Lead, AT = fs.AT & Lead, SL = fs.SL & Lead;
+    const lk_u64 Y = fs.Y & Lead, U = fs.U & Lead, T = fs.T & Lead, PE = fs.PE & Lead, CO = fs.CO & Lead;
+
+#define LK_NEXTB(X, Xn_) ((lk_nl(X, Xn_, m0, m1, m2) >> 1) | ((lk_nl(Xn_, 0, n0, n1, n2) & 1ull) << 63))
+    // string ends: E = lead whose next lead is a string start
+    const lk_u64 E = Lead & LK_NEXTB(B, Bn);
+    const lk_u64 En = Ln & (lk_nl(Bn, 0, n0, n1, n2) >> 1);                  // valid for the low bits
+    const lk_u64 E2 = E | (Lead & LK_NEXTB(E, En));
+    const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
+
+    const lk_u64 nextS = LK_NEXTB(S, Sn) | E;
+    const lk_u64 nextL = LK_NEXTB(Lw, Lwn) & nE, nextAN = LK_NEXTB(AN, ANn) & nE, nextAT = LK_NEXTB(AT, ATn) & nE;
+    const lk_u64 nextA_raw = LK_NEXTB(A, An), nextSL_raw = LK_NEXTB(SL, SLn);
+    const lk_u64 nextA = nextA_raw & nE, nextSL = nextSL_raw & nE;
+    // AFTER_NEXT: the NEXT feature of the next char
+    const lk_u64 nAn = Ln & (lk_nl(An, 0, n0, n1, n2) >> 1), nSLn = Ln & (lk_nl(SLn, 0, n0, n1, n2) >> 1);
+    const lk_u64 anA = LK_NEXTB(nextA_raw & Lead, nAn) & nE2, anSL = LK_NEXTB(nextSL_raw & Lead, nSLn) & nE2;
+#undef LK_NEXTB
+
+    const lk_feat1 fp = lk_decode1(h.prev);
+#define LK_PREVB(X) ((((fs.X) << 1) | (lk_u64)fp.X) & nB)
+    const lk_u64 prevS = ((fs.S << 1) | (lk_u64)fp.S) | B;
+    const lk_u64 prevY = LK_PREVB(Y), prevL = LK_PREVB(L), prevAN = LK_PREVB(AN), prevA = LK_PREVB(A);
+#undef LK_PREVB
+
+    lk_local r;
+    r.S = S;
+    r.t_space = S;
+    r.t_sym = Y;
+    r.t_prevsym = prevY & Lead;
+    r.t_camel_next = U & nextL;
+    r.t_camel_prev = U & prevL;
+    r.raw = r.t_space | r.t_sym | r.t_prevsym | r.t_camel_next | r.t_camel_prev;
+    r.start = (T & prevS & nextA) | (PE & prevS & nextAT & anA) | (AT & prevAN & nextAN) | (CO & nextSL & anSL & prevA);
+    r.sym = Y & nextS;
+    *Ss_out = fs.S;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Runtime rule tables: the reference's extension point (default_tokenizer.py:9-30) lets a user build other
 // C_SPLIT / C_MASK / C_SYM matrices with build_combo_matrix (latok_utils.py:27-56) over the 25 feature columns.
 // _combine_matrix_rows (latok.c:318-354) is "sum over rows of the product over the row's columns"; on a 0/1 feature

@@ -26,6 +26,7 @@
 
 #include "kernels.h"
 #include "lane_math.h"
+#include "utf8_decode.h"
 
 namespace latok {
 
@@ -145,6 +146,192 @@ struct TileLds {
 // idx0 = index of the first string that starts at or after the tile's first char.
 // With write_summary the tile summary is written to *summ_l (LDS copy of the segment).
 // Returns this lane's 64-bit boundary word (kModeBits); with DEFER the caller stores it later (write combining).
+// ---------------------------------------------------------------------------------------------------------------
+// kModeBytes, phase 1: the tile is 4096 BYTES of UTF-8.  Every byte position of the staging buffer receives the split
+// code of the char that owns the byte (a lead byte and its <= 3 continuation bytes: "smeared" codes; stray
+// continuation bytes keep 0).  The continuation-byte bits of row r (64 positions) go into the row's 16 pad bytes
+// (offset 80 r + 64).  Halo: halo[0] = smeared code of byte t0-1, halo[3] = continuation bits of the 8 bytes after the
+// tile, halo[8..15] = their smeared codes.  An all-ASCII tile (the common case) is one table lookup per byte.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool u8_is_cont(uint32_t b) { return (b & 0xC0u) == 0x80u; }
+
+// code of the sequence that starts at byte J of the 19-byte window (meaningful when byte J is a lead byte)
+template <int J>
+__device__ __forceinline__ uint32_t bytes_code_at(const TileLds& L, const uint32_t (&w)[5]) {
+    return classify1(L.t1, L.t2, utf8_decode_at<J>(w));
+}
+
+// The "owner" state after a run of bytes: the code of the last char and how many more continuation bytes it may take.
+struct ByteCarry {
+    uint32_t code;
+    int left;
+};
+
+__device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
+    const int64_t total = P.total;
+    const uint8_t* __restrict__ u8 = P.u8;
+    // the tile: 4 x 16 bytes per lane (row i covers bytes 1024 i + 16 lane ..)
+    u32x4 v[4];
+    if (t0 + kTile <= total) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(u8 + t0) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            uint32_t d[4] = {0, 0, 0, 0};
+            const int64_t p = t0 + 1024 * i + 16 * lane;
+            for (int j = 0; j < 16; ++j)
+                if (p + j < total) d[j >> 2] |= (uint32_t)u8[p + j] << (8 * (j & 3));
+            v[i].x = d[0]; v[i].y = d[1]; v[i].z = d[2]; v[i].w = d[3];
+        }
+    }
+    // halo bytes: lane 0 looks at the 4 bytes before the tile, lanes 1..11 at the 11 bytes after it
+    uint32_t hb = 0;
+    if (lane == 0) {
+        for (int k = 1; k <= 4; ++k)
+            if (t0 - k >= 0) hb |= (uint32_t)u8[t0 - k] << (8 * (k - 1));      // byte k-1 of hb = byte t0-k
+    } else if (lane < 12) {
+        const int64_t q = t0 + kTile + (lane - 1);
+        if (q < total) hb = u8[q];
+    }
+    uint32_t hi_bits = hb & 0x80808080u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hi_bits |= (v[i].x | v[i].y | v[i].z | v[i].w) & 0x80808080u;
+    *reinterpret_cast<lk_u64*>(L.stage + 80u * lane + 64u) = 0ull;              // continuation bits of row `lane`
+    if (lane < 2) *reinterpret_cast<lk_u64*>(L.halo + 8u * lane) = 0ull;
+    const bool all_ascii = __all(hi_bits == 0u);
+    wave_lds_sync();   // the zero stores are ordered before everything below
+
+    // the char that owns byte t0-1 (its lead is at most 3 bytes further back): halo[0], and the state that enters the tile
+    ByteCarry in0;
+    in0.code = 0;
+    in0.left = 0;
+    if (!all_ascii && lane == 0 && t0 > 0) {
+        int k = 1;                                                              // candidate lead at t0 - k
+        while (k < 4 && t0 - k > 0 && u8_is_cont((hb >> (8 * (k - 1))) & 0xFFu)) ++k;
+        const uint32_t b0 = (hb >> (8 * (k - 1))) & 0xFFu;
+        if (!u8_is_cont(b0)) {
+            uint32_t nb[3];
+            for (int j = 1; j <= 3; ++j) {
+                const int64_t q = t0 - k + j;
+                nb[j - 1] = q < total ? (uint32_t)u8[q] : 0xFFu;
+            }
+            const uint32_t code = classify1(L.t1, L.t2, utf8_decode_bytes(b0, nb[0], nb[1], nb[2]));
+            in0.code = code;
+            in0.left = 3 - (k - 1);                     // k-1 continuation bytes were already taken before the tile
+            L.halo[0] = (uint8_t)code;                  // byte t0-1 is the lead itself or one of those continuation bytes
+        }
+    } else if (all_ascii && lane == 0 && t0 > 0) {
+        L.halo[0] = L.t2[hb & 0xFFu];
+    }
+
+    ByteCarry row_in = in0;                             // state entering lane 0 of the current row (wave-uniform use)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        if (all_ascii || __all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
+            // this 1 KiB row is pure ASCII (no char reaches into it or out of it): one lookup per byte
+            uint32_t cc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                cc[j] = (uint32_t)L.t2[d[j] & 0xFFu] | ((uint32_t)L.t2[(d[j] >> 8) & 0xFFu] << 8) |
+                        ((uint32_t)L.t2[(d[j] >> 16) & 0xFFu] << 16) | ((uint32_t)L.t2[d[j] >> 24] << 24);
+            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+            row_in.code = 0;
+            row_in.left = 0;
+            continue;
+        }
+        // bytes 16..18 after my chunk: the next lane's first dword; lane 63: lane 0's next row, or the bytes after the tile
+        uint32_t nx = __shfl_down(d[0], 1);
+        const uint32_t wrap = __shfl(v[(i + 1) & 3].x, 0);
+        if (lane == 63) {
+            nx = wrap;
+            if (i == 3) {
+                nx = 0;
+                for (int j = 0; j < 3; ++j)
+                    if (t0 + kTile + j < total) nx |= (uint32_t)u8[t0 + kTile + j] << (8 * j);
+            }
+        }
+        const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx | 0xFF000000u};
+        const int64_t p0 = t0 + 1024 * i + 16 * lane;
+        const int64_t remain = total - p0;                                    // bytes that exist from p0 on
+        const uint32_t exist19 = remain >= 19 ? 0x7FFFFu : (remain <= 0 ? 0u : ((1u << remain) - 1u));
+        const uint32_t lead19 = utf8_lead_nibble(w[0]) | (utf8_lead_nibble(w[1]) << 4) | (utf8_lead_nibble(w[2]) << 8) |
+                                (utf8_lead_nibble(w[3]) << 12) | (utf8_lead_nibble(w[4]) << 16);
+        const uint32_t cont16 = ~lead19 & exist19 & 0xFFFFu;                   // bytes beyond the end are not continuations
+        // all 16 candidate codes at once (independent chains: the LDS lookups overlap)
+        uint32_t code[16];
+#define LATOK_BC(J) code[J] = bytes_code_at<J>(L, w);
+        LATOK_BC(0) LATOK_BC(1) LATOK_BC(2) LATOK_BC(3) LATOK_BC(4) LATOK_BC(5) LATOK_BC(6) LATOK_BC(7)
+        LATOK_BC(8) LATOK_BC(9) LATOK_BC(10) LATOK_BC(11) LATOK_BC(12) LATOK_BC(13) LATOK_BC(14) LATOK_BC(15)
+#undef LATOK_BC
+        // owner scan over my 16 bytes from the empty state; the state after 16 bytes does not depend on what entered
+        uint32_t cur = 0;
+        int left = 0;
+        uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool is_c = (cont16 >> k) & 1u;
+            const bool keep = is_c && left > 0;
+            cur = is_c ? (keep ? cur : 0u) : code[k];
+            left = is_c ? (keep ? left - 1 : 0) : 3;
+            out[k >> 2] |= cur << (8 * (k & 3));
+        }
+        // what enters my chunk: the previous lane's final state (lane 0: the previous row's lane 63 / the tile's entry)
+        ByteCarry cin;
+        cin.code = __shfl_up(cur, 1);
+        cin.left = __shfl_up(left, 1);
+        if (lane == 0) cin = row_in;
+        {   // leading continuation bytes of my chunk belong to that char
+            const uint32_t lead_run = cont16 & 1u ? ((cont16 & 3u) == 3u ? ((cont16 & 7u) == 7u ? 3u : 2u) : 1u) : 0u;
+            const uint32_t take = min(lead_run, (uint32_t)max(cin.left, 0));
+            const uint32_t m = take == 0u ? 0u : (take == 1u ? 0xFFu : (take == 2u ? 0xFFFFu : 0xFFFFFFu));
+            out[0] = (out[0] & ~m) | ((cin.code * 0x010101u) & m);
+        }
+        *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(out[0], out[1], out[2], out[3]);
+        // continuation bits of my 16 positions -> pad of row (16 i + lane / 4), 16-bit slot (lane % 4)
+        *reinterpret_cast<uint16_t*>(L.stage + 80u * (16u * i + ((uint32_t)lane >> 2)) + 64u + 2u * ((uint32_t)lane & 3u)) =
+            (uint16_t)cont16;
+        row_in.code = __shfl(cur, 63);
+        row_in.left = __shfl(left, 63);
+    }
+    if (all_ascii) {
+        if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.t2[hb & 0xFFu];
+        return;
+    }
+    // the 8 bytes after the tile: smeared codes into halo[8..15], continuation bits into halo[3].  Lane k+1 owns byte k.
+    {
+        const int k = lane - 1;
+        const int64_t q0 = t0 + kTile + k;
+        const bool in_win = lane >= 1 && lane < 9 && q0 < total;
+        const bool is_c = in_win && u8_is_cont(hb & 0xFFu);
+        const lk_u64 cm = __ballot(is_c);
+        const uint32_t cbits = (uint32_t)((cm >> 1) & 0xFFull);
+        if (lane == 1) L.halo[3] = (uint8_t)cbits;
+        const uint32_t b1 = (uint32_t)__shfl_down(hb, 1), b2 = (uint32_t)__shfl_down(hb, 2), b3 = (uint32_t)__shfl_down(hb, 3);
+        const uint32_t e1 = q0 + 1 < total ? (b1 & 0xFFu) : 0xFFu, e2 = q0 + 2 < total ? (b2 & 0xFFu) : 0xFFu,
+                       e3 = q0 + 3 < total ? (b3 & 0xFFu) : 0xFFu;
+        const uint32_t my_code = classify1(L.t1, L.t2, utf8_decode_bytes(hb & 0xFFu, e1, e2, e3));
+        // owner of byte k: the nearest lead at k, k-1, k-2, k-3 inside the window, else the char that leaves the tile
+        uint32_t own = 0;
+        const uint32_t c1 = (uint32_t)__shfl_up(my_code, 1), c2 = (uint32_t)__shfl_up(my_code, 2), c3 = (uint32_t)__shfl_up(my_code, 3);
+        if (in_win) {
+            if (!is_c) {
+                own = my_code;
+            } else {
+                // run of continuation bytes that ends at k, limited to 3
+                const bool p1c = k >= 1 && ((cbits >> (k - 1)) & 1u), p2c = k >= 2 && ((cbits >> (k - 2)) & 1u);
+                if (k >= 1 && !p1c) own = c1;
+                else if (k >= 2 && p1c && !p2c) own = c2;
+                else if (k >= 3 && p1c && p2c && !((cbits >> (k - 3)) & 1u)) own = c3;
+                else if (k < row_in.left && (k == 0 || (p1c && (k == 1 || p2c)))) own = row_in.code;   // all bytes before k are continuations
+            }
+            L.halo[8 + k] = (uint8_t)own;
+        }
+    }
+}
+
 // Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
 // words are in the wave's LDS buffer L.  (A separate function because a producer / consumer variant of the kernel ran
 // the two phases in different waves; see DESIGN.md, negative results.)
@@ -161,6 +348,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     const lk_u64 B = L.bw[lane];
     const int64_t base = t0 + 64 * (int64_t)lane;
     lk_local loc;
+    lk_u64 space_plane = 0;   // SPACE plane for the token-span passes (byte mode: smeared over continuation bytes)
     if (MODE == kModeBlockMask) {
         // a1 -> start plane, a2 -> space plane; 64 bytes each, non-zero = set (PyArray_Nonzero, latok.c:178,198)
         lk_u64 st = 0, sp = 0;
@@ -204,7 +392,27 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
         lk_bitslice64(d, plane);
-        if (MODE == kModeRules) {
+        if (MODE == kModeBytes) {
+            // byte space: continuation bits of my row / of the 8 bytes after it, smeared codes of those 8 bytes
+            const lk_u64 C = *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 64u);
+            lk_halo_bytes hb;
+            hb.prev = h.prev;
+            hb.next_codes = lane < 63 ? *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 80u)
+                                      : *reinterpret_cast<const lk_u64*>(L.halo + 8);
+            hb.next_cont = lane < 63 ? (uint32_t)L.stage[80u * lane + 80u + 64u] : (uint32_t)L.halo[3];
+            hb.next_B = (uint32_t)(L.bw[lane + 1] & 0xFFFFull);
+            if (__ballot(C != 0ull || hb.next_cont != 0u) == 0ull) {
+                // no multi-byte char in or right after the tile: positions are chars, the plain rules apply
+                lk_halo ha;
+                ha.prev = h.prev;
+                ha.next0 = (uint32_t)(hb.next_codes & 0xFFull);
+                ha.next1 = (uint32_t)((hb.next_codes >> 8) & 0xFFull);
+                loc = lk_rules(lk_decode(plane), ha, B, Bn);
+                space_plane = loc.S;
+            } else {
+                loc = lk_rules_bytes(plane, C, hb, B, &space_plane);
+            }
+        } else if (MODE == kModeRules) {
             loc = lk_rules_generic(plane, h, B, Bn, P.rules);
         } else {
             const lk_feat f = lk_decode(plane);
@@ -283,7 +491,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         if (mode_writes_bits(MODE)) {
             out_word = ((loc.raw & keep) | loc.sym | B) & valid;
             if (!DEFER) P.bits_out[base >> 6] = out_word;
-            if (P.space_out) P.space_out[base >> 6] = loc.S & valid;   // token-span mode only
+            if (P.space_out) P.space_out[base >> 6] = (MODE == kModeBytes ? space_plane : loc.S) & valid;   // token-span mode only
         } else {
             // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
             // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the
@@ -345,7 +553,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     // the next 64 strings and the three halo characters
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
-    if (MODE != kModeBlockMask && lane < 3) {
+    if (MODE != kModeBlockMask && MODE != kModeBytes && lane < 3) {
         const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
         if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
     }
@@ -353,6 +561,8 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
+    } else if (MODE == kModeBytes) {
+        bytes_phase1(P, L, t0, lane);
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
@@ -378,7 +588,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
-    if (MODE != kModeBlockMask && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
+    if (MODE != kModeBlockMask && MODE != kModeBytes && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
     L.bw[lane] = 0;
     if (lane == 0) L.bw[64] = 0;
     LATOK_STAMP(2);
@@ -1178,6 +1388,7 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
+    else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
@@ -1187,6 +1398,7 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
     if (mode == kModeBits) hipLaunchKernelGGL((k_resolve_fix<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_resolve_fix<kModeRules>), grid, block, 0, st, P);
+    else if (mode == kModeBytes) hipLaunchKernelGGL((k_resolve_fix<kModeBytes>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }

@@ -49,6 +49,8 @@ struct Model {
     const int8_t* bm_a2 = nullptr;
     int8_t* bm_out = nullptr;
     const lk_rule_tables* rules = nullptr;   // runtime rule tables (kModeRules of the HIP kernel)
+    const uint8_t* u8 = nullptr;             // byte-space mode (kModeBytes): positions are UTF-8 bytes, row_off byte offsets
+    uint64_t* space_bits = nullptr;          // optional: smeared SPACE plane (byte mode)
     int64_t n_fix = 0, n_patch = 0;
 
     void clear_range(int64_t lo, int64_t hi, int64_t limit, int keep_first, int keep_last) {
@@ -66,7 +68,30 @@ struct Model {
         }
     }
 
-    uint32_t code_at(int64_t p) const { return (cps && p >= 0 && p < total) ? classify(cps[p], rules != nullptr) : 0u; }
+    bool cont_at(int64_t p) const { return u8 && p >= 0 && p < total && (u8[p] & 0xC0u) == 0x80u; }
+    // byte mode: code of the char that owns byte p (a lead byte and up to 3 continuation bytes after it); 0 for stray
+    // continuation bytes.  Decoding mirrors aux_kernels.hip:utf8_decode_at (truncated sequence -> U+FFFD).
+    uint32_t byte_code_at(int64_t p) const {
+        if (p < 0 || p >= total) return 0u;
+        int64_t q = p;
+        for (int k = 0; k < 3 && cont_at(q); ++k) --q;
+        if (q < 0 || cont_at(q)) return 0u;
+        const uint32_t b0 = u8[q];
+        uint32_t cp = b0;
+        int extra = 0;
+        if (b0 >= 0xF0u) { cp = b0 & 0x07u; extra = 3; }
+        else if (b0 >= 0xE0u) { cp = b0 & 0x0Fu; extra = 2; }
+        else if (b0 >= 0xC0u) { cp = b0 & 0x1Fu; extra = 1; }
+        for (int j = 1; j <= extra; ++j) {
+            if (cont_at(q + j)) cp = (cp << 6) | (u8[q + j] & 0x3Fu);
+            else { cp = 0xFFFDu; break; }
+        }
+        return classify(cp);
+    }
+    uint32_t code_at(int64_t p) const {
+        if (u8) return byte_code_at(p);
+        return (cps && p >= 0 && p < total) ? classify(cps[p], rules != nullptr) : 0u;
+    }
 
     // stage 0: tile_first[t] = first string index s with row_off[s] >= t*kTile
     void build_tile_index() {
@@ -115,6 +140,23 @@ struct Model {
                 }
                 loc[j] = lk_local();
                 loc[j].start = st; loc[j].S = sp; loc[j].raw = ~0ull; loc[j].sym = 0;
+            } else if (u8) {
+                lk_halo_bytes hb;
+                hb.prev = code_at(base - 1);
+                hb.next_codes = 0;
+                hb.next_cont = 0;
+                for (int k = 0; k < 8; ++k) {
+                    hb.next_codes |= (lk_u64)code_at(base + 64 + k) << (8 * k);
+                    hb.next_cont |= (uint32_t)cont_at(base + 64 + k) << k;
+                }
+                hb.next_B = (uint32_t)(Bw[j + 1] & 0xFFFFull);
+                lk_u64 C = 0, Ss = 0;
+                for (int i = 0; i < 64; ++i) C |= (lk_u64)cont_at(base + i) << i;
+                loc[j] = lk_rules_bytes(plane, C, hb, Bw[j], &Ss);
+                if (space_bits && base < total) {
+                    const int64_t remain = total - base;
+                    space_bits[base >> 6] = Ss & (remain >= 64 ? ~0ull : ((1ull << remain) - 1ull));
+                }
             } else if (rules) {
                 loc[j] = lk_rules_generic(plane, h, Bw[j], Bw[j + 1] & 3ull, *rules);
             } else {
@@ -216,7 +258,7 @@ struct Model {
             const int tz0 = summ[(size_t)t].b > 0;
             if (q_in[(size_t)t] != 0 || tz[(size_t)t] != tz0) {
                 const TileSummary& sm = summ[(size_t)t];
-                if (bits && !values && !bm_out && !rules && sm.has_closing && q_in[(size_t)t] <= 1 &&
+                if (bits && !values && !bm_out && !rules && !u8 && sm.has_closing && q_in[(size_t)t] <= 1 &&
                     (q_in[(size_t)t] == 0 || sm.head_starts == 0)) {
                     // patch in place (mirrors k_scan_resolve)
                     const int64_t t0 = t * kTile, t_end = std::min<int64_t>(t0 + kTile, total);
@@ -245,6 +287,25 @@ extern "C" int fused_split_batch(const uint32_t* cps, const int64_t* row_off, in
     m.n_tiles = (m.total + kTile - 1) / kTile;
     m.values = values_out;
     m.bits = bits_out;
+    m.run();
+    if (n_fix_out) *n_fix_out = m.n_fix + m.n_patch;
+    return 0;
+}
+
+// byte-space mode: UTF-8 bytes + byte offsets in, boundary bits at lead-byte positions out (kModeBytes of the HIP kernel)
+extern "C" int fused_split_batch_utf8(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, uint64_t* bits_out,
+                                      uint64_t* space_out, int64_t* n_fix_out) {
+    if (n_str < 0) return -1;
+    Model m;
+    m.cps = nullptr;
+    m.u8 = u8;
+    m.row_off = byte_off;
+    m.n_str = n_str;
+    m.total = n_str > 0 ? byte_off[n_str] : 0;
+    m.n_tiles = (m.total + kTile - 1) / kTile;
+    m.values = nullptr;
+    m.bits = bits_out;
+    m.space_bits = space_out;
     m.run();
     if (n_fix_out) *n_fix_out = m.n_fix + m.n_patch;
     return 0;

@@ -101,3 +101,48 @@ def test_model_runtime_rule_tables(model, oracle, name):
             assert np.array_equal(bits, oracle_rule_bits(oracle, texts, tables)), (name, rep, kind)
             if name == "default":
                 assert np.array_equal(bits, oracle.split_batch(cps, row, want_values=False)[1])
+
+
+def test_model_utf8_byte_space(model, oracle):
+    """Byte-space rule algebra (lane_math.h: lk_rules_bytes -- smeared code planes, continuation plane, "next lead"
+    shifts) in the CPU model: boundary bits and the smeared SPACE plane at BYTE positions of the UTF-8 encoding against
+    the oracle's code-point results mapped to bytes."""
+    model.fused_split_batch_utf8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = random.Random(31)
+    alpha = ALPHABETS["mixed"] + list("é日🤓ü　 ") + ["http://é", "a@日", ".@ü", "#日"]
+    for it in range(400):
+        kind = rng.choice([0, 0, 0, 1, 2])
+        if kind == 0:
+            texts = random_strings(rng, rng.randint(1, 6), 0, 14, alpha)
+        elif kind == 1:
+            texts = random_strings(rng, rng.randint(1, 30), 0, 300, alpha)
+        else:
+            texts = random_strings(rng, rng.randint(1, 3), 2000, 9000, alpha)
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        boff = np.zeros(len(texts) + 1, np.int64)
+        np.cumsum([len(b) for b in blobs], out=boff[1:])
+        total = int(boff[-1])
+        if total == 0:
+            continue
+        flags = np.zeros(total, bool)
+        space = np.zeros(total, bool)
+        for t, b0 in zip(texts, boff[:-1]):
+            if not t:
+                continue
+            v = oracle.split_values(t)
+            m = oracle.gen_parse_matrix(t)
+            pos = 0
+            for i, ch in enumerate(t):
+                n = len(ch.encode("utf-8", "surrogatepass"))
+                flags[b0 + pos] = v[i] != 0
+                space[b0 + pos:b0 + pos + n] = m[i, 5] != 0
+                pos += n
+        u8 = np.frombuffer(b"".join(blobs), np.uint8)
+        bits = np.zeros((total + 63) // 64, np.uint64)
+        sp = np.zeros_like(bits)
+        assert model.fused_split_batch_utf8(u8.ctypes.data, boff.ctypes.data, len(texts), bits.ctypes.data, sp.ctypes.data,
+                                            None) == 0
+        got = np.unpackbits(bits.view(np.uint8), bitorder="little")[:total].astype(bool)
+        gsp = np.unpackbits(sp.view(np.uint8), bitorder="little")[:total].astype(bool)
+        assert np.array_equal(got, flags), (it, texts if total < 200 else total)
+        assert np.array_equal(gsp, space), (it, "space plane")

@@ -571,3 +571,50 @@ def test_featurize_long_tokens_across_words_and_tiles(gpu, oracle):
         for tok, (a, b) in zip(toks, want):
             f = m[a:b].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8)
             assert np.array_equal(tok.features, f), (t[:40], a, b, tok.features, f)
+
+
+def _byte_expect(oracle, texts):
+    """oracle boundaries / SPACE flags mapped from code-point to byte positions of the UTF-8 encoding"""
+    blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+    boff = np.zeros(len(texts) + 1, np.int64)
+    np.cumsum([len(b) for b in blobs], out=boff[1:])
+    flags = np.zeros(int(boff[-1]), bool)
+    per_string = []
+    for t, b0 in zip(texts, boff[:-1]):
+        lens = np.array([len(ch.encode("utf-8", "surrogatepass")) for ch in t], np.int64)
+        start = np.zeros(len(t) + 1, np.int64)
+        np.cumsum(lens, out=start[1:])
+        nz = oracle.split_offsets(t) if t else np.zeros(0, np.int64)
+        flags[b0 + start[nz]] = True
+        per_string.append(start[nz])
+    return blobs, boff, flags, per_string
+
+
+def test_utf8_byte_space(gpu, oracle):
+    """Fused UTF-8 ingest: the tile kernel works on BYTE positions (kModeBytes); boundaries, offsets and token spans are
+    the reference's, mapped to byte positions of the UTF-8 buffer.  ASCII tiles, mixed tiles, multi-byte chars across word
+    and tile edges, multi-byte spaces, lone surrogates (surrogatepass), empty strings."""
+    from latok_amd import batch
+    rng = random.Random(2024)
+    alpha = ALPHABETS["mixed"] + list("é日🤓ü　 ") + ["http://é", "a@日", ".@ü", "#日"]
+    cases = [[G1, "", "日本語のテキスト、です。 🤓 ok ", "é", "🤓", "a　b c", "x" * 4095 + "é" + "y" * 10, "\ud800 lone \udfff"],
+             random_strings(rng, 300, 0, 60, alpha), random_strings(rng, 40, 0, 400, ALPHABETS["words"]),
+             random_strings(rng, 4, 3000, 20000, alpha), random_strings(rng, 3, 5000, 30000, ALPHABETS["rare_space_at"] + ["é"]),
+             random_strings(rng, 2000, 0, 6, alpha), ["é" * 5000, "🤓" * 3000 + " a", "日" * 4096 + "@" + "語" * 4096]]
+    for texts in cases:
+        blobs, boff, flags, per_string = _byte_expect(oracle, texts)
+        utf8 = np.frombuffer(b"".join(blobs), np.uint8)
+        total = int(boff[-1])
+        bits = batch.split_mask_utf8_bytes_csr(utf8, boff)
+        got = bits_to_bool(bits, total)
+        if not np.array_equal(got, flags):
+            bad = int(np.nonzero(got != flags)[0][0])
+            s = int(np.searchsorted(boff, bad, side="right") - 1)
+            raise AssertionError(f"byte mask differs at byte {bad} (string {s}, byte {bad - boff[s]} of {boff[s + 1] - boff[s]})")
+        counts, offs = batch.split_offsets_utf8_bytes_csr(utf8, boff)
+        assert np.array_equal(counts, [len(x) for x in per_string])
+        assert np.array_equal(offs, np.concatenate(per_string) if per_string else np.zeros(0, np.int64))
+        toks = batch.tokenize_utf8_batch(blobs)
+        for t, g in zip(texts, toks):
+            want = [w.encode("utf-8", "surrogatepass") for w in (oracle.tokenize(t) if t else [])]
+            assert g == want, (t[:60], g[:8], want[:8])

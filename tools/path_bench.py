@@ -8,6 +8,7 @@
   utf8_mask       latok_split_mask_utf8_batch       (8f-3: UTF-8 in, code-point row offsets + mask out)
   utf8_offsets    latok_split_offsets_utf8_batch
   utf8_spans      latok_token_spans_utf8_batch
+  bytes_mask / bytes_offsets / bytes_spans   latok_*_utf8_bytes_batch (8f-3 fused: the tile kernel reads the bytes)
   rules_mask      latok_split_mask_batch after latok_set_rules(built-in tables)   (8f-4)
 
 Every line carries: ms per call (wall clock around `--iters` blocking calls, inputs and outputs in HBM; the
@@ -56,7 +57,8 @@ def main():
     ap.add_argument("--strings", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
-    ap.add_argument("--paths", default="mask,offsets,spans,features,utf8_mask,utf8_offsets,utf8_spans,rules_mask")
+    ap.add_argument("--paths", default="mask,offsets,spans,features,utf8_mask,utf8_offsets,utf8_spans,"
+                                       "bytes_mask,bytes_offsets,bytes_spans,rules_mask")
     args = ap.parse_args()
     lib = _lib.ensure_init()
     model, seed, lo, hi = WORKLOADS[args.workload]
@@ -129,6 +131,18 @@ def main():
     if "utf8_spans" in paths:
         run("utf8_spans", lambda: lib.latok_token_spans_utf8_batch(d_u8, d_boff, n, n8, d_counts, d_items, cap, C.byref(nout), D, None),
             lambda: n8 + csr + 8 * n + 16 * nout.value, "UTF-8 bytes + 8 B/string read; 8 B/string + 16 B/token written")
+    bwords = (n8 + 63) // 64
+    if "bytes_mask" in paths:
+        d_bbits = lib.latok_dev_alloc(bwords * 8 + 8)
+        nout.value = 0
+        run("bytes_mask", lambda: lib.latok_split_mask_utf8_bytes_batch(d_u8, d_boff, n, n8, d_bbits, D, None),
+            lambda: n8 + csr + bwords * 8, "UTF-8 bytes + 8 B/string read; 1 bit/byte written (byte space, fused ingest)")
+    if "bytes_offsets" in paths:
+        run("bytes_offsets", lambda: lib.latok_split_offsets_utf8_bytes_batch(d_u8, d_boff, n, n8, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: n8 + csr + 8 * n + 8 * nout.value, "UTF-8 bytes + 8 B/string read; 8 B/string + 8 B/boundary written (byte offsets)")
+    if "bytes_spans" in paths:
+        run("bytes_spans", lambda: lib.latok_token_spans_utf8_bytes_batch(d_u8, d_boff, n, n8, d_counts, d_items, cap, C.byref(nout), D, None),
+            lambda: n8 + csr + 8 * n + 16 * nout.value, "UTF-8 bytes + 8 B/string read; 8 B/string + 16 B/token written (byte ranges)")
     if "rules_mask" in paths:
         from latok_amd import batch
         from latok_amd.core import default_tokenizer as dt

@@ -3,8 +3,8 @@
 
 Worker processes build random batches from adversarial alphabets in several shape regimes (many tiny strings, tweets,
 multi-tile documents, no-whitespace documents with starts, dense starts) and compute the oracle's split values / bitmask on
-the CPU; the main process runs the same batch through the C ABI (values, bitmask, offsets, token spans, and the bitmask
-under run-time rule tables) and compares bit for bit.  Stops after --seconds.
+the CPU; the main process runs the same batch through the C ABI (values, bitmask, offsets, token spans, the bitmask
+under run-time rule tables, and the UTF-8 entry points in byte space and in code-point units) and compares bit for bit.  Stops after --seconds.
 
 usage: tools/soak.py [--seconds 120] [--workers 12] [--seed 1]
 """
@@ -55,7 +55,18 @@ def make_batch(seed):
                 flags[k:k + len(t)] = orc.split_values_rules(t, *rules) != 0
             k += len(t)
         rule_bits = np.packbits(np.concatenate([flags, np.zeros((-cps.size) % 64, bool)]), bitorder="little").view(np.uint64)
-    return seed, kind, cps, row, vals, bits, space, rules, rule_bits
+    # UTF-8 view of the batch: bytes, byte offsets, byte position of every code point (multi-byte material is added to
+    # some batches by replacing a few ASCII letters)
+    u8 = boff = bpos = None
+    if rng.random() < 0.5 and cps.size < 200000:
+        lens = 1 + (cps >= 0x80).astype(np.int64) + (cps >= 0x800) + (cps >= 0x10000)
+        pref = np.zeros(cps.size + 1, np.int64)
+        np.cumsum(lens, out=pref[1:])
+        u8 = np.frombuffer("".join(texts).encode("utf-8", "surrogatepass"), np.uint8)
+        assert u8.size == int(pref[-1])
+        boff = np.ascontiguousarray(pref[row])
+        bpos = pref[:-1]
+    return seed, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos
 
 
 def spans_from(vals, space, row):
@@ -83,14 +94,14 @@ def main():
     args = ap.parse_args()
     from latok_amd import batch
     t_end = time.time() + args.seconds
-    n_batches = n_chars = n_rules = n_spans = 0
+    n_batches = n_chars = n_rules = n_spans = n_u8 = 0
     seed = args.seed * 1_000_003
     last = time.time()
     with mp.Pool(args.workers) as pool:
         pending = [pool.apply_async(make_batch, (seed + i,)) for i in range(args.workers * 2)]
         seed += len(pending)
         while pending:
-            sd, kind, cps, row, vals, bits, space, rules, rule_bits = pending.pop(0).get()
+            sd, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos = pending.pop(0).get()
             if time.time() < t_end:
                 pending.append(pool.apply_async(make_batch, (seed,)))
                 seed += 1
@@ -116,14 +127,28 @@ def main():
                     batch.reset_rules()
                 assert np.array_equal(rb, rule_bits), "rule-table bitmask differs: " + tag
                 n_rules += 1
+            if u8 is not None and cps.size > 0:
+                # byte space: boundaries at the lead byte of every boundary char; staged path: code-point units
+                flags = np.zeros(u8.size, bool)
+                flags[bpos[vals != 0]] = True
+                bb = batch.split_mask_utf8_bytes_csr(u8, boff)
+                got = np.unpackbits(bb.view(np.uint8), bitorder="little")[:u8.size].astype(bool)
+                assert np.array_equal(got, flags), "byte-space bitmask differs: " + tag
+                bc, bo = batch.split_offsets_utf8_bytes_csr(u8, boff)
+                exp_b = [bpos[row[s]:row[s + 1]][vals[row[s]:row[s + 1]] != 0] - boff[s] for s in range(len(row) - 1)]
+                assert np.array_equal(bc, [len(e) for e in exp_b]), "byte offset counts differ: " + tag
+                assert np.array_equal(bo, np.concatenate(exp_b)), "byte offsets differ: " + tag
+                cb, crow = batch.split_mask_utf8_csr(u8, boff)
+                assert np.array_equal(crow, row) and np.array_equal(cb, bits), "code-point UTF-8 path differs: " + tag
+                n_u8 += 1
             n_batches += 1
             n_chars += cps.size
             if time.time() - last > 30:
                 last = time.time()
-                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks ... ok",
+                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8 ... ok",
                       flush=True)
     print(f"soak passed: {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
-          f"{args.seconds:.0f} s")
+          f"{n_u8} UTF-8 (byte space + code-point) checks, {args.seconds:.0f} s")
 
 
 if __name__ == "__main__":

@@ -349,6 +349,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     const int64_t base = t0 + 64 * (int64_t)lane;
     lk_local loc;
     lk_u64 space_plane = 0;   // SPACE plane for the token-span passes (byte mode: smeared over continuation bytes)
+    int no_patch = 0;         // byte mode: the tile holds multi-byte chars, the resolve stage must recompute, not patch
     if (MODE == kModeBlockMask) {
         // a1 -> start plane, a2 -> space plane; 64 bytes each, non-zero = set (PyArray_Nonzero, latok.c:178,198)
         lk_u64 st = 0, sp = 0;
@@ -401,7 +402,8 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                                       : *reinterpret_cast<const lk_u64*>(L.halo + 8);
             hb.next_cont = lane < 63 ? (uint32_t)L.stage[80u * lane + 80u + 64u] : (uint32_t)L.halo[3];
             hb.next_B = (uint32_t)(L.bw[lane + 1] & 0xFFFFull);
-            if (__ballot(C != 0ull || hb.next_cont != 0u) == 0ull) {
+            no_patch = __ballot(C != 0ull || hb.next_cont != 0u) != 0ull;
+            if (!no_patch) {
                 // no multi-byte char in or right after the tile: positions are chars, the plain rules apply
                 lk_halo ha;
                 ha.prev = h.prev;
@@ -461,7 +463,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         const int tail_sym = lane_read((int)(loc.sym >> 63), 63);
         if (lane == 0) {
             const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
-                             (tail_sym << 29);
+                             (tail_sym << 29) | (no_patch << 30);
             *summ_l = make_int4(tile_fn.a, tile_fn.b, head, geom);   // LDS; the segment publishes them in one burst
 #ifdef LATOK_AB_SUMM_PER_TILE
             P.summ[t] = *summ_l;
@@ -1006,7 +1008,9 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
             const int tz0 = s.y > 0;
             if (q_in != 0 || tz != tz0) {
                 const int geom = s.w;
-                if (MODE == kModeBits && (geom & 1) && q_in <= 1 && (q_in == 0 || s.z == 0)) {
+                // (byte mode: only tiles without multi-byte chars, where "last char of a block" = "last position")
+                if ((MODE == kModeBits || MODE == kModeBytes) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
+                    (q_in == 0 || s.z == 0)) {
                     // Patch in place: one pending start entering a tile whose head block has no start of its own
                     // zeroes that head block; a tail block that turns out to be zeroed is cleared.  What stays in a
                     // cleared block: the C_SYM bit of its last char and the bit of a string start.

@@ -618,3 +618,17 @@ def test_utf8_byte_space(gpu, oracle):
         for t, g in zip(texts, toks):
             want = [w.encode("utf-8", "surrogatepass") for w in (oracle.tokenize(t) if t else [])]
             assert g == want, (t[:60], g[:8], want[:8])
+
+
+def test_c_example_program(gpu, oracle, tmp_path):
+    """examples/tokenize_utf8.c: a plain C caller of the C ABI (byte-space token ranges) prints the reference's tokens."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "tokenize_utf8")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "tokenize_utf8.c"),
+                           "-L" + os.path.join(ROOT, "latok_amd"), "-llatok_hip", "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"),
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, timeout=120, check=True).stdout.decode("utf-8").splitlines()
+    texts = [G1, "see http://a.b/c or mail me@x.org", "camelCase 日本語 🤓"]
+    assert out == [f"{i}:" + "".join(f" [{t}]" for t in oracle.tokenize(s)) for i, s in enumerate(texts)]

@@ -159,3 +159,17 @@ def test_shard_bounds_balance_and_cover():
         if n_str >= 8 * world and row[-1] > 0:
             sizes = np.array([p[0].size for p in parts])
             assert sizes.max() - sizes.min() <= 2 * lens.max()      # balanced up to one string per cut
+
+
+def test_header_is_plain_c_and_example_links(tmp_path):
+    """include/latok_hip.h is the C ABI: it has to compile as C99 (no C++ or torch types), and a C program that uses it
+    links against the library without anything else."""
+    import subprocess
+    from conftest import ROOT
+    src = os.path.join(ROOT, "examples", "tokenize_utf8.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-fsyntax-only", src])
+    exe = str(tmp_path / "tokenize_utf8")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), src, "-L" + os.path.join(ROOT, "latok_amd"),
+                           "-llatok_hip", "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"), "-o", exe])
+    assert os.path.exists(exe)

@@ -578,7 +578,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
         HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total,
-                                           d_row, n_str, d_tile_first, d_items, nullptr, st));
+                                           d_row, n_str, d_tile_first, d_items, st));
         if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
             return rc;
         HIP_TRY(hipStreamSynchronize(st));
@@ -610,7 +610,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         }
     }
     HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total, d_row,
-                                       n_str, d_tile_first, d_items, nullptr, st));
+                                       n_str, d_tile_first, d_items, st));
     if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
         return rc;
     if (!dev) {

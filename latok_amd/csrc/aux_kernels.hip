@@ -2,8 +2,9 @@
 //   * the reference's native functions one string at a time, as plain element-parallel kernels (compat surface):
 //       _gen_parse_matrix      reference latok/core/src/latok/latok.c:31-138
 //       _combine_matrix_rows   reference latok/core/src/latok/latok.c:275-370
-//   * boundary-offset compaction (np.nonzero, reference latok/core/default_tokenizer.py:148)
-//   * synthetic corpus fill and UTF-8 size reduction for the benchmark
+//   * device-wide exclusive scan (used by the compaction passes and the UTF-8 decoder)
+//   * the staged UTF-8 decoder (code-point units; the byte-space ingest lives in split_kernels.hip)
+//   * synthetic corpus fill, UTF-8 size reduction and the streaming-read ceiling kernel for the benchmark
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -136,7 +136,7 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 //       word's end follows the masks further) and puts the records into an LDS window at their rank inside the wave;
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
 // KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
-// KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end}, tok_sid[k] = string id (featurize pass).
+// KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end} (featurize; the sums come from k_features_tiles).
 constexpr int kScatterWaves = 4;                 // waves per workgroup
 constexpr int kScatterWin = 1024;                // int64 slots of one wave's LDS window (8 KiB)
 
@@ -165,12 +165,11 @@ template <int KIND>
 __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
     const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
     const int64_t* __restrict__ word_rank, int64_t n_words, int64_t total, const int64_t* __restrict__ row_off,
-    int64_t n_str, const int64_t* __restrict__ tile_first, int64_t* __restrict__ out, int64_t* __restrict__ tok_sid) {
+    int64_t n_str, const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
     constexpr int kVals = KIND == 0 ? 1 : (KIND == 1 ? 2 : 4);      // int64 values per item
     constexpr int kWin = KIND == 2 ? kScatterWin : kScatterWin;     // int64 slots of one wave's window
     constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
     __shared__ int64_t win_s[kScatterWaves][kWin];
-    __shared__ int64_t sid_s[kScatterWaves][KIND == 2 ? kCap : 1];
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
@@ -189,7 +188,6 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
     const int off = inc - cnt;                                      // rank of my first item inside the wave
     const int64_t base_out = __shfl(w < n_words ? word_rank[w] : 0, 0);   // lane 0's word always exists
     int64_t* win = win_s[wave];
-    int64_t* sidw = sid_s[wave];
     long long* smax = smax_s[wave];
 
     // (a) string that contains the first char of every word
@@ -277,7 +275,6 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
                     rec[1] = e - lo;
                     rec[2] = a2 - lo;
                     rec[3] = e2 - lo;
-                    if (tok_sid) sidw[k - win0] = s;
                 }
             }
             ++k;
@@ -301,8 +298,6 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
             if (((n_val - head) & 1) && lane == 0)
                 __builtin_nontemporal_store((long long)win[n_val - 1], (long long*)dst + n_val - 1);
         }
-        if (KIND == 2 && tok_sid)
-            for (int i = lane; i < n_here; i += 64) tok_sid[base_out + win0 + i] = sidw[i];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -328,19 +323,19 @@ hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, 
 
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, const int64_t* tile_first, int64_t* out, int64_t* tok_sid, hipStream_t st) {
+                               int64_t n_str, const int64_t* tile_first, int64_t* out, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
     const int64_t per_block = (int64_t)kScatterWaves * 64;
     const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(kScatterWaves * 64);
     if (kind == 0)
         hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out, tok_sid);
+                           row_off, n_str, tile_first, out);
     else if (kind == 1)
         hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out, tok_sid);
+                           row_off, n_str, tile_first, out);
     else
         hipLaunchKernelGGL((k_word_scatter<2>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out, tok_sid);
+                           row_off, n_str, tile_first, out);
     return hipGetLastError();
 }
 

@@ -98,7 +98,7 @@ hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, 
                                 int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, const int64_t* tile_first, int64_t* out, int64_t* tok_sid, hipStream_t st);
+                               int64_t n_str, const int64_t* tile_first, int64_t* out, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

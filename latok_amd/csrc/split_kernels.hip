@@ -824,7 +824,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // stage 1: the tiles.  The tile range is cut into segments of P.seg_tiles (<= 1024) consecutive tiles; a workgroup
-// owns whole segments (grid-stride), its 16 waves take the segment's tiles round-robin.  Per segment the workgroup
+// owns whole segments (grid-stride), its kWPB waves take the segment's tiles round-robin.  Per segment the workgroup
 //   (a) finds the first string of the segment with a block-wide k-ary search over row_off and derives, in LDS, the
 //       first string of every tile (this replaces a separate indexing pass over row_off),
 //   (b) runs the tiles, each publishing its 16-byte summary to LDS and to global memory,

@@ -632,3 +632,81 @@ def test_c_example_program(gpu, oracle, tmp_path):
     out = subprocess.run([exe], capture_output=True, timeout=120, check=True).stdout.decode("utf-8").splitlines()
     texts = [G1, "see http://a.b/c or mail me@x.org", "camelCase 日本語 🤓"]
     assert out == [f"{i}:" + "".join(f" [{t}]" for t in oracle.tokenize(s)) for i, s in enumerate(texts)]
+
+
+def test_device_pointer_forms_match_host_pointer_forms(gpu, oracle):
+    """Every batch entry point with LATOK_DEVICE_PTRS (inputs and outputs in HBM, caller-owned) against the same call with
+    host pointers, on a mixed batch that is larger than the small-batch path and contains multi-byte chars."""
+    from latok_amd import _lib, batch
+    lib = gpu
+    rng = random.Random(808)
+    alpha = ALPHABETS["mixed"] + list("é日🤓") + ["http://é", "a@日"]
+    texts = random_strings(rng, 700, 0, 120, alpha) + random_strings(rng, 3, 3000, 9000, alpha) + ["", "x"]
+    cps, row = pack(texts)
+    n, total = len(texts), int(row[-1])
+    blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+    u8, boff = batch.pack_utf8(blobs)
+    nb = int(boff[-1])
+    D = _lib.DEVICE_PTRS
+
+    def dev(a):
+        a = np.ascontiguousarray(a)
+        p = lib.latok_dev_alloc(max(a.nbytes, 16) + 64)
+        assert p
+        _lib.check(lib.latok_memcpy_h2d(p, a.ctypes.data, a.nbytes))
+        return p
+
+    def back(p, shape, dtype):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            _lib.check(lib.latok_memcpy_d2h(out.ctypes.data, p, out.nbytes))
+        return out
+
+    d_cps, d_row, d_u8, d_boff = dev(cps), dev(row), dev(u8), dev(boff)
+    cap = max(total, nb) + 8
+    d_bits = lib.latok_dev_alloc(((cap + 63) // 64) * 8 + 8)
+    d_counts = lib.latok_dev_alloc(n * 8 + 8)
+    d_items = lib.latok_dev_alloc(cap * 32)
+    d_feat = lib.latok_dev_alloc(cap * 25)
+    d_cprow = lib.latok_dev_alloc((n + 1) * 8)
+    nout, tcp = C.c_int64(0), C.c_int64(0)
+    try:
+        _lib.check(lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None))
+        _lib.check(lib.latok_sync())
+        assert np.array_equal(back(d_bits, (total + 63) // 64, np.uint64), batch.split_mask_batch(cps, row))
+        for name, fn, host, width in [
+            ("offsets", lambda: lib.latok_split_offsets_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.split_offsets_csr(cps, row), 1),
+            ("spans", lambda: lib.latok_token_spans_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.token_spans_csr(cps, row), 2),
+            ("utf8 offsets", lambda: lib.latok_split_offsets_utf8_batch(d_u8, d_boff, n, nb, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.split_offsets_utf8_csr(u8, boff), 1),
+            ("utf8 spans", lambda: lib.latok_token_spans_utf8_batch(d_u8, d_boff, n, nb, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.token_spans_utf8_csr(u8, boff), 2),
+            ("byte offsets", lambda: lib.latok_split_offsets_utf8_bytes_batch(d_u8, d_boff, n, nb, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.split_offsets_utf8_bytes_csr(u8, boff), 1),
+            ("byte spans", lambda: lib.latok_token_spans_utf8_bytes_batch(d_u8, d_boff, n, nb, d_counts, d_items, cap, C.byref(nout), D, None),
+             batch.token_spans_utf8_bytes_csr(u8, boff), 2),
+        ]:
+            _lib.check(fn())
+            _lib.check(lib.latok_sync())
+            h_counts, h_items = host
+            assert nout.value == len(h_items), name
+            assert np.array_equal(back(d_counts, n, np.int64), h_counts), name
+            assert np.array_equal(back(d_items, nout.value * width, np.int64).reshape(h_items.shape), h_items), name
+        _lib.check(lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D, None))
+        _lib.check(lib.latok_sync())
+        h_counts, h_spans, h_feats = batch.token_features_csr(cps, row)
+        assert nout.value == len(h_spans) and np.array_equal(back(d_counts, n, np.int64), h_counts)
+        assert np.array_equal(back(d_items, (nout.value, 4), np.int64), h_spans)
+        assert np.array_equal(back(d_feat, (nout.value, 25), np.int8), h_feats)
+        _lib.check(lib.latok_split_mask_utf8_batch(d_u8, d_boff, n, nb, d_bits, (cap + 63) // 64, d_cprow, C.byref(tcp), D, None))
+        _lib.check(lib.latok_sync())
+        assert tcp.value == total and np.array_equal(back(d_cprow, n + 1, np.int64), row)
+        assert np.array_equal(back(d_bits, (total + 63) // 64, np.uint64), batch.split_mask_batch(cps, row))
+        _lib.check(lib.latok_split_mask_utf8_bytes_batch(d_u8, d_boff, n, nb, d_bits, D, None))
+        _lib.check(lib.latok_sync())
+        assert np.array_equal(back(d_bits, (nb + 63) // 64, np.uint64), batch.split_mask_utf8_bytes_csr(u8, boff))
+    finally:
+        for p in (d_cps, d_row, d_u8, d_boff, d_bits, d_counts, d_items, d_feat, d_cprow):
+            lib.latok_dev_free(p)

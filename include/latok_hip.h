@@ -17,6 +17,10 @@
  *     (row_off[0] == 0, non-decreasing).  Device `cps` pointers must be 16-byte aligned.
  *   - `total_chars` = row_off[n_str]; the caller normally knows it.  Pass -1 to let the library read it (in device
  *     mode that costs one blocking 8-byte device->host copy).
+ *   - threads and streams: host calls are serialised by an internal lock; all calls share one set of device workspaces,
+ *     so work submitted on different streams is ordered on the device (a call waits for the previous call's last
+ *     kernel before its own first one) -- calls never overlap, whatever stream they use.  The compaction entry
+ *     points (offsets / spans / features) read one 8-byte total back and therefore block even in device mode.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H

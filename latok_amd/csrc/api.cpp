@@ -114,6 +114,9 @@ struct Ctx {
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
+    hipStream_t turn_stream = nullptr;
+    bool turn_stream_valid = false;
 } g;
 
 int ensure_workspace(int64_t n_tiles) {
@@ -129,6 +132,24 @@ int need_init() {
     if (!g.inited) return fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called (no CPU fallback exists)");
     return LATOK_OK;
 }
+
+// The workspaces (tile summaries, bitmasks, ranks, staging) are shared by all calls.  Host calls are serialised by g_mu,
+// but with caller streams the kernels of two calls could still overlap on the device: a call that runs on another
+// stream than the previous one first waits (on the device) for that call's last kernel.
+struct StreamTurn {
+    hipStream_t st;
+    explicit StreamTurn(void* stream) : st(stream ? (hipStream_t)stream : g.stream) {
+        if (g.inited && g.turn_event && g.turn_stream_valid && g.turn_stream != st)
+            (void)hipStreamWaitEvent(st, g.turn_event, 0);
+    }
+    ~StreamTurn() {
+        if (g.inited && g.turn_event) {
+            (void)hipEventRecord(g.turn_event, st);
+            g.turn_stream = st;
+            g.turn_stream_valid = true;
+        }
+    }
+};
 
 // enqueue the pipeline on device-resident data
 int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
@@ -209,7 +230,8 @@ int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int
                  int flags, void* stream) {
     int rc = need_init();
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
         if (total == 0) return LATOK_OK;
@@ -279,6 +301,8 @@ int latok_init(int device) {
     g.n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     for (auto& e : g.ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventCreateWithFlags(&g.turn_event, hipEventDisableTiming));
+    g.turn_stream_valid = false;
 
     // tables: stage-1 (padded), stage-2 as split codes (fused path) and as class ids + class words (parse matrix)
     std::vector<uint8_t> t1(latok::kStage1Pad, kStage1[LATOK_TBL_STAGE1_LEN - 1]);
@@ -318,6 +342,9 @@ int latok_shutdown(void) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
+    if (g.turn_event) (void)hipEventDestroy(g.turn_event);
+    g.turn_event = nullptr;
+    g.turn_stream_valid = false;
     (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
     g.inited = false;
@@ -482,7 +509,8 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if (rc) return rc;
     if (!n_items_out) return fail(LATOK_ERR_INVALID, "the total-count output pointer is NULL");
     *n_items_out = 0;
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
@@ -643,7 +671,8 @@ int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_
     int rc = need_init();
     if (rc) return rc;
     if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total_cps = 0;
     if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total_cps))) return rc;
@@ -665,7 +694,8 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
     int rc = need_init();
     if (rc) return rc;
     if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total = 0;
     BytesRoute br;
@@ -720,7 +750,8 @@ int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_o
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = need_init();
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         if ((rc = resolve_total_device(byte_off, n_str, &total_bytes, st))) return rc;
         if (total_bytes == 0) return LATOK_OK;
@@ -781,7 +812,8 @@ int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int f
     if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
     if (n == 0) return LATOK_OK;
     if (!cps || !matrix_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     const uint8_t* t1 = (const uint8_t*)g.t1.p;
     const uint8_t* t2 = (const uint8_t*)g.t2cls.p;
     const uint16_t* cw = (const uint16_t*)g.cw.p;
@@ -809,7 +841,8 @@ int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64
     if (cols == 0) return LATOK_OK;
     if (!m || !idx || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
     const int n_idx = idx_ndim == 2 ? irows * icols : icols;
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         HIP_TRY(latok::launch_combine_rows((const uint8_t*)m, stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out, st));
         return LATOK_OK;
@@ -842,7 +875,8 @@ int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out,
     if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
     if (n == 0) return LATOK_OK;
     if (!a1 || !a2 || !out) return fail(LATOK_ERR_INVALID, "must specify two aligning 1d numpy array args");
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     // the block mask of ONE array pair is the batch pipeline over a single "string" [0, n) whose planes are a1 / a2
     const int64_t row[2] = {0, n};
@@ -976,7 +1010,8 @@ int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int 
     if (!buf_dev || !ms_out || bytes < 16384 || iters <= 0 || warmup < 0)
         return fail(LATOK_ERR_INVALID, "stream_read: need a device buffer of >= 16 KiB, iters > 0");
     if (((uintptr_t)buf_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device pointer must be 16-byte aligned");
-    hipStream_t st = g.stream;
+    StreamTurn turn(nullptr);
+    hipStream_t st = turn.st;
     uint32_t* sink = (uint32_t*)g.scalar.p + 8;
     for (int i = 0; i < warmup; ++i) HIP_TRY(latok::launch_stream_read(buf_dev, bytes, sink, g.n_cu, st));
     HIP_TRY(hipEventRecord(g.ev[0], st));
@@ -995,7 +1030,8 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
     if (rc) return rc;
     if (iters < 0 || warmup < 0) return fail(LATOK_ERR_INVALID, "iters and warmup must be >= 0");
     if (((uintptr_t)cps_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
-    hipStream_t st = g.stream;
+    StreamTurn turn(nullptr);
+    hipStream_t st = turn.st;
     if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
     for (int i = 0; i < warmup; ++i)
         if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;

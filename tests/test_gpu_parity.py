@@ -710,3 +710,42 @@ def test_device_pointer_forms_match_host_pointer_forms(gpu, oracle):
     finally:
         for p in (d_cps, d_row, d_u8, d_boff, d_bits, d_counts, d_items, d_feat, d_cprow):
             lib.latok_dev_free(p)
+
+
+def test_calls_on_different_streams_are_ordered(gpu, oracle):
+    """Two device-pointer calls on two caller streams share the library's workspaces: the second must wait for the first on
+    the device.  Alternate big batches between two streams without synchronising in between and check both results."""
+    import ctypes as C2
+    from latok_amd import _lib, batch
+    lib = gpu
+    hip = C2.CDLL("libamdhip64.so")
+    s1, s2 = C2.c_void_p(), C2.c_void_p()
+    assert hip.hipStreamCreate(C2.byref(s1)) == 0 and hip.hipStreamCreate(C2.byref(s2)) == 0
+    rng = random.Random(5150)
+    batches = []
+    try:
+        for i in range(2):
+            texts = random_strings(rng, 20000 + 5000 * i, 0, 90, ALPHABETS["mixed"])
+            cps, row = pack(texts)
+            d_cps = lib.latok_dev_alloc(cps.nbytes + 64)
+            d_row = lib.latok_dev_alloc(row.nbytes)
+            d_bits = lib.latok_dev_alloc(((cps.size + 63) // 64) * 8 + 8)
+            _lib.check(lib.latok_memcpy_h2d(d_cps, cps.ctypes.data, cps.nbytes))
+            _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
+            batches.append((cps, row, d_cps, d_row, d_bits))
+        _lib.check(lib.latok_sync())
+        for rep in range(6):
+            for i, st in ((0, s1), (1, s2)):
+                cps, row, d_cps, d_row, d_bits = batches[i]
+                _lib.check(lib.latok_split_mask_batch(d_cps, d_row, len(row) - 1, cps.size, d_bits, _lib.DEVICE_PTRS, st))
+        assert hip.hipStreamSynchronize(s1) == 0 and hip.hipStreamSynchronize(s2) == 0
+        for cps, row, d_cps, d_row, d_bits in batches:
+            got = np.empty((cps.size + 63) // 64, np.uint64)
+            _lib.check(lib.latok_memcpy_d2h(got.ctypes.data, d_bits, got.nbytes))
+            assert np.array_equal(got, oracle.split_batch(cps, row, want_values=False)[1])
+    finally:
+        for b in batches:
+            for p in b[2:]:
+                lib.latok_dev_free(p)
+        hip.hipStreamDestroy(s1)
+        hip.hipStreamDestroy(s2)

@@ -4,7 +4,7 @@
 Worker processes build random batches from adversarial alphabets in several shape regimes (many tiny strings, tweets,
 multi-tile documents, no-whitespace documents with starts, dense starts) and compute the oracle's split values / bitmask on
 the CPU; the main process runs the same batch through the C ABI (values, bitmask, offsets, token spans, the bitmask
-under run-time rule tables, and the UTF-8 entry points in byte space and in code-point units) and compares bit for bit.  Stops after --seconds.
+under run-time rule tables, featurize sums, and the UTF-8 entry points in byte space and in code-point units) and compares bit for bit.  Stops after --seconds.
 
 usage: tools/soak.py [--seconds 120] [--workers 12] [--seed 1]
 """
@@ -66,7 +66,23 @@ def make_batch(seed):
         assert u8.size == int(pref[-1])
         boff = np.ascontiguousarray(pref[row])
         bpos = pref[:-1]
-    return seed, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos
+    # featurize: per-token column sums from the oracle's n x 25 matrix (small batches only)
+    feats = None
+    if cps.size < 6000 and rng.random() < 0.5:
+        rows_ = []
+        for s_, t in enumerate(texts):
+            if not t:
+                continue
+            m = orc.gen_parse_matrix(t).astype(np.uint8)
+            a = int(row[s_])
+            v = vals[a:a + len(t)]
+            sp = space[a:a + len(t)]
+            nz = np.nonzero(v)[0].tolist() + [len(t)]
+            for p_, e_ in zip(nz[:-1], nz[1:]):
+                if (~sp[p_:e_]).any():
+                    rows_.append(m[p_:e_].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8))
+        feats = np.array(rows_, np.int8).reshape(-1, 25)
+    return seed, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos, feats
 
 
 def spans_from(vals, space, row):
@@ -94,14 +110,14 @@ def main():
     args = ap.parse_args()
     from latok_amd import batch
     t_end = time.time() + args.seconds
-    n_batches = n_chars = n_rules = n_spans = n_u8 = 0
+    n_batches = n_chars = n_rules = n_spans = n_u8 = n_feat = 0
     seed = args.seed * 1_000_003
     last = time.time()
     with mp.Pool(args.workers) as pool:
         pending = [pool.apply_async(make_batch, (seed + i,)) for i in range(args.workers * 2)]
         seed += len(pending)
         while pending:
-            sd, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos = pending.pop(0).get()
+            sd, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos, feats = pending.pop(0).get()
             if time.time() < t_end:
                 pending.append(pool.apply_async(make_batch, (seed,)))
                 seed += 1
@@ -127,6 +143,10 @@ def main():
                     batch.reset_rules()
                 assert np.array_equal(rb, rule_bits), "rule-table bitmask differs: " + tag
                 n_rules += 1
+            if feats is not None and cps.size > 0:
+                fc, fs, ff = batch.token_features_csr(cps, row)
+                assert ff.shape == feats.shape and np.array_equal(ff, feats), "featurize sums differ: " + tag
+                n_feat += 1
             if u8 is not None and cps.size > 0:
                 # byte space: boundaries at the lead byte of every boundary char; staged path: code-point units
                 flags = np.zeros(u8.size, bool)
@@ -145,10 +165,10 @@ def main():
             n_chars += cps.size
             if time.time() - last > 30:
                 last = time.time()
-                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8 ... ok",
+                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8, {n_feat} featurize ... ok",
                       flush=True)
     print(f"soak passed: {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
-          f"{n_u8} UTF-8 (byte space + code-point) checks, {args.seconds:.0f} s")
+          f"{n_u8} UTF-8 (byte space + code-point) checks, {n_feat} featurize checks, {args.seconds:.0f} s")
 
 
 if __name__ == "__main__":

@@ -647,7 +647,6 @@ __device__ __forceinline__ Hd64 hd_then(Hd64 x, Hd64 y) {
     return r;
 }
 
-constexpr int kScanThreads = kWPB * 64;   // one element per thread of the workgroup
 constexpr int kScanWaves = kWPB;
 
 __device__ __forceinline__ Fn64 fn_identity() { Fn64 f; f.a = 0; f.b = 0; return f; }   // identity on q >= 0
@@ -793,21 +792,26 @@ static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0, "alignment");
 
 // Both tables are contiguous in LDS ([stage1 | stage2]) and in global memory (api.cpp uploads them back to back), so the
 // copy is one stream of kTablesLdsBytes / 16 vectors; all of a thread's loads are issued before its first LDS write.
+template <int NT = kWPB * 64>
 __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) {
     constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
-    constexpr int kPer = (kVec + kWPB * 64 - 1) / (kWPB * 64);    // 4 with 768 threads
+    constexpr int kPer = (kVec + NT - 1) / NT;                    // 4 with 768 threads
     const uint4* src = reinterpret_cast<const uint4*>(P.t1);
     uint4* dst = reinterpret_cast<uint4*>(lds);
-    uint4 tmp[kPer];
+    if (kPer <= 4) {
+        uint4 tmp[kPer <= 4 ? kPer : 1];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = threadIdx.x + j * kWPB * 64;
-        if (i < kVec) tmp[j] = src[i];
-    }
+        for (int j = 0; j < (kPer <= 4 ? kPer : 1); ++j) {
+            const int i = threadIdx.x + j * NT;
+            if (i < kVec) tmp[j] = src[i];
+        }
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const int i = threadIdx.x + j * kWPB * 64;
-        if (i < kVec) dst[i] = tmp[j];
+        for (int j = 0; j < (kPer <= 4 ? kPer : 1); ++j) {
+            const int i = threadIdx.x + j * NT;
+            if (i < kVec) dst[i] = tmp[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < kVec; i += NT) dst[i] = src[i];
     }
 }
 
@@ -951,14 +955,16 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
 // by "pending at the tile end") were wrong: patches the bitmask in place for the common cases, or recomputes the tile
 // with the exact inputs (the same tile code; Unicode tables are only copied to LDS if that ever happens).
 // ---------------------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
+// NW = waves per workgroup: NW * 64 threads must cover a segment's tiles (one tile per thread).  Batches whose segments
+// are short (C2: 122 tiles) run it with 2 or 4 waves instead of 12 -- the stage is all latency, fewer waves start faster.
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsTotal];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = P.seg_tiles;
-    ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
+    ScanLdsT<NW>& scan = *reinterpret_cast<ScanLdsT<NW>*>(lds + kLdsScan);
     int* misc = reinterpret_cast<int*>(lds + kLdsMisc);          // misc[0] = number of tiles to recompute
     int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment
     int2* fix_in = reinterpret_cast<int2*>(lds + kLdsSumm);      // {q_in, tail_zero}
@@ -977,7 +983,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
         Fn64 pf = fn_identity();
         Hd64 sh = hd_identity();
         if (P.n_segs > 1) {
-            const int64_t per = (P.n_segs + kScanThreads - 1) / kScanThreads;
+            const int64_t per = (P.n_segs + NW * 64 - 1) / (NW * 64);
             const int64_t lo = min((int64_t)tid * per, P.n_segs), hi = min(lo + per, P.n_segs);
             Fn64 f = fn_identity();
             Hd64 h = hd_identity();
@@ -986,7 +992,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
                 if (j > seg) h = hd_then(h, P.seg_hd[j]);
             }
             Fn64 ef; Hd64 eh;
-            block_scan(f, h, scan, &ef, &eh, &pf, &sh);
+            block_scan<NW>(f, h, scan, &ef, &eh, &pf, &sh);
         }
         const long long q_seg_in = fn_apply(pf, 0);
         Hd64 rest; rest.h = sh.h; rest.c = 1;   // what follows the segment: sh.h starts before the next closing
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
             h.h = s.z; h.c = s.w & 1;
         }
         Fn64 ef, tfn; Hd64 eh, th;
-        block_scan(f, h, scan, &ef, &eh, &tfn, &th);   // (its barriers also publish misc[0] = 0)
+        block_scan<NW>(f, h, scan, &ef, &eh, &tfn, &th);   // (its barriers also publish misc[0] = 0)
         if (tid < n_seg) {
             const long long q_in = fn_apply(ef, q_seg_in);
             const long long q_end = fn_apply(f, q_in);
@@ -1031,12 +1037,12 @@ __global__ __launch_bounds__(kWPB * 64) void k_resolve_fix(SplitParams P) {
         const int n_fix = misc[0];
         if (n_fix > 0) {
             if (!tables_loaded && MODE != kModeBlockMask) {
-                load_tables(lds, P);
+                load_tables<NW * 64>(lds, P);
                 tables_loaded = true;
                 __syncthreads();
             }
             const TileLds L = wave_lds(lds, wave);
-            for (int i = wave; i < n_fix; i += kWPB) {
+            for (int i = wave; i < n_fix; i += NW) {
                 const int64_t tt = T0 + fix_t[i];
                 const int2 in = fix_in[i];
                 const int64_t idx0 = wave_lower_bound(P.row_off, P.n_str + 1, tt * kTile, lane);
@@ -1399,11 +1405,18 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
 
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
-    if (mode == kModeBits) hipLaunchKernelGGL((k_resolve_fix<kModeBits>), grid, block, 0, st, P);
-    else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues>), grid, block, 0, st, P);
-    else if (mode == kModeRules) hipLaunchKernelGGL((k_resolve_fix<kModeRules>), grid, block, 0, st, P);
-    else if (mode == kModeBytes) hipLaunchKernelGGL((k_resolve_fix<kModeBytes>), grid, block, 0, st, P);
-    else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask>), grid, block, 0, st, P);
+#define LATOK_RESOLVE(M)                                                                                        \
+    do {                                                                                                        \
+        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<M, 2>), grid, dim3(128), 0, st, P);           \
+        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<M, 4>), grid, dim3(256), 0, st, P);      \
+        else hipLaunchKernelGGL((k_resolve_fix<M, kWPB>), grid, block, 0, st, P);                               \
+    } while (0)
+    if (mode == kModeBits) LATOK_RESOLVE(kModeBits);
+    else if (mode == kModeValues) LATOK_RESOLVE(kModeValues);
+    else if (mode == kModeRules) LATOK_RESOLVE(kModeRules);
+    else if (mode == kModeBytes) LATOK_RESOLVE(kModeBytes);
+    else LATOK_RESOLVE(kModeBlockMask);
+#undef LATOK_RESOLVE
     return hipGetLastError();
 }
 

@@ -755,6 +755,52 @@ __device__ __forceinline__ int64_t block_lower_bound(const int64_t* __restrict__
     return lo;
 }
 
+// Both lower bounds of a segment (first string at or after c0 and at or after c1) in ONE round of loads when the row
+// offsets are roughly evenly spaced: each half of the workgroup looks at a window of row_off around the position an
+// even spacing predicts, and counts the entries below its target.  The searched k-ary form above needs 2 dependent
+// rounds per bound, and at the start of a kernel every round is a trip to HBM (the segment prologue was ~9 us of a
+// 107 us kernel).  Falls back to the search for a bound that is not inside its window.  scratch: >= 2 * waves ints.
+template <int NT>
+__device__ __forceinline__ void block_lower_bound_pair(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t total,
+                                                       int64_t c0, int64_t c1, int* scratch, int64_t* lb0, int64_t* lb1) {
+    constexpr int kHalf = NT / 2, kE = 8, kWin = kHalf * kE;     // 384 threads x 8 entries = 3072 per window
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int which = tid >= kHalf;
+    const int64_t c = which ? c1 : c0;
+    int64_t guess = total > 0 ? (int64_t)((double)c * (double)(n_entries - 1) / (double)total) : 0;
+    int64_t wlo = guess - kWin / 2;
+    if (wlo > n_entries - kWin) wlo = n_entries - kWin;
+    if (wlo < 0) wlo = 0;
+    const int64_t e0 = wlo + (int64_t)(tid - which * kHalf) * kE;
+    int below = 0;
+#pragma unroll
+    for (int j = 0; j < kE; ++j)
+        if (e0 + j < n_entries && row_off[e0 + j] < c) ++below;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = below;
+    __syncthreads();
+    int cnt[2] = {0, 0};
+    for (int w = 0; w < NT / 64; ++w) cnt[w >= kHalf / 64] += scratch[w];
+    int64_t res[2];
+    bool ok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t ck = k ? c1 : c0;
+        int64_t g = total > 0 ? (int64_t)((double)ck * (double)(n_entries - 1) / (double)total) : 0;
+        int64_t lo = g - kWin / 2;
+        if (lo > n_entries - kWin) lo = n_entries - kWin;
+        if (lo < 0) lo = 0;
+        const int64_t hi = min(lo + kWin, n_entries);
+        res[k] = lo + cnt[k];
+        ok[k] = (cnt[k] > 0 || lo == 0) && (lo + cnt[k] < hi || hi == n_entries);   // the bound lies inside the window
+    }
+    __syncthreads();   // scratch is reused by the fallback
+    *lb0 = ok[0] ? res[0] : block_lower_bound(row_off, n_entries, c0, scratch);
+    *lb1 = ok[1] ? res[1] : block_lower_bound(row_off, n_entries, c1, scratch);
+}
+
 __device__ __forceinline__ int64_t wave_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
                                                     int lane) {
     int64_t lo = 0, hi = n_entries;
@@ -856,12 +902,13 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     const int64_t T1 = min(T0 + S, P.n_tiles);
     const int n_seg = (int)(T1 - T0);
     // (a) first string of the segment, then of each of its tiles
-    const int64_t s_lo = to_scalar64(block_lower_bound(P.row_off, P.n_str + 1, T0 * kTile, misc));
+    int64_t lb0, lb1;
+    block_lower_bound_pair<kWPB * 64>(P.row_off, P.n_str + 1, P.total, T0 * kTile, T1 * kTile, misc, &lb0, &lb1);
+    const int64_t s_lo = to_scalar64(lb0);
     {
-        // the strings that matter end with the first one that starts at or after the segment's end: found with a second
-        // search, so that the fill below is one barrier-free pass (a chunked scan with a barrier per 768 strings cost
-        // ~4 us per segment of tweet-sized strings)
-        const int64_t s_hi = to_scalar64(block_lower_bound(P.row_off, P.n_str + 1, T1 * kTile, misc));
+        // the strings that matter end with the first one that starts at or after the segment's end; the fill is one
+        // barrier-free pass over them
+        const int64_t s_hi = to_scalar64(lb1);
         for (int64_t s = s_lo + tid; s <= s_hi && s <= P.n_str; s += kWPB * 64) {
             const int64_t p = P.row_off[s];
             const int64_t prev = s > 0 ? P.row_off[s - 1] : -1;

@@ -110,7 +110,7 @@ struct Ctx {
     // pipeline workspace (sized by tiles)
     DevBuf summ, seg_agg, fix_count;
     // staging for host-pointer calls and for the offsets API
-    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, counts, bases, scan_tot, scalar, h_aux, tile_first;
+    DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, wpref, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -335,7 +335,7 @@ int latok_shutdown(void) {
     g.pin.release();
     g.pin_tot.release();
     g.rules_on = false;
-    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
                       &g.h_aux})
         b->release();
     for (auto& e : g.ev) {
@@ -481,8 +481,8 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
 
 // featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
 static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
-                            const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_first, int8_t* d_feat,
-                            hipStream_t st) {
+                            const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt, const uint16_t* d_pref,
+                            const int64_t* d_tile_first, int8_t* d_feat, hipStream_t st) {
     latok::FeatParams F;
     F.cps = d_cps;
     F.row_off = d_row;
@@ -492,7 +492,9 @@ static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t
     F.t1 = (const uint8_t*)g.t1rule.p;
     F.bits = d_bits;
     F.kept = d_kept;
-    F.word_rank = d_rank;
+    F.tile_rank = d_rank;
+    F.tile_cnt = d_tile_cnt;
+    F.word_pref = d_pref;
     F.tile_first = d_tile_first;
     F.features = d_feat;
     HIP_TRY(latok::launch_features_tiles(F, g.n_cu, st));
@@ -580,10 +582,12 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
     if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
     if (spans && (rc = g.kept.ensure((size_t)words * 8 + 8))) return rc;
-    if ((rc = g.wcnt.ensure((size_t)words * 8 + 8))) return rc;
-    if ((rc = g.bases.ensure((size_t)words * 8 + 8))) return rc;
+    const int64_t c_tiles = (words + 63) / 64;
+    if ((rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
+    if ((rc = g.bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
+    if ((rc = g.wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
     if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
-    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(words) * 8))) return rc;
+    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(c_tiles) * 8))) return rc;
     uint64_t* d_bits = (uint64_t*)g.bits.p;
     uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
     uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
@@ -594,20 +598,22 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
                            nullptr, nullptr, d_space, d_tile_first, d_u8)))
         return rc;
-    HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, st));
+    const int64_t* d_tcnt = (const int64_t*)g.wcnt.p;
+    const uint16_t* d_pref = (const uint16_t*)g.wpref.p;
+    HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, (uint16_t*)g.wpref.p, st));
     int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
     if ((rc = g.pin_tot.ensure(64))) return rc;
-    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, words, d_rank, d_total, (int64_t*)g.scan_tot.p, st,
+    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, c_tiles, d_rank, d_total, (int64_t*)g.scan_tot.p, st,
                                          small ? nullptr : (int64_t*)g.pin_tot.d));
     int64_t* d_counts = dev ? counts_out : (small ? (int64_t*)((char*)g.pin.d + po_counts) : (int64_t*)g.counts.p);
-    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_row, n_str, total, d_total, d_counts, st));
+    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, st));
     if (small) {
         // the scatter cannot overrun: the pinned item area holds one item per char, the most there can be
         int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
-        HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total,
-                                           d_row, n_str, d_tile_first, d_items, st));
-        if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
+        HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words,
+                                           total, d_row, n_str, d_tile_first, d_items, st));
+        if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_feat, st)))
             return rc;
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t n_small = *(const int64_t*)((char*)g.pin.h + po_n);
@@ -637,9 +643,9 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
             d_feat = (int8_t*)g.h_aux.p;
         }
     }
-    HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, words, total, d_row,
-                                       n_str, d_tile_first, d_items, st));
-    if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tile_first, d_feat, st)))
+    HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
+                                       d_row, n_str, d_tile_first, d_items, st));
+    if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_feat, st)))
         return rc;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));

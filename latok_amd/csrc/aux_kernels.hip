@@ -183,8 +183,35 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(int64_t* __restrict__ o
         if (base + j < n) out[base + j] += add;
 }
 
+// the whole scan in one workgroup (each thread owns a contiguous run): for the tile-level arrays (n = chars / 4096)
+__global__ __launch_bounds__(kScanBlock) void k_scan_small(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                                           int64_t* __restrict__ total, int64_t* __restrict__ total_host) {
+    __shared__ long long lds[kScanBlock / 64];
+    const int64_t per = (n + kScanBlock - 1) / kScanBlock;
+    const int64_t lo = min((int64_t)threadIdx.x * per, n), hi = min(lo + per, n);
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += in[i];
+    long long tot;
+    long long run = block_exclusive_scan_ll(sum, &tot, lds);
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) {
+        *total = tot;
+        if (total_host) *total_host = tot;
+    }
+}
+
+constexpr int64_t kScanSmallMax = 4096;   // beyond that one workgroup is slower than three launches over many
+
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
                                  hipStream_t st, int64_t* total_host) {
+    if (n <= kScanSmallMax) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, st, in, n, out, total, total_host);
+        return hipGetLastError();
+    }
     const int64_t n_blocks = scan_blocks(n);
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, in, n, out, block_tot);
     hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(kScanBlock), 0, st, block_tot, n_blocks, total, total_host);

@@ -85,46 +85,64 @@ __device__ __forceinline__ bool tail_has_nonspace(const uint64_t* __restrict__ b
     return false;
 }
 
+// One wave per 4096-char tile, lane = word: the tile's item count (-> a scan over TILES, 64x fewer elements than
+// words) and every word's exclusive prefix inside its tile (uint16).  rank(word) = tile_rank[tile] + word_pref[word].
 template <bool SPANS>
-__global__ void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, int64_t n_words,
-                              int64_t total, uint64_t* __restrict__ kept_out, int64_t* __restrict__ cnt) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    const uint64_t x = bits[w];
-    if (!SPANS) {
-        cnt[w] = __popcll(x);
-        return;
-    }
-    const uint64_t nn = ~space[w] & valid_mask(w, total);   // non-SPACE chars of the word
-    uint64_t kept = 0, rest = x;
-    while (rest) {
-        const int b = __builtin_ctzll(rest);
-        rest &= rest - 1;
-        const uint64_t from_b = ~0ull << b;
-        if (rest) {   // the token ends at the next boundary of this word
-            const uint64_t seg = from_b & ((rest & (~rest + 1ull)) - 1ull);
-            if (nn & seg) kept |= 1ull << b;
-        } else if ((nn & from_b) || tail_has_nonspace(bits, space, w, n_words, total)) {
-            kept |= 1ull << b;
+__global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                                                     int64_t n_words, int64_t total, uint64_t* __restrict__ kept_out,
+                                                     int64_t* __restrict__ tile_cnt, uint16_t* __restrict__ word_pref) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t w = t * 64 + lane;
+    if (t * 64 >= n_words) return;   // whole wave
+    int cnt = 0;
+    if (w < n_words) {
+        const uint64_t x = bits[w];
+        if (!SPANS) {
+            cnt = __popcll(x);
+        } else {
+            const uint64_t nn = ~space[w] & valid_mask(w, total);   // non-SPACE chars of the word
+            uint64_t kept = 0, rest = x;
+            while (rest) {
+                const int b = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                const uint64_t from_b = ~0ull << b;
+                if (rest) {   // the token ends at the next boundary of this word
+                    const uint64_t seg = from_b & ((rest & (~rest + 1ull)) - 1ull);
+                    if (nn & seg) kept |= 1ull << b;
+                } else if ((nn & from_b) || tail_has_nonspace(bits, space, w, n_words, total)) {
+                    kept |= 1ull << b;
+                }
+            }
+            kept_out[w] = kept;
+            cnt = __popcll(kept);
         }
     }
-    kept_out[w] = kept;
-    cnt[w] = __popcll(kept);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (w < n_words) word_pref[w] = (uint16_t)(inc - cnt);
+    if (lane == 63) tile_cnt[t] = inc;
 }
 
 // ---- pass 2: items per string = rank(row_off[s+1]) - rank(row_off[s]) ------------------------------------------------
-__device__ __forceinline__ int64_t rank_at(const uint64_t* __restrict__ mask, const int64_t* __restrict__ word_rank,
-                                           int64_t x, int64_t total, int64_t n_items) {
+__device__ __forceinline__ int64_t rank_at(const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
+                                           const uint16_t* __restrict__ word_pref, int64_t x, int64_t total, int64_t n_items) {
     if (x >= total) return n_items;
-    return word_rank[x >> 6] + __popcll(mask[x >> 6] & low_mask((int)(x & 63)));
+    const int64_t w = x >> 6;
+    return tile_rank[w >> 6] + word_pref[w] + __popcll(mask[w] & low_mask((int)(x & 63)));
 }
-__global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t* __restrict__ word_rank,
-                                const int64_t* __restrict__ row_off, int64_t n_str, int64_t total,
-                                const int64_t* __restrict__ n_items, int64_t* __restrict__ counts) {
+__global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
+                                const uint16_t* __restrict__ word_pref, const int64_t* __restrict__ row_off, int64_t n_str,
+                                int64_t total, const int64_t* __restrict__ n_items, int64_t* __restrict__ counts) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_str) return;
     const int64_t n = *n_items;
-    counts[s] = rank_at(mask, word_rank, row_off[s + 1], total, n) - rank_at(mask, word_rank, row_off[s], total, n);
+    counts[s] = rank_at(mask, tile_rank, word_pref, row_off[s + 1], total, n) -
+                rank_at(mask, tile_rank, word_pref, row_off[s], total, n);
 }
 
 // ---- pass 3 --------------------------------------------------------------------------------------------------------
@@ -164,8 +182,9 @@ __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict
 template <int KIND>
 __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
     const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
-    const int64_t* __restrict__ word_rank, int64_t n_words, int64_t total, const int64_t* __restrict__ row_off,
-    int64_t n_str, const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
+    const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
+    int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
+    const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
     constexpr int kVals = KIND == 0 ? 1 : (KIND == 1 ? 2 : 4);      // int64 values per item
     constexpr int kWin = KIND == 2 ? kScatterWin : kScatterWin;     // int64 slots of one wave's window
     constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
@@ -175,18 +194,11 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
     const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
     if (w0 >= n_words) return;                                      // whole wave (no block-wide barrier is used below)
     const int64_t w = w0 + lane;
-    const uint64_t x = w < n_words ? item_mask[w] : 0ull;
-    const int cnt = __popcll(x);
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    const int n_wave = __shfl(inc, 63);
+    const int n_wave = (int)tile_cnt[w0 >> 6];
     if (n_wave == 0) return;
-    const int off = inc - cnt;                                      // rank of my first item inside the wave
-    const int64_t base_out = __shfl(w < n_words ? word_rank[w] : 0, 0);   // lane 0's word always exists
+    const uint64_t x = w < n_words ? item_mask[w] : 0ull;
+    const int off = w < n_words ? (int)word_pref[w] : 0;            // rank of my first item inside the wave
+    const int64_t base_out = tile_rank[w0 >> 6];
     int64_t* win = win_s[wave];
     long long* smax = smax_s[wave];
 
@@ -305,37 +317,39 @@ __global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
 hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
-                              uint64_t* kept, int64_t* cnt, hipStream_t st) {
+                              uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_words + 255) / 256)), block(256);
-    if (spans) hipLaunchKernelGGL((k_word_counts<true>), grid, block, 0, st, bits, space, n_words, total, kept, cnt);
-    else hipLaunchKernelGGL((k_word_counts<false>), grid, block, 0, st, bits, space, n_words, total, kept, cnt);
+    const int64_t n_tiles = (n_words + 63) / 64;
+    const dim3 grid((unsigned)((n_tiles + 3) / 4)), block(256);
+    if (spans) hipLaunchKernelGGL((k_word_counts<true>), grid, block, 0, st, bits, space, n_words, total, kept, tile_cnt, word_pref);
+    else hipLaunchKernelGGL((k_word_counts<false>), grid, block, 0, st, bits, space, n_words, total, kept, tile_cnt, word_pref);
     return hipGetLastError();
 }
 
-hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, const int64_t* row_off, int64_t n_str,
-                                int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st) {
+hipError_t launch_string_counts(const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref, const int64_t* row_off,
+                                int64_t n_str, int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st) {
     if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_string_counts, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, mask, word_rank, row_off,
-                       n_str, total, n_items, counts);
+    hipLaunchKernelGGL(k_string_counts, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, mask, tile_rank, word_pref,
+                       row_off, n_str, total, n_items, counts);
     return hipGetLastError();
 }
 
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
-                               const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, const int64_t* tile_first, int64_t* out, hipStream_t st) {
+                               const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
+                               int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, int64_t* out,
+                               hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
     const int64_t per_block = (int64_t)kScatterWaves * 64;
     const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(kScatterWaves * 64);
     if (kind == 0)
-        hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out);
+        hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
+                           total, row_off, n_str, tile_first, out);
     else if (kind == 1)
-        hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out);
+        hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
+                           total, row_off, n_str, tile_first, out);
     else
-        hipLaunchKernelGGL((k_word_scatter<2>), grid, block, 0, st, bits, space, item_mask, word_rank, n_words, total,
-                           row_off, n_str, tile_first, out);
+        hipLaunchKernelGGL((k_word_scatter<2>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
+                           total, row_off, n_str, tile_first, out);
     return hipGetLastError();
 }
 

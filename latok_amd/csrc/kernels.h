@@ -72,7 +72,9 @@ struct FeatParams {
     const uint8_t* t1;            // [stage-1 | stage-2 rule codes], contiguous (global memory)
     const uint64_t* bits;         // final boundary bitmask
     const uint64_t* kept;         // boundaries whose token is kept (k_word_counts<true>)
-    const int64_t* word_rank;     // exclusive scan of popcount(kept): index of a word's first token
+    const int64_t* tile_rank;     // index of a tile's first token (exclusive scan of the per-tile token counts)
+    const int64_t* tile_cnt;      // tokens per tile
+    const uint16_t* word_pref;    // tokens of the tile before each word
     const int64_t* tile_first;    // per tile: first string that starts at or after its first char
     int8_t* features;             // [n_tokens][25]
 };
@@ -93,12 +95,13 @@ hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int
                                  hipStream_t st, int64_t* total_host = nullptr);
 // compact_kernels.hip: word-parallel compaction (offsets / token spans / featurize spans)
 hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
-                              uint64_t* kept, int64_t* cnt, hipStream_t st);
-hipError_t launch_string_counts(const uint64_t* mask, const int64_t* word_rank, const int64_t* row_off, int64_t n_str,
-                                int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
+                              uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, hipStream_t st);
+hipError_t launch_string_counts(const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref, const int64_t* row_off,
+                                int64_t n_str, int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
 hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
-                               const int64_t* word_rank, int64_t n_words, int64_t total, const int64_t* row_off,
-                               int64_t n_str, const int64_t* tile_first, int64_t* out, hipStream_t st);
+                               const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
+                               int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, int64_t* out,
+                               hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

@@ -1174,18 +1174,11 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     const int64_t total = P.total;
     const int64_t n_words = (total + 63) >> 6;
     const int64_t w = t * 64 + lane;
-    const lk_u64 x = w < n_words ? P.kept[w] : 0ull;          // kept tokens that start in my word
-    const int cnt = lk_popc(x);
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    const int n_wave = __shfl(inc, 63);
+    const int n_wave = (int)P.tile_cnt[t];
     if (n_wave == 0) return;
-    const int off = inc - cnt;
-    const int64_t base_out = lane_read64(w < n_words ? P.word_rank[w] : 0, 0);
+    const lk_u64 x = w < n_words ? P.kept[w] : 0ull;          // kept tokens that start in my word
+    const int off = w < n_words ? (int)P.word_pref[w] : 0;
+    const int64_t base_out = P.tile_rank[t];
     const lk_u64 xb = w < n_words ? P.bits[w] : 0ull;         // all boundaries of my word
 
     // ---- classify the tile into rule codes (mirror of process_tile phase 1) ---------------------------------------

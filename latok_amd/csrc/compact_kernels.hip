@@ -155,8 +155,10 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
 // KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
 // KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end} (featurize; the sums come from k_features_tiles).
-constexpr int kScatterWaves = 4;                 // waves per workgroup
-constexpr int kScatterWin = 1024;                // int64 slots of one wave's LDS window (8 KiB)
+// waves per workgroup / int64 slots of one wave's LDS window (8 KiB), per KIND.  Windows that hold a whole tile's records
+// for the 16- and 32-byte kinds (2048 / 4096 slots, fewer waves per CU) were measured: fewer rounds, but slower overall.
+constexpr int scatter_waves(int kind) { return 4; }
+constexpr int scatter_win(int kind) { return 1024; }
 
 __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
                                                        int lane) {
@@ -180,13 +182,14 @@ __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kScatterWaves * 64) void k_word_scatter(
+__global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
     const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
     constexpr int kVals = KIND == 0 ? 1 : (KIND == 1 ? 2 : 4);      // int64 values per item
-    constexpr int kWin = KIND == 2 ? kScatterWin : kScatterWin;     // int64 slots of one wave's window
+    constexpr int kScatterWaves = scatter_waves(KIND);
+    constexpr int kWin = scatter_win(KIND);                         // int64 slots of one wave's window
     constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
     __shared__ int64_t win_s[kScatterWaves][kWin];
     __shared__ long long smax_s[kScatterWaves][65];
@@ -339,8 +342,8 @@ hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* s
                                int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, int64_t* out,
                                hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
-    const int64_t per_block = (int64_t)kScatterWaves * 64;
-    const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(kScatterWaves * 64);
+    const int64_t per_block = (int64_t)scatter_waves(kind) * 64;
+    const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(scatter_waves(kind) * 64);
     if (kind == 0)
         hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
                            total, row_off, n_str, tile_first, out);

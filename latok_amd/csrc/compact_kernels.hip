@@ -96,27 +96,37 @@ __global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict_
     const int64_t w = t * 64 + lane;
     if (t * 64 >= n_words) return;   // whole wave
     int cnt = 0;
-    if (w < n_words) {
-        const uint64_t x = bits[w];
-        if (!SPANS) {
-            cnt = __popcll(x);
-        } else {
-            const uint64_t nn = ~space[w] & valid_mask(w, total);   // non-SPACE chars of the word
-            uint64_t kept = 0, rest = x;
-            while (rest) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                const uint64_t from_b = ~0ull << b;
-                if (rest) {   // the token ends at the next boundary of this word
-                    const uint64_t seg = from_b & ((rest & (~rest + 1ull)) - 1ull);
-                    if (nn & seg) kept |= 1ull << b;
-                } else if ((nn & from_b) || tail_has_nonspace(bits, space, w, n_words, total)) {
-                    kept |= 1ull << b;
-                }
-            }
-            kept_out[w] = kept;
-            cnt = __popcll(kept);
+    const uint64_t x = w < n_words ? bits[w] : 0ull;
+    if (!SPANS) {
+        cnt = __popcll(x);
+    } else {
+        const uint64_t nn = w < n_words ? (~space[w] & valid_mask(w, total)) : 0ull;   // non-SPACE chars of the word
+        // the next word's masks from the neighbour lane (lane 63: from memory): the word's last token normally ends there
+        uint64_t x1 = __shfl_down(x, 1), nn1 = __shfl_down(nn, 1);
+        if (lane == 63) {
+            const bool has = w + 1 < n_words;
+            x1 = has ? bits[w + 1] : 0ull;
+            nn1 = has ? (~space[w + 1] & valid_mask(w + 1, total)) : 0ull;
         }
+        uint64_t kept = 0, rest = x;
+        while (rest) {
+            const int b = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            const uint64_t from_b = ~0ull << b;
+            bool k;
+            if (rest) {   // the token ends at the next boundary of this word
+                k = (nn & from_b & ((rest & (~rest + 1ull)) - 1ull)) != 0;
+            } else if (nn & from_b) {
+                k = true;
+            } else if (x1) {   // it ends at the first boundary of the next word
+                k = (nn1 & ((x1 & (~x1 + 1ull)) - 1ull)) != 0;
+            } else {
+                k = nn1 != 0 || (w + 1 < n_words && tail_has_nonspace(bits, space, w + 1, n_words, total));
+            }
+            if (k) kept |= 1ull << b;
+        }
+        if (w < n_words) kept_out[w] = kept;
+        cnt = __popcll(kept);
     }
     int inc = cnt;
 #pragma unroll

@@ -1442,18 +1442,19 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
 
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
-#define LATOK_RESOLVE(M)                                                                                        \
-    do {                                                                                                        \
-        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<M, 2>), grid, dim3(128), 0, st, P);           \
-        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<M, 4>), grid, dim3(256), 0, st, P);      \
-        else hipLaunchKernelGGL((k_resolve_fix<M, kWPB>), grid, block, 0, st, P);                               \
-    } while (0)
-    if (mode == kModeBits) LATOK_RESOLVE(kModeBits);
-    else if (mode == kModeValues) LATOK_RESOLVE(kModeValues);
-    else if (mode == kModeRules) LATOK_RESOLVE(kModeRules);
-    else if (mode == kModeBytes) LATOK_RESOLVE(kModeBytes);
-    else LATOK_RESOLVE(kModeBlockMask);
-#undef LATOK_RESOLVE
+    // The bitmask mode repairs almost everything in place, so its resolve stage is pure latency and runs with as few
+    // waves as cover a segment; the modes that recompute tiles keep all 12 waves for that.
+    if (mode == kModeBits) {
+        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeBits, 2>), grid, dim3(128), 0, st, P);
+        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeBits, 4>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((k_resolve_fix<kModeBits, kWPB>), grid, block, 0, st, P);
+    } else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeRules) hipLaunchKernelGGL((k_resolve_fix<kModeRules, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeBytes) {   // (ASCII tiles are repaired in place here too; measured better with few waves on C2 and C3)
+        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 2>), grid, dim3(128), 0, st, P);
+        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 4>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((k_resolve_fix<kModeBytes, kWPB>), grid, block, 0, st, P);
+    } else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask, kWPB>), grid, block, 0, st, P);
     return hipGetLastError();
 }
 

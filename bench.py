@@ -220,7 +220,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 code points -> u64 bitmask (integer/bit ops)", "data": "synthetic",
+            "dtype": "u64", "dtype_note": "u32 code points in, 64-bit bit-sliced boolean words, u64 bitmask out (integer / bit ops)",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "strings_per_gpu": n_str, "strings_total": strs_all,
                        "chars_total": chars_all, "utf8_bytes_total": utf8_all, "sharding": f"{world} x independent string shards"},
             "ms_per_step_hip_events_rank0": ms_events.value / args.steps,

@@ -481,8 +481,9 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
 
 // featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
 static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
-                            const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt, const uint16_t* d_pref,
-                            const int64_t* d_tile_first, int8_t* d_feat, hipStream_t st) {
+                            const uint64_t* d_space, const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt,
+                            const uint16_t* d_pref, const int64_t* d_tile_first, int64_t* d_spans4, int8_t* d_feat,
+                            hipStream_t st) {
     latok::FeatParams F;
     F.cps = d_cps;
     F.row_off = d_row;
@@ -496,7 +497,9 @@ static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t
     F.tile_cnt = d_tile_cnt;
     F.word_pref = d_pref;
     F.tile_first = d_tile_first;
+    F.space = d_space;
     F.features = d_feat;
+    F.spans4 = d_spans4;
     HIP_TRY(latok::launch_features_tiles(F, g.n_cu, st));
     return LATOK_OK;
 }
@@ -611,10 +614,14 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         // the scatter cannot overrun: the pinned item area holds one item per char, the most there can be
         int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
-        HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words,
-                                           total, d_row, n_str, d_tile_first, d_items, st));
-        if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_feat, st)))
-            return rc;
+        if (feats) {   // spans and sums come from one kernel
+            if ((rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
+                                       d_items, d_feat, st)))
+                return rc;
+        } else {
+            HIP_TRY(latok::launch_word_scatter(spans ? 1 : 0, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
+                                               d_row, n_str, d_tile_first, d_items, st));
+        }
         HIP_TRY(hipStreamSynchronize(st));
         const int64_t n_small = *(const int64_t*)((char*)g.pin.h + po_n);
         *n_items_out = n_small;
@@ -643,10 +650,14 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
             d_feat = (int8_t*)g.h_aux.p;
         }
     }
-    HIP_TRY(latok::launch_word_scatter(feats ? 2 : (spans ? 1 : 0), d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
-                                       d_row, n_str, d_tile_first, d_items, st));
-    if (feats && (rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_feat, st)))
-        return rc;
+    if (feats) {   // spans and sums come from one kernel
+        if ((rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
+                                   d_feat, st)))
+            return rc;
+    } else {
+        HIP_TRY(latok::launch_word_scatter(spans ? 1 : 0, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total, d_row,
+                                           n_str, d_tile_first, d_items, st));
+    }
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
         if (feats) HIP_TRY(hipMemcpyAsync(features_out, d_feat, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));

@@ -16,54 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bitscan.h"
 #include "kernels.h"
 
 namespace latok {
-
-__device__ __forceinline__ uint64_t low_mask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
-
-// first set bit of `bits` at a position in [from, limit), or `limit`
-__device__ __forceinline__ int64_t next_set_bit(const uint64_t* __restrict__ bits, int64_t from, int64_t limit) {
-    for (int64_t w = from >> 6; from < limit; ++w) {
-        uint64_t x = bits[w];
-        const int64_t base = w << 6;
-        if (from > base) x &= ~0ull << (from - base);
-        if (x) {
-            const int64_t p = base + __builtin_ctzll(x);
-            return p < limit ? p : limit;
-        }
-        from = base + 64;
-    }
-    return limit;
-}
-// first position in [from, to) whose bit is 0, or `to`
-__device__ __forceinline__ int64_t next_zero_bit(const uint64_t* __restrict__ bits, int64_t from, int64_t to) {
-    for (int64_t w = from >> 6; from < to; ++w) {
-        uint64_t x = ~bits[w];
-        const int64_t base = w << 6;
-        if (from > base) x &= ~0ull << (from - base);
-        if (x) {
-            const int64_t p = base + __builtin_ctzll(x);
-            return p < to ? p : to;
-        }
-        from = base + 64;
-    }
-    return to;
-}
-// last position in [from, to) whose bit is 0, plus one; `from` if none
-__device__ __forceinline__ int64_t prev_zero_end(const uint64_t* __restrict__ bits, int64_t from, int64_t to) {
-    for (int64_t w = (to - 1) >> 6; to > from; --w) {
-        uint64_t x = ~bits[w];
-        const int64_t base = w << 6;
-        if (to < base + 64) x &= (1ull << (to - base)) - 1ull;
-        if (x) {
-            const int64_t p = base + 63 - __builtin_clzll(x);
-            return p >= from ? p + 1 : from;
-        }
-        to = base;
-    }
-    return from;
-}
 
 // ---- pass 1 --------------------------------------------------------------------------------------------------------
 // SPANS = false: items = boundary bits.  SPANS = true: items = boundaries whose token is kept; the kept-mask word is
@@ -164,7 +120,7 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 //       word's end follows the masks further) and puts the records into an LDS window at their rank inside the wave;
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
 // KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
-// KIND 2: spans[4k..] = {raw start, raw end, stripped start, stripped end} (featurize; the sums come from k_features_tiles).
+// (featurize writes its 4-value span records from k_features_tiles, together with the sums)
 // waves per workgroup / int64 slots of one wave's LDS window (8 KiB), per KIND.  Windows that hold a whole tile's records
 // for the 16- and 32-byte kinds (2048 / 4096 slots, fewer waves per CU) were measured: fewer rounds, but slower overall.
 constexpr int scatter_waves(int kind) { return 4; }
@@ -197,7 +153,7 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
     const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
-    constexpr int kVals = KIND == 0 ? 1 : (KIND == 1 ? 2 : 4);      // int64 values per item
+    constexpr int kVals = KIND == 0 ? 1 : 2;                        // int64 values per item
     constexpr int kScatterWaves = scatter_waves(KIND);
     constexpr int kWin = scatter_win(KIND);                         // int64 slots of one wave's window
     constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
@@ -292,15 +248,9 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
                     a2 = seg ? base + __builtin_ctzll(seg) : next_zero_bit(space, base + 64, e);
                     e2 = prev_zero_end(space, a2, e);
                 }
-                if (KIND == 1) {
-                    rec[0] = a2 - lo;
-                    rec[1] = e2 - lo;
-                } else {
-                    rec[0] = p - lo;
-                    rec[1] = e - lo;
-                    rec[2] = a2 - lo;
-                    rec[3] = e2 - lo;
-                }
+                (void)e;
+                rec[0] = a2 - lo;
+                rec[1] = e2 - lo;
             }
             ++k;
         }
@@ -357,11 +307,8 @@ hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* s
     if (kind == 0)
         hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
                            total, row_off, n_str, tile_first, out);
-    else if (kind == 1)
-        hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
-                           total, row_off, n_str, tile_first, out);
     else
-        hipLaunchKernelGGL((k_word_scatter<2>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
+        hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
                            total, row_off, n_str, tile_first, out);
     return hipGetLastError();
 }

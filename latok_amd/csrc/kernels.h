@@ -76,7 +76,9 @@ struct FeatParams {
     const int64_t* tile_cnt;      // tokens per tile
     const uint16_t* word_pref;    // tokens of the tile before each word
     const int64_t* tile_first;    // per tile: first string that starts at or after its first char
+    const uint64_t* space;        // SPACE bitmask (only walked for tokens that span more than two words)
     int8_t* features;             // [n_tokens][25]
+    int64_t* spans4;              // [n_tokens][4] = {raw start, raw end, stripped start, stripped end}, string relative
 };
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
 

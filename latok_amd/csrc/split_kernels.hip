@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "bitscan.h"
 #include "kernels.h"
 #include "lane_math.h"
 #include "utf8_decode.h"
@@ -1162,12 +1163,13 @@ __device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint3
 // each with a window for kFeatRound tokens (a 4096-char tile of word-soup text has ~830), which doubles as the
 // code-byte staging buffer before the planes are built.
 constexpr int kFeatWaves = 4;
-constexpr int kFeatRound = 1024;
-constexpr int kFeatWaveLds = kFeatRound * 25 + 16 + 66 * 8;           // window | halo | string-start words
+constexpr int kFeatRound = 896;                                       // tokens per round
+constexpr int kFeatWinBytes = kFeatRound * 32;                        // holds 25-byte feature records, then 32-byte span records
+constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | halo | string-start words
 constexpr int kFeatLdsTotal = kTablesLdsBytes + kFeatWaves * kFeatWaveLds;
-static_assert(kFeatRound * 25 >= kStageBytes, "the window doubles as the staging buffer");
+static_assert(kFeatWinBytes >= kStageBytes, "the window doubles as the staging buffer");
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
-static_assert((kFeatRound * 25) % 16 == 0 && kFeatWaveLds % 16 == 0, "alignment");
+static_assert(kFeatWinBytes % 16 == 0 && kFeatWaveLds % 16 == 0, "alignment");
 
 __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds& L, int64_t t, int lane) {
     const int64_t t0 = t * kTile;
@@ -1184,6 +1186,8 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // ---- classify the tile into rule codes (mirror of process_tile phase 1) ---------------------------------------
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);
     int64_t idx0 = P.tile_first[t];
+    // start of the string that is open when the tile begins (spans are string relative)
+    const int64_t start_before = idx0 > 0 ? P.row_off[idx0 - 1] : 0;
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     uint32_t halo_cp = 0xFFFFFFFFu;
     if (lane < 3) {
@@ -1259,6 +1263,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #pragma unroll
     for (int j = 0; j < 7; ++j) C.v[j] = 0;
     bool open = need_tail;                                     // still collecting
+    lk_u64 xb_next_tile = 0, nn_next_tile = 0;                 // boundary / non-SPACE masks of the next tile's first word
     for (int d = 1; d < 64; ++d) {
         if (!__ballot(open && lane + d < 64)) break;
         FeatSums Hs;
@@ -1297,6 +1302,8 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         const lk_u64 xb65 = (q0 >> 6) < n_words ? P.bits[q0 >> 6] : 0ull;
         const lk_u64 hm65 = (xb65 ? ((xb65 & (~xb65 + 1ull)) - 1ull) : ~0ull) & valid65;
         const FeatSums H65 = feat_popc(F65, hm65);
+        xb_next_tile = xb65;
+        nn_next_tile = ~LK_PLANE_GET(F65, 5) & valid65;
         if (open) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) C.v[j] = swar_add_u8(C.v[j], H65.v[j]);
@@ -1378,6 +1385,76 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         if (lane < n_bytes - tail0) dst[tail0 + lane] = win[tail0 + lane];
         wave_lds_sync();
     }
+
+    // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
+    // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
+    const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
+    lk_u64 xb1 = __shfl_down(xb, 1), nn1 = __shfl_down(nn, 1);  // the next word's masks
+    if (lane == 63) { xb1 = xb_next_tile; nn1 = nn_next_tile; }
+    // start of the string that is open at my word's first char: the last string start before my word inside the tile,
+    // else the one that was open when the tile began
+    int last_b = B ? 64 * lane + 63 - __builtin_clzll(B) : -1;  // tile-relative position of my word's last string start
+    int carry = last_b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(carry, d);
+        if (lane >= d && o > carry) carry = o;
+    }
+    carry = __shfl_up(carry, 1);
+    if (lane == 0) carry = -1;
+    const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
+    int64_t* swin = reinterpret_cast<int64_t*>(L.stage);
+    rest = x;
+    k = off;
+    for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
+        while (rest && k < win0 + kFeatRound) {
+            const int b = lk_ctz(rest);
+            rest &= rest - 1;
+            const int64_t p = base + b;
+            const lk_u64 bl = B & ((2ull << b) - 1ull);         // string starts at or before the token (b = 63: all)
+            const int64_t lo = bl ? base + 63 - __builtin_clzll(bl) : lo_in;
+            const lk_u64 above = xb & (~1ull << b);
+            int64_t e, a2, e2;
+            if (above) {
+                const int eb = lk_ctz(above);
+                const lk_u64 seg = nn & (~0ull << b) & ((1ull << eb) - 1ull);
+                e = base + eb;
+                a2 = base + lk_ctz(seg);
+                e2 = base + 64 - __builtin_clzll(seg);
+            } else if (xb1) {
+                const int eb = lk_ctz(xb1);
+                const lk_u64 seg0 = nn & (~0ull << b);
+                const lk_u64 seg1 = nn1 & ((1ull << eb) - 1ull);
+                e = base + 64 + eb;
+                a2 = seg0 ? base + lk_ctz(seg0) : base + 64 + lk_ctz(seg1);
+                e2 = seg1 ? base + 128 - __builtin_clzll(seg1) : base + 64 - __builtin_clzll(seg0);
+            } else {
+                e = next_set_bit(P.bits, base + 64, total);
+                const lk_u64 seg = nn & (~0ull << b);
+                a2 = seg ? base + lk_ctz(seg) : next_zero_bit(P.space, base + 64, e);
+                e2 = prev_zero_end(P.space, a2, e);
+            }
+            int64_t* rec = swin + (k - win0) * 4;
+            rec[0] = p - lo;
+            rec[1] = e - lo;
+            rec[2] = a2 - lo;
+            rec[3] = e2 - lo;
+            ++k;
+        }
+        wave_lds_sync();
+        {
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const int n_pair = min(kFeatRound, n_wave - win0) * 2;
+            ll2* dst = reinterpret_cast<ll2*>(P.spans4 + (base_out + win0) * 4);
+            for (int i = lane; i < n_pair; i += 64) {
+                ll2 v;
+                v.x = swin[2 * i];
+                v.y = swin[2 * i + 1];
+                __builtin_nontemporal_store(v, dst + i);
+            }
+        }
+        wave_lds_sync();
+    }
 }
 
 __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P) {
@@ -1397,8 +1474,8 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     L.t2 = lds + kStage1Pad;
     uint8_t* mine = lds + kTablesLdsBytes + wave * kFeatWaveLds;
     L.stage = mine;
-    L.halo = mine + kFeatRound * 25;
-    L.bw = reinterpret_cast<lk_u64*>(mine + kFeatRound * 25 + 16);
+    L.halo = mine + kFeatWinBytes;
+    L.bw = reinterpret_cast<lk_u64*>(mine + kFeatWinBytes + 16);
     for (int64_t t = (int64_t)blockIdx.x * kFeatWaves + wave; t < P.n_tiles; t += (int64_t)gridDim.x * kFeatWaves)
         feature_tile(P, L, t, lane);
 }

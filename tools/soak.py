@@ -69,7 +69,7 @@ def make_batch(seed):
     # featurize: per-token column sums from the oracle's n x 25 matrix (small batches only)
     feats = None
     if cps.size < 6000 and rng.random() < 0.5:
-        rows_ = []
+        rows_, spans4_ = [], []
         for s_, t in enumerate(texts):
             if not t:
                 continue
@@ -81,7 +81,9 @@ def make_batch(seed):
             for p_, e_ in zip(nz[:-1], nz[1:]):
                 if (~sp[p_:e_]).any():
                     rows_.append(m[p_:e_].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8))
-        feats = np.array(rows_, np.int8).reshape(-1, 25)
+                    ns_ = np.nonzero(~sp[p_:e_])[0]
+                    spans4_.append((p_, e_, p_ + int(ns_[0]), p_ + int(ns_[-1]) + 1))
+        feats = (np.array(rows_, np.int8).reshape(-1, 25), np.array(spans4_, np.int64).reshape(-1, 4))
     return seed, kind, cps, row, vals, bits, space, rules, rule_bits, u8, boff, bpos, feats
 
 
@@ -145,7 +147,8 @@ def main():
                 n_rules += 1
             if feats is not None and cps.size > 0:
                 fc, fs, ff = batch.token_features_csr(cps, row)
-                assert ff.shape == feats.shape and np.array_equal(ff, feats), "featurize sums differ: " + tag
+                assert ff.shape == feats[0].shape and np.array_equal(ff, feats[0]), "featurize sums differ: " + tag
+                assert np.array_equal(fs, feats[1]), "featurize span records differ: " + tag
                 n_feat += 1
             if u8 is not None and cps.size > 0:
                 # byte space: boundaries at the lead byte of every boundary char; staged path: code-point units

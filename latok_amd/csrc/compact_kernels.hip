@@ -113,9 +113,9 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 
 // ---- pass 3 --------------------------------------------------------------------------------------------------------
 // One wave per 64 consecutive words (4096 chars).  The wave
-//   (a) finds the string that contains the first char of each of its words: one k-ary search over row_off for the
-//       4096-char window, then the starts inside the window go through an LDS max + a prefix max over the lanes
-//       (empty strings share a start: the max keeps the last, i.e. the one that owns the chars);
+//   (a) finds where the owning string of every position begins: the string starts inside the tile become bits in LDS,
+//       the last start before each word is a prefix max over the lanes, and the string that was open when the tile began
+//       comes from the per-tile string index the tile kernel publishes;
 //   (b) lane = word: walks the items of its word (all mask arithmetic inside the word; only a token that runs past the
 //       word's end follows the masks further) and puts the records into an LDS window at their rank inside the wave;
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
@@ -171,31 +171,38 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     int64_t* win = win_s[wave];
     long long* smax = smax_s[wave];
 
-    // (a) string that contains the first char of every word
+    // (a) where the string that owns a position begins: string-start bits of the tile in LDS (one atomicOr per string
+    //     that starts in it), per lane the last start before its word (prefix max), and for everything before the first
+    //     start the string that was open when the tile began.  No per-item loads: a lane that had to fetch row_off at
+    //     every string change stalled the whole wave on every step of its item loop.
     const int64_t t0 = w0 << 6;
     // first string starting at or after t0: published by the tile kernel (one wave = one tile), else searched
     int64_t idx0 = tile_first ? tile_first[w0 >> 6] : scatter_lower_bound(row_off, n_str, t0, lane);
     if (idx0 > n_str) idx0 = n_str;
-    smax[lane] = -1;
-    if (lane == 0) smax[64] = -1;
+    const int64_t start_before = idx0 > 0 ? row_off[idx0 - 1] : 0;
+    unsigned long long* bw = reinterpret_cast<unsigned long long*>(smax);
+    bw[lane] = 0ull;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int64_t i0 = idx0; i0 < n_str; i0 += 64) {
         const int64_t sidx = i0 + lane;
         const int64_t ro = sidx < n_str ? row_off[sidx] : INT64_MAX;
         const int64_t rel = ro - t0;
-        if (rel < 4096) atomicMax(&smax[(rel + 63) >> 6], (long long)sidx);   // first word that begins at or after it
+        if (rel >= 0 && rel < 4096) atomicOr(&bw[rel >> 6], 1ull << (rel & 63));
         if (__shfl(ro, 63) >= t0 + 4096) break;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    long long sid = smax[lane];
+    const uint64_t Bw = bw[lane];
+    int carry = Bw ? 64 * lane + 63 - __builtin_clzll(Bw) : -1;     // tile-relative position of my word's last string start
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const long long o = __shfl_up(sid, d);
-        if (lane >= d && o > sid) sid = o;
+        const int o = __shfl_up(carry, d);
+        if (lane >= d && o > carry) carry = o;
     }
-    if (sid < idx0 - 1) sid = idx0 - 1;                             // a string that began before the window
+    carry = __shfl_up(carry, 1);
+    if (lane == 0) carry = -1;
+    const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
 
     // (b) + (c), window by window
     const int64_t base = w << 6;
@@ -212,8 +219,6 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
             nn1 = has ? (~space[w + 1] & valid_mask(w + 1, total)) : 0ull;
         }
     }
-    int64_t s = sid, lo = 0, hi = 0;
-    if (x) { lo = row_off[s]; hi = row_off[s + 1]; }
     uint64_t rest = x;
     int k = off;                                                    // wave rank of my next item
     for (int win0 = 0; win0 < n_wave; win0 += kCap) {
@@ -221,7 +226,8 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
             const int b = __builtin_ctzll(rest);
             rest &= rest - 1;
             const int64_t p = base + b;
-            while (p >= hi) { ++s; lo = hi; hi = row_off[s + 1]; }   // next (non-empty) string
+            const uint64_t bl = Bw & ((2ull << b) - 1ull);            // string starts at or before the item (b = 63: all)
+            const int64_t lo = bl ? base + 63 - __builtin_clzll(bl) : lo_in;
             int64_t* rec = win + (k - win0) * kVals;
             if (KIND == 0) {
                 rec[0] = p - lo;

@@ -121,10 +121,11 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
 // KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
 // (featurize writes its 4-value span records from k_features_tiles, together with the sums)
-// waves per workgroup / int64 slots of one wave's LDS window (8 KiB), per KIND.  Windows that hold a whole tile's records
-// for the 16- and 32-byte kinds (2048 / 4096 slots, fewer waves per CU) were measured: fewer rounds, but slower overall.
+// waves per workgroup / int64 slots of one wave's LDS window, per KIND.  The item loop is VALU-bound (lanes with few items
+// wait for lanes with many, and every round repeats that), so the 16-byte kind takes a window that holds a whole tile's
+// records (2048 slots = 1024 spans) even though that halves the waves per CU: 2-3 % faster end to end.
 constexpr int scatter_waves(int kind) { return 4; }
-constexpr int scatter_win(int kind) { return 1024; }
+constexpr int scatter_win(int kind) { return kind == 1 ? 2048 : 1024; }
 
 __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
                                                        int lane) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     constexpr int kVals = KIND == 0 ? 1 : 2;                        // int64 values per item
     constexpr int kScatterWaves = scatter_waves(KIND);
     constexpr int kWin = scatter_win(KIND);                         // int64 slots of one wave's window
-    constexpr int kCap = kWin / kVals;                              // items per window: 1024 / 512 / 256
+    constexpr int kCap = kWin / kVals;                              // items per window: 1024
     __shared__ int64_t win_s[kScatterWaves][kWin];
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

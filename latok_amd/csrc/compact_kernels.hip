@@ -121,11 +121,7 @@ __global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t
 //   (c) streams the window to the output: consecutive lanes write consecutive 8-byte words.
 // KIND 0: offsets[k] = p - start of its string.   KIND 1: spans[2k..] = stripped extent.
 // (featurize writes its 4-value span records from k_features_tiles, together with the sums)
-// waves per workgroup / int64 slots of one wave's LDS window, per KIND.  The item loop is VALU-bound (lanes with few items
-// wait for lanes with many, and every round repeats that), so the 16-byte kind takes a window that holds a whole tile's
-// records (2048 slots = 1024 spans) even though that halves the waves per CU: 2-3 % faster end to end.
-constexpr int scatter_waves(int kind) { return 4; }
-constexpr int scatter_win(int kind) { return kind == 1 ? 2048 : 1024; }
+constexpr int scatter_waves(int kind) { return 4; }   // waves per workgroup
 
 __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
                                                        int lane) {
@@ -154,11 +150,9 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
     const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
-    constexpr int kVals = KIND == 0 ? 1 : 2;                        // int64 values per item
     constexpr int kScatterWaves = scatter_waves(KIND);
-    constexpr int kWin = scatter_win(KIND);                         // int64 slots of one wave's window
-    constexpr int kCap = kWin / kVals;                              // items per window: 1024
-    __shared__ int64_t win_s[kScatterWaves][kWin];
+    constexpr int kCodes = 1024;                                    // items per round
+    __shared__ int64_t buf_s[kScatterWaves][kCodes];                // KIND 0: window of values; KIND 1: the item codes
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
@@ -169,7 +163,8 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const uint64_t x = w < n_words ? item_mask[w] : 0ull;
     const int off = w < n_words ? (int)word_pref[w] : 0;            // rank of my first item inside the wave
     const int64_t base_out = tile_rank[w0 >> 6];
-    int64_t* win = win_s[wave];
+    uint16_t* codes = reinterpret_cast<uint16_t*>(buf_s[wave]);
+    int64_t* win = buf_s[wave];
     long long* smax = smax_s[wave];
 
     // (a) where the string that owns a position begins: string-start bits of the tile in LDS (one atomicOr per string
@@ -206,7 +201,6 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
 
     // (b) + (c), window by window
-    const int64_t base = w << 6;
     const uint64_t xb = w < n_words ? bits[w] : 0ull;               // all boundaries of the word (item_mask is a subset)
     const uint64_t nn = (KIND != 0 && w < n_words) ? (~space[w] & valid_mask(w, total)) : 0ull;
     // the next word's masks (a token that crosses the word's end normally ends there): from the neighbour lane
@@ -220,55 +214,29 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
             nn1 = has ? (~space[w + 1] & valid_mask(w + 1, total)) : 0ull;
         }
     }
+    // (b) token spans: every lane lists its items as (lane, bit) codes at their rank inside the wave ...
+    // (c) ... and the wave then takes the items in rank order, lane j the j-th: the owner word's masks arrive through
+    //     shuffles, so all 64 lanes are busy whatever the spread of items over the words is (a word-major loop runs as
+    //     long as the fullest word, typically 2x the mean), and the records go straight to consecutive addresses.
     uint64_t rest = x;
     int k = off;                                                    // wave rank of my next item
-    for (int win0 = 0; win0 < n_wave; win0 += kCap) {
-        while (rest && k < win0 + kCap) {
-            const int b = __builtin_ctzll(rest);
-            rest &= rest - 1;
-            const int64_t p = base + b;
-            const uint64_t bl = Bw & ((2ull << b) - 1ull);            // string starts at or before the item (b = 63: all)
-            const int64_t lo = bl ? base + 63 - __builtin_clzll(bl) : lo_in;
-            int64_t* rec = win + (k - win0) * kVals;
-            if (KIND == 0) {
-                rec[0] = p - lo;
-            } else {
-                // token [p, e): e = next boundary; stripped extent [a2, e2)
-                const uint64_t above = xb & (~1ull << b);
-                int64_t e, a2, e2;
-                if (above) {                                        // everything inside this word
-                    const int eb = __builtin_ctzll(above);
-                    const uint64_t seg = nn & (~0ull << b) & ((1ull << eb) - 1ull);   // kept => seg != 0
-                    e = base + eb;
-                    a2 = base + __builtin_ctzll(seg);
-                    e2 = base + 64 - __builtin_clzll(seg);
-                } else if (xb1) {                                   // ends at the first boundary of the next word
-                    const int eb = __builtin_ctzll(xb1);
-                    const uint64_t seg0 = nn & (~0ull << b);
-                    const uint64_t seg1 = nn1 & ((1ull << eb) - 1ull);           // eb < 64: bit eb is set in xb1
-                    e = base + 64 + eb;
-                    a2 = seg0 ? base + __builtin_ctzll(seg0) : base + 64 + __builtin_ctzll(seg1);
-                    e2 = seg1 ? base + 128 - __builtin_clzll(seg1) : base + 64 - __builtin_clzll(seg0);
-                } else {
-                    e = next_set_bit(bits, base + 64, total);
-                    const uint64_t seg = nn & (~0ull << b);
-                    a2 = seg ? base + __builtin_ctzll(seg) : next_zero_bit(space, base + 64, e);
-                    e2 = prev_zero_end(space, a2, e);
-                }
-                (void)e;
-                rec[0] = a2 - lo;
-                rec[1] = e2 - lo;
+    if (KIND == 0) {
+        // offsets are one subtraction per item: here the word-major loop through an LDS window is the faster form
+        const int64_t base = w << 6;
+        for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
+            while (rest && k < win0 + kCodes) {
+                const int b = __builtin_ctzll(rest);
+                rest &= rest - 1;
+                const uint64_t bl = Bw & ((2ull << b) - 1ull);
+                win[k - win0] = base + b - (bl ? base + 63 - __builtin_clzll(bl) : lo_in);
+                ++k;
             }
-            ++k;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int n_here = min(kCap, n_wave - win0);
-        int64_t* dst = out + (base_out + win0) * kVals;
-        {   // 16 bytes per lane and store; the output is written once and not read back by this pipeline
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int n_val = min(kCodes, n_wave - win0);
+            int64_t* dst = out + base_out + win0;
             typedef long long ll2 __attribute__((ext_vector_type(2)));
-            const int n_val = n_here * kVals;
-            const int head = (KIND == 0 && (((uintptr_t)dst >> 3) & 1)) ? 1 : 0;   // odd 8-byte slot: one scalar first
+            const int head = (((uintptr_t)dst >> 3) & 1) ? 1 : 0;   // odd 8-byte slot: one scalar first
             if (head && lane == 0) __builtin_nontemporal_store((long long)win[0], (long long*)dst);
             const int n_pair = (n_val - head) >> 1;
             for (int i = lane; i < n_pair; i += 64) {
@@ -279,6 +247,67 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
             }
             if (((n_val - head) & 1) && lane == 0)
                 __builtin_nontemporal_store((long long)win[n_val - 1], (long long*)dst + n_val - 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
+        while (rest && k < win0 + kCodes) {
+            const int b = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            codes[k - win0] = (uint16_t)((lane << 6) | b);
+            ++k;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n_here = min(kCodes, n_wave - win0);
+        for (int j0 = 0; j0 < n_here; j0 += 64) {
+            const int j = j0 + lane;
+            const bool active = j < n_here;
+            const int code = active ? (int)codes[j] : 0;
+            const int owner = code >> 6, b = code & 63;
+            const uint64_t o_Bw = __shfl(Bw, owner);
+            const int64_t o_lo_in = __shfl(lo_in, owner);
+            uint64_t o_xb = 0, o_nn = 0, o_xb1 = 0, o_nn1 = 0;
+            if (KIND != 0) {
+                o_xb = __shfl(xb, owner);
+                o_nn = __shfl(nn, owner);
+                o_xb1 = __shfl(xb1, owner);
+                o_nn1 = __shfl(nn1, owner);
+            }
+            if (active) {
+                const int64_t obase = (w0 + owner) << 6;
+                const uint64_t bl = o_Bw & ((2ull << b) - 1ull);      // string starts at or before the item (b = 63: all)
+                const int64_t lo = bl ? obase + 63 - __builtin_clzll(bl) : o_lo_in;
+                {
+                    // token [p, e): e = next boundary; stripped extent [a2, e2)
+                    const uint64_t above = o_xb & (~1ull << b);
+                    int64_t a2, e2;
+                    if (above) {                                    // everything inside the owner word
+                        const int eb = __builtin_ctzll(above);
+                        const uint64_t seg = o_nn & (~0ull << b) & ((1ull << eb) - 1ull);   // kept => seg != 0
+                        a2 = obase + __builtin_ctzll(seg);
+                        e2 = obase + 64 - __builtin_clzll(seg);
+                    } else if (o_xb1) {                             // ends at the first boundary of the next word
+                        const int eb = __builtin_ctzll(o_xb1);
+                        const uint64_t seg0 = o_nn & (~0ull << b);
+                        const uint64_t seg1 = o_nn1 & ((1ull << eb) - 1ull);     // eb < 64: bit eb is set in xb1
+                        a2 = seg0 ? obase + __builtin_ctzll(seg0) : obase + 64 + __builtin_ctzll(seg1);
+                        e2 = seg1 ? obase + 128 - __builtin_clzll(seg1) : obase + 64 - __builtin_clzll(seg0);
+                    } else {
+                        const int64_t e = next_set_bit(bits, obase + 64, total);
+                        const uint64_t seg = o_nn & (~0ull << b);
+                        a2 = seg ? obase + __builtin_ctzll(seg) : next_zero_bit(space, obase + 64, e);
+                        e2 = prev_zero_end(space, a2, e);
+                    }
+                    typedef long long ll2 __attribute__((ext_vector_type(2)));
+                    ll2 v;
+                    v.x = a2 - lo;
+                    v.y = e2 - lo;
+                    __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(out) + base_out + win0 + j);
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -64,23 +64,18 @@ __global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict_
             x1 = has ? bits[w + 1] : 0ull;
             nn1 = has ? (~space[w + 1] & valid_mask(w + 1, total)) : 0ull;
         }
-        uint64_t kept = 0, rest = x;
-        while (rest) {
-            const int b = __builtin_ctzll(rest);
-            rest &= rest - 1;
-            const uint64_t from_b = ~0ull << b;
-            bool k;
-            if (rest) {   // the token ends at the next boundary of this word
-                k = (nn & from_b & ((rest & (~rest + 1ull)) - 1ull)) != 0;
-            } else if (nn & from_b) {
-                k = true;
-            } else if (x1) {   // it ends at the first boundary of the next word
-                k = (nn1 & ((x1 & (~x1 + 1ull)) - 1ull)) != 0;
-            } else {
-                k = nn1 != 0 || (w + 1 < n_words && tail_has_nonspace(bits, space, w + 1, n_words, total));
-            }
-            if (k) kept |= 1ull << b;
-        }
+        // Which boundaries start a token with a non-SPACE char, for all boundaries of the word at once: on the bit-reversed
+        // word a boundary is the TOP of its token, so "some non-SPACE below me in my token" is a carry chain -- one add.
+        //   generate = non-SPACE chars that are not boundaries, propagate = non-boundaries, carry-in = the token that
+        //   continues into the next word(s) has a non-SPACE char there
+        bool cin;
+        if (x1) cin = (nn1 & ((x1 & (~x1 + 1ull)) - 1ull)) != 0;
+        else cin = nn1 != 0 || (x != 0 && w + 1 < n_words && tail_has_nonspace(bits, space, w + 1, n_words, total));
+        const uint64_t xr = __builtin_bitreverse64(x), nr = __builtin_bitreverse64(nn);
+        const uint64_t g = nr & ~xr, pr = ~xr;
+        const uint64_t a = pr | g;
+        const uint64_t carries = (a + g + (cin ? 1ull : 0ull)) ^ a ^ g;      // carry INTO every position
+        const uint64_t kept = __builtin_bitreverse64(xr & (nr | carries));
         if (w < n_words) kept_out[w] = kept;
         cnt = __popcll(kept);
     }

@@ -1347,6 +1347,133 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         }
     }
 
+    // ---- per-word values both forms below need --------------------------------------------------------------------
+    const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
+    lk_u64 xb1 = __shfl_down(xb, 1), nn1 = __shfl_down(nn, 1);  // the next word's masks
+    if (lane == 63) { xb1 = xb_next_tile; nn1 = nn_next_tile; }
+    // start of the string that is open at my word's first char: the last string start before my word inside the tile,
+    // else the one that was open when the tile began
+    int last_b = B ? 64 * lane + 63 - __builtin_clzll(B) : -1;  // tile-relative position of my word's last string start
+    int carry = last_b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(carry, d);
+        if (lane >= d && o > carry) carry = o;
+    }
+    carry = __shfl_up(carry, 1);
+    if (lane == 0) carry = -1;
+    const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
+
+    // ---- skewed tiles (some word holds many more tokens than the mean, e.g. CJK text where every char is a token):
+    // token-major form.  Every lane lists its tokens as (lane, bit) codes at their rank inside the tile, then lane j
+    // takes the j-th token and pulls the owner word's 25 planes (and masks) through shuffles, so all lanes stay busy.
+    // ~70 64-bit shuffles per token make it the slower form for evenly filled tiles, hence the choice per tile.
+    int maxc = lk_popc(x);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
+    // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
+    if (maxc * 2 > ((n_wave + 63) >> 6) * 3) {
+        uint8_t* fwin = L.stage;
+        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRound * 25);   // behind the feature records
+        lk_u64 trest = x;
+        int tk = off;
+        for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
+            while (trest && tk < win0 + kFeatRound) {
+                const int b = lk_ctz(trest);
+                trest &= trest - 1;
+                codes[tk - win0] = (uint16_t)((lane << 6) | b);
+                ++tk;
+            }
+            wave_lds_sync();
+            const int n_here = min(kFeatRound, n_wave - win0);
+            for (int j0 = 0; j0 < n_here; j0 += 64) {
+                const int j = j0 + lane;
+                const bool active = j < n_here;
+                const int code = active ? (int)codes[j] : 0;
+                const int owner = code >> 6, b = code & 63;
+                const int64_t obase = t0 + 64 * (int64_t)owner;
+                const int64_t orem = total - obase;
+                const lk_u64 ovalid = orem >= 64 ? ~0ull : (orem <= 0 ? 0ull : ((1ull << orem) - 1ull));
+                const lk_u64 o_xb = (lk_u64)__shfl((long long)xb, owner), o_xb1 = (lk_u64)__shfl((long long)xb1, owner),
+                             o_nn1 = (lk_u64)__shfl((long long)nn1, owner), o_B = (lk_u64)__shfl((long long)B, owner);
+                const int64_t o_lo_in = __shfl((long long)lo_in, owner);
+                const lk_u64 above = o_xb & (~1ull << b);
+                lk_u64 seg = (~0ull << b) & ovalid;
+                if (above) seg &= (above & (~above + 1ull)) - 1ull;
+                FeatSums sum;
+#pragma unroll
+                for (int q = 0; q < 7; ++q) sum.v[q] = 0;
+                lk_u64 o_S = 0;
+#pragma unroll
+                for (int c = 0; c < LK_N_FEATURES; ++c) {
+                    const lk_u64 pc = (lk_u64)__shfl((long long)LK_PLANE_GET(F, c), owner);
+                    if (c == 5) o_S = pc;
+                    sum.v[c >> 2] |= (uint32_t)__popcll(pc & seg) << (8 * (c & 3));
+                }
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const uint32_t cq = (uint32_t)__shfl((int)C.v[q], owner);
+                    if (!above) sum.v[q] = swar_add_u8(sum.v[q], cq);
+                }
+                if (active) {
+                    uint8_t* rec = fwin + j * 25;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) __builtin_memcpy(rec + 4 * q, &sum.v[q], 4);
+                    rec[24] = (uint8_t)sum.v[6];
+                    const lk_u64 o_nn = ~o_S & ovalid;
+                    const int64_t p = obase + b;
+                    const lk_u64 bl = o_B & ((2ull << b) - 1ull);
+                    const int64_t lo = bl ? obase + 63 - __builtin_clzll(bl) : o_lo_in;
+                    int64_t e, a2, e2;
+                    if (above) {
+                        const int eb = lk_ctz(above);
+                        const lk_u64 sg = o_nn & (~0ull << b) & ((1ull << eb) - 1ull);
+                        e = obase + eb;
+                        a2 = obase + lk_ctz(sg);
+                        e2 = obase + 64 - __builtin_clzll(sg);
+                    } else if (o_xb1) {
+                        const int eb = lk_ctz(o_xb1);
+                        const lk_u64 sg0 = o_nn & (~0ull << b);
+                        const lk_u64 sg1 = o_nn1 & ((1ull << eb) - 1ull);
+                        e = obase + 64 + eb;
+                        a2 = sg0 ? obase + lk_ctz(sg0) : obase + 64 + lk_ctz(sg1);
+                        e2 = sg1 ? obase + 128 - __builtin_clzll(sg1) : obase + 64 - __builtin_clzll(sg0);
+                    } else {
+                        e = next_set_bit(P.bits, obase + 64, total);
+                        const lk_u64 sg = o_nn & (~0ull << b);
+                        a2 = sg ? obase + lk_ctz(sg) : next_zero_bit(P.space, obase + 64, e);
+                        e2 = prev_zero_end(P.space, a2, e);
+                    }
+                    typedef long long ll2 __attribute__((ext_vector_type(2)));
+                    ll2* sp = reinterpret_cast<ll2*>(P.spans4 + (base_out + win0 + j) * 4);
+                    ll2 v0, v1;
+                    v0.x = p - lo;
+                    v0.y = e - lo;
+                    v1.x = a2 - lo;
+                    v1.y = e2 - lo;
+                    __builtin_nontemporal_store(v0, sp);
+                    __builtin_nontemporal_store(v1, sp + 1);
+                }
+            }
+            wave_lds_sync();
+            const int n_bytes = n_here * 25;
+            uint8_t* dst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
+            const int head = (int)((4u - ((uintptr_t)dst & 3u)) & 3u);
+            const int hb = min(head, n_bytes);
+            if (lane < hb) dst[lane] = fwin[lane];
+            const int n_dw = (n_bytes - hb) >> 2;
+            for (int i = lane; i < n_dw; i += 64) {
+                uint32_t v;
+                __builtin_memcpy(&v, fwin + hb + 4 * i, 4);
+                *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
+            }
+            const int tail0 = hb + 4 * n_dw;
+            if (lane < n_bytes - tail0) dst[tail0 + lane] = fwin[tail0 + lane];
+            wave_lds_sync();
+        }
+        return;
+    }
+
     // ---- tokens of my word, round by round through the staging buffer -------------------------------------------------
     uint8_t* win = L.stage;
     lk_u64 rest = x;
@@ -1388,21 +1515,6 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 
     // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
-    const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
-    lk_u64 xb1 = __shfl_down(xb, 1), nn1 = __shfl_down(nn, 1);  // the next word's masks
-    if (lane == 63) { xb1 = xb_next_tile; nn1 = nn_next_tile; }
-    // start of the string that is open at my word's first char: the last string start before my word inside the tile,
-    // else the one that was open when the tile began
-    int last_b = B ? 64 * lane + 63 - __builtin_clzll(B) : -1;  // tile-relative position of my word's last string start
-    int carry = last_b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(carry, d);
-        if (lane >= d && o > carry) carry = o;
-    }
-    carry = __shfl_up(carry, 1);
-    if (lane == 0) carry = -1;
-    const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
     int64_t* swin = reinterpret_cast<int64_t*>(L.stage);
     rest = x;
     k = off;

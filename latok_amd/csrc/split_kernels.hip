@@ -902,22 +902,42 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     const int64_t T0 = seg * S;
     const int64_t T1 = min(T0 + S, P.n_tiles);
     const int n_seg = (int)(T1 - T0);
-    // (a) first string of the segment, then of each of its tiles
-    int64_t lb0, lb1;
-    block_lower_bound_pair<kWPB * 64>(P.row_off, P.n_str + 1, P.total, T0 * kTile, T1 * kTile, misc, &lb0, &lb1);
-    const int64_t s_lo = to_scalar64(lb0);
+    // (a) first string of each tile of the segment.  One trip to memory when the row offsets are roughly evenly spaced:
+    //     a window of row_off around the range an even spacing predicts is read once and every entry fills the tiles it
+    //     is the first string of; if a tile stays unfilled the window missed, and the bounds are searched instead.
+    int64_t s_lo;
     {
-        // the strings that matter end with the first one that starts at or after the segment's end; the fill is one
-        // barrier-free pass over them
-        const int64_t s_hi = to_scalar64(lb1);
-        for (int64_t s = s_lo + tid; s <= s_hi && s <= P.n_str; s += kWPB * 64) {
-            const int64_t p = P.row_off[s];
-            const int64_t prev = s > 0 ? P.row_off[s - 1] : -1;
-            int64_t w0 = (prev < 0 ? 0 : prev / kTile + 1);
-            int64_t w1 = p / kTile;
-            if (w0 < T0) w0 = T0;
-            if (w1 > T1 - 1) w1 = T1 - 1;
-            for (int64_t w = w0; w <= w1; ++w) tf[w - T0] = (int)(s - s_lo);
+        const int64_t n_entries = P.n_str + 1;
+        auto guess = [&](int64_t c) -> int64_t {
+            int64_t g = P.total > 0 ? (int64_t)((double)c * (double)P.n_str / (double)P.total) : 0;
+            return g < 0 ? 0 : (g > P.n_str ? P.n_str : g);
+        };
+        constexpr int64_t kMargin = 1536;
+        int64_t wlo = guess(T0 * kTile) - kMargin, whi = guess(T1 * kTile) + kMargin + 1;
+        if (wlo < 0) wlo = 0;
+        if (whi > n_entries) whi = n_entries;
+        if (tid < n_seg) tf[tid] = -1;
+        __syncthreads();
+        auto fill = [&](int64_t first, int64_t last_incl, int64_t base) {
+            for (int64_t s = first + tid; s <= last_incl && s <= P.n_str; s += kWPB * 64) {
+                const int64_t p = P.row_off[s];
+                const int64_t prev = s > 0 ? P.row_off[s - 1] : -1;
+                int64_t w0 = (prev < 0 ? 0 : prev / kTile + 1);
+                int64_t w1 = p / kTile;
+                if (w0 < T0) w0 = T0;
+                if (w1 > T1 - 1) w1 = T1 - 1;
+                for (int64_t w = w0; w <= w1; ++w) tf[w - T0] = (int)(s - base);
+            }
+        };
+        wlo = to_scalar64(wlo);
+        fill(wlo, whi - 1, wlo);
+        __syncthreads();
+        s_lo = wlo;
+        if (!__syncthreads_and(tid >= n_seg || tf[tid] >= 0)) {
+            int64_t lb0, lb1;
+            block_lower_bound_pair<kWPB * 64>(P.row_off, n_entries, P.total, T0 * kTile, T1 * kTile, misc, &lb0, &lb1);
+            s_lo = to_scalar64(lb0);
+            fill(s_lo, to_scalar64(lb1), s_lo);
         }
     }
     __syncthreads();   // tables (first segment) and tf are in place

@@ -749,3 +749,22 @@ def test_calls_on_different_streams_are_ordered(gpu, oracle):
                 lib.latok_dev_free(p)
         hip.hipStreamDestroy(s1)
         hip.hipStreamDestroy(s2)
+
+
+def test_very_uneven_string_lengths(gpu, oracle):
+    """The segment prologue guesses where a segment's strings sit in row_off from an even spacing and falls back to a
+    search when the guess window misses: batches whose string lengths are as uneven as possible (hundreds of thousands of
+    1-3-char strings next to 100 K-char documents, both orders, and interleaved) must take that fallback and stay exact."""
+    from latok_amd import batch
+    rng = random.Random(271828)
+    tiny = random_strings(rng, 200000, 1, 3, ALPHABETS["starts"])
+    huge = random_strings(rng, 40, 90000, 110000, ALPHABETS["words"])
+    mixed = []
+    for i, h in enumerate(huge[:10]):
+        mixed += tiny[i * 5000:(i + 1) * 5000] + [h]
+    for texts in (tiny + huge, huge + tiny, mixed):
+        cps, row = pack(texts)
+        _, want = oracle.split_batch(cps, row, want_values=False)
+        assert np.array_equal(batch.split_mask_batch(cps, row), want)
+        counts, offs = batch.split_offsets_csr(cps, row)
+        assert int(counts.sum()) == len(offs) == int(np.unpackbits(want.view(np.uint8)).sum())

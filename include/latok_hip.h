@@ -196,7 +196,7 @@ int latok_rules_active(void);  /* 1 while custom tables are installed */
 /* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
  * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
  * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (k_tiles_main), measured with its own
- * event pair per launch in `iters` further passes; n_fix_tiles_out = tiles re-done by the fix-up stage in the last
+ * event pair per launch in `iters` further passes that are enqueued back to back and synchronised once; n_fix_tiles_out = tiles re-done by the fix-up stage in the last
  * pass.  Any may be NULL (a NULL output skips its passes), so warm-up-only and kernel-only calls are possible. */
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,

@@ -409,6 +409,117 @@ def test_beyond_4GiB_batch(gpu, oracle):
             lib.latok_dev_free(p)
 
 
+def test_positions_beyond_int32(gpu, oracle):
+    """2.3e9 chars in ONE batch (9.5 GB of code points): character positions, bitmask word indices times 64 and token
+    ranks near the tail no longer fit 32 bits.  Mask against the oracle on slices from the head, the 2^31 crossing and
+    the tail; offsets / spans / featurize of the tail against the same strings run as a small batch of their own (the
+    results are per string, so they must not depend on where the string sits); byte space on the same text as UTF-8
+    (ASCII corpus: byte positions == char positions, so the two bitmasks must be identical)."""
+    from latok_amd import _lib, batch
+    lib = gpu
+    n_str, seed, model, lo, hi = 18_000_000, 0x1A70C0DE, 0, 64, 192
+    row = np.zeros(n_str + 1, np.int64)
+    _lib.check(lib.latok_corpus_offsets(seed, 0, n_str, lo, hi, row.ctypes.data))
+    total = int(row[-1])
+    assert total > 2 ** 31 + 10_000_000
+    n_words = (total + 63) // 64
+    D = _lib.DEVICE_PTRS
+    ptrs = []
+
+    def alloc(nbytes):
+        p = lib.latok_dev_alloc(nbytes)
+        assert p, _lib.last_error()
+        ptrs.append(p)
+        return p
+
+    def back(p, shape, dtype, skip=0):
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            _lib.check(lib.latok_memcpy_d2h(out.ctypes.data, p + skip, out.nbytes))
+        return out
+
+    try:
+        d_row, d_cps, d_bits = alloc(row.nbytes), alloc(total * 4), alloc(n_words * 8 + 8)
+        _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
+        _lib.check(lib.latok_corpus_fill_device(seed, model, 0, n_str, d_row, d_cps, None))
+        _lib.check(lib.latok_split_mask_batch(d_cps, d_row, n_str, total, d_bits, D, None))
+        _lib.check(lib.latok_sync())
+        bits = back(d_bits, n_words, np.uint64)
+        s_cross = int(np.searchsorted(row, 2 ** 31)) - 2000
+        n_tail = 3000
+        for s0 in (0, s_cross, n_str - n_tail):
+            s1 = s0 + (4000 if s0 != n_str - n_tail else n_tail)
+            c0, c1 = int(row[s0]), int(row[s1])
+            cps = back(d_cps, c1 - c0, np.uint32, skip=4 * c0)
+            ov, _ = oracle.split_batch(cps, row[s0:s1 + 1] - c0, want_bits=False)
+            w0, w1 = c0 // 64, (c1 + 63) // 64
+            got = bits_to_bool(bits[w0:w1], (w1 - w0) * 64)[c0 - w0 * 64:c1 - w0 * 64]
+            assert np.array_equal(got, ov != 0), s0
+        starts = row[:-1]
+        assert ((bits[starts >> 6] >> (starts & 63).astype(np.uint64)) & np.uint64(1)).all()
+        if total % 64:
+            assert int(bits[-1]) >> (total % 64) == 0
+        n_bound = int(np.bitwise_count(bits).sum())
+
+        # the tail strings as a batch of their own (host pointers, positions < 2^20)
+        s0 = n_str - n_tail
+        c0 = int(row[s0])
+        t_cps = back(d_cps, total - c0, np.uint32, skip=4 * c0)
+        t_row = np.ascontiguousarray(row[s0:] - c0)
+        d_counts = alloc(n_str * 8)
+        nout = C.c_int64(0)
+        cap = n_bound + 8
+        d_items = alloc(cap * 32)
+        d_feat = alloc(cap * 25)
+
+        def tail(width, dtype=np.int64, p=None):
+            counts = back(d_counts, n_str, np.int64)
+            assert int(counts.sum()) == nout.value
+            k0 = int(counts[:s0].sum())
+            item = width * np.dtype(dtype).itemsize
+            return counts[s0:], back(p or d_items, (nout.value - k0, width), dtype, skip=k0 * item)
+
+        _lib.check(lib.latok_split_offsets_batch(d_cps, d_row, n_str, total, d_counts, d_items, cap, C.byref(nout), D, None))
+        assert nout.value == n_bound
+        cnt, items = tail(1)
+        w_cnt, w_items = batch.split_offsets_csr(t_cps, t_row)
+        assert np.array_equal(cnt, w_cnt) and np.array_equal(items.ravel(), w_items)
+        _lib.check(lib.latok_token_spans_batch(d_cps, d_row, n_str, total, d_counts, d_items, cap, C.byref(nout), D, None))
+        cnt, items = tail(2)
+        w_cnt, w_items = batch.token_spans_csr(t_cps, t_row)
+        assert np.array_equal(cnt, w_cnt) and np.array_equal(items, w_items)
+        n_tok = nout.value
+        _lib.check(lib.latok_token_features_batch(d_cps, d_row, n_str, total, d_counts, d_items, d_feat, cap, C.byref(nout), D, None))
+        assert nout.value == n_tok
+        cnt, items = tail(4)
+        _, feats = tail(25, np.int8, d_feat)
+        w_cnt, w_items, w_feats = batch.token_features_csr(t_cps, t_row)
+        assert np.array_equal(cnt, w_cnt) and np.array_equal(items, w_items) and np.array_equal(feats, w_feats)
+
+        # byte space over the same text (ASCII: one byte per char, identical positions)
+        lib.latok_dev_free(ptrs.pop())   # d_feat
+        u8 = np.empty(total, np.uint8)
+        step = 1 << 28
+        for a in range(0, total, step):
+            b = min(total, a + step)
+            chunk = back(d_cps, b - a, np.uint32, skip=4 * a)
+            assert int(chunk.max()) < 0x80
+            u8[a:b] = chunk
+        d_u8 = alloc(total + 64)
+        _lib.check(lib.latok_memcpy_h2d(d_u8, u8.ctypes.data, total))
+        _lib.check(lib.latok_memset_dev(d_bits, 0, n_words * 8))
+        _lib.check(lib.latok_split_mask_utf8_bytes_batch(d_u8, d_row, n_str, total, d_bits, D, None))
+        _lib.check(lib.latok_sync())
+        assert np.array_equal(back(d_bits, n_words, np.uint64), bits)
+        _lib.check(lib.latok_token_spans_utf8_bytes_batch(d_u8, d_row, n_str, total, d_counts, d_items, cap, C.byref(nout), D, None))
+        assert nout.value == n_tok
+        cnt, items = tail(2)
+        assert np.array_equal(cnt, w_cnt) and np.array_equal(items, w_items[:, 2:4] if w_items.shape[1] == 4 else w_items)
+    finally:
+        for p in ptrs:
+            lib.latok_dev_free(p)
+
+
 def test_utf8_ingest(gpu, oracle):
     """UTF-8 CSR input: device decode == Python's decoder, and offsets / spans equal the UTF-32 path."""
     from latok_amd import batch

@@ -137,6 +137,27 @@ int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int6
                                int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
                                int64_t* n_tokens_out, int flags, void* stream);
 
+/* ---- PEP 393 buffers: the reference's own input format ------------------------------------------------------------
+ * The reference reads a str through PyUnicode_KIND / PyUnicode_DATA (latok.c:53-55,79): fixed-width code units of
+ * kind = 1 (Latin-1), 2 (UCS-2) or 4 (UCS-4) bytes.  These entry points take that buffer as it is: `units` = the
+ * packed units of all strings, row_off / total_chars / every result in units = chars (CPython stores text with astral
+ * chars as kind 4, so a kind-2 unit is always a whole code point; lone surrogates are classified as the code points
+ * they are).  A caller that holds Python strings never widens them to UTF-32, and a Latin-1 / UCS-2 batch costs 1 / 2
+ * bytes per char on the bus and in HBM: the tile kernel reads the narrow units itself (mask, offsets, spans); featurize
+ * and run-time rule tables widen them once on the device.  Results are identical to the UTF-32 entry points on the
+ * widened text.  kind = 4 forwards to those.  With LATOK_DEVICE_PTRS `units` must be 16-byte aligned. */
+int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                uint64_t* mask_bits_out, int flags, void* stream);
+int latok_split_offsets_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                   int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
+                                   int flags, void* stream);
+int latok_token_spans_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                 int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                 int flags, void* stream);
+int latok_token_features_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                    int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
+                                    int64_t* n_tokens_out, int flags, void* stream);
+
 /* ---- the reference's three native functions, one string at a time (compat surface) ---------------------------- */
 /* _gen_parse_matrix (latok.c:31-138): n code points -> int8[n][25], C-contiguous. */
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream);

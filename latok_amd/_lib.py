@@ -42,6 +42,10 @@ SIGNATURES = {
     "latok_split_offsets_utf8_bytes_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_token_spans_utf8_bytes_batch": (ci, [vp, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_token_features_batch": (ci, [vp, vp, i64, i64, vp, vp, vp, i64, C.POINTER(i64), ci, vp]),
+    "latok_split_mask_kind_batch": (ci, [vp, ci, vp, i64, i64, vp, ci, vp]),
+    "latok_split_offsets_kind_batch": (ci, [vp, ci, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
+    "latok_token_spans_kind_batch": (ci, [vp, ci, vp, i64, i64, vp, vp, i64, C.POINTER(i64), ci, vp]),
+    "latok_token_features_kind_batch": (ci, [vp, ci, vp, i64, i64, vp, vp, vp, i64, C.POINTER(i64), ci, vp]),
     "latok_parse_matrix": (ci, [vp, i64, vp, ci, vp]),
     "latok_combine_matrix_rows": (ci, [vp, i64, i64, i64, i64, vp, ci, ci, ci, vp, ci, vp]),
     "latok_block_mask": (ci, [vp, vp, i64, vp, ci, vp]),

@@ -252,6 +252,87 @@ def tokenize_utf8_batch(blobs):
     return out
 
 
+# ---- PEP 393 code units: 1 / 2 / 4 bytes per char, the buffer the reference itself reads (latok.c:53-55,79) -----------
+def pack_kind(texts):
+    """list[str] -> (units, row_off): units uint8 / uint16 / uint32 = the narrowest PEP 393 kind that holds every char of
+    the batch (what CPython stores for the joined text), row_off int64[n+1] in chars."""
+    lens = np.fromiter((len(t) for t in texts), dtype=np.int64, count=len(texts))
+    row_off = np.zeros(len(texts) + 1, np.int64)
+    np.cumsum(lens, out=row_off[1:])
+    joined = "".join(texts)
+    try:
+        units = np.frombuffer(joined.encode("latin-1"), dtype=np.uint8)
+    except UnicodeEncodeError:
+        blob = joined.encode("utf-16-le", "surrogatepass")
+        if len(blob) == 2 * len(joined):
+            units = np.frombuffer(blob, dtype="<u2").astype(np.uint16, copy=False)
+        else:   # astral chars: kind 4
+            units = np.frombuffer(joined.encode("utf-32-le", "surrogatepass"), dtype="<u4").astype(np.uint32, copy=False)
+    return np.ascontiguousarray(units), row_off
+
+
+def _csr_kind(units, row_off):
+    units = np.ascontiguousarray(units)
+    if units.dtype not in (np.uint8, np.uint16, np.uint32):
+        raise ValueError("units must be uint8 (Latin-1), uint16 (UCS-2) or uint32 (UCS-4)")
+    row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+    if row_off.ndim != 1 or row_off.size < 1:
+        raise ValueError("row_off must be a 1-D array of n_str + 1 offsets")
+    if units.ndim != 1 or (row_off.size > 1 and units.size < int(row_off[-1])):
+        raise ValueError("units is shorter than row_off[-1]")
+    return units, row_off, int(units.dtype.itemsize)
+
+
+def split_mask_kind_csr(units, row_off) -> np.ndarray:
+    """split_mask_batch for PEP 393 code units (dtype picks the kind); bit i = packed char i starts a token."""
+    units, row_off, kind = _csr_kind(units, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    bits = np.zeros((total + 63) // 64, np.uint64)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_split_mask_kind_batch(_ptr(units), kind, _ptr(row_off), n_str, total, _ptr(bits), 0, None))
+    return bits
+
+
+def _compact_kind(fn, width, units, row_off):
+    units, row_off, kind = _csr_kind(units, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    items = np.empty((max(total, 1), width), np.int64)
+    n_out = C.c_int64(0)
+    _lib.check(fn(_ptr(units), kind, _ptr(row_off), n_str, total, _ptr(counts), _ptr(items), items.shape[0],
+                  C.byref(n_out), 0, None))
+    return counts, items[:n_out.value].copy()
+
+
+def split_offsets_kind_csr(units, row_off):
+    """(counts, offsets) like split_offsets_csr for PEP 393 code units."""
+    counts, items = _compact_kind(_lib.ensure_init().latok_split_offsets_kind_batch, 1, units, row_off)
+    return counts, items.reshape(-1)
+
+
+def token_spans_kind_csr(units, row_off):
+    """(counts, spans[n_tokens, 2]) like token_spans_csr for PEP 393 code units."""
+    return _compact_kind(_lib.ensure_init().latok_token_spans_kind_batch, 2, units, row_off)
+
+
+def token_features_kind_csr(units, row_off):
+    """(counts, spans[n_tokens, 4], features int8[n_tokens, 25]) like token_features_csr for PEP 393 code units."""
+    units, row_off, kind = _csr_kind(units, row_off)
+    n_str = row_off.size - 1
+    total = int(row_off[-1]) if n_str > 0 else 0
+    counts = np.zeros(n_str, np.int64)
+    cap = max(total, 1)
+    spans = np.empty((cap, 4), np.int64)
+    feats = np.empty((cap, _lib.FEATURE_COUNT), np.int8)
+    n_tok = C.c_int64(0)
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_token_features_kind_batch(_ptr(units), kind, _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
+                                                   _ptr(feats), cap, C.byref(n_tok), 0, None))
+    return counts, spans[:n_tok.value].copy(), feats[:n_tok.value].copy()
+
+
 def spans_from_offsets(text, nz):
     """Token strings of one text from its boundary offsets, as the reference's loop builds them
     (default_tokenizer.py:149-158): slice between consecutive boundaries, strip, drop empties."""

@@ -156,13 +156,14 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
-                 const uint8_t* d_u8 = nullptr) {
+                 const uint8_t* d_u8 = nullptr, int unit_kind = 0) {
     if (total <= 0 || n_str <= 0) return LATOK_OK;
-    if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes
+    if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
         if (g.rules_on) return fail(LATOK_ERR_INVALID, "run-time rule tables are not available in byte space; use the code-point UTF-8 entry points");
-        if (((uintptr_t)d_u8 & 15) != 0) return fail(LATOK_ERR_INVALID, "device UTF-8 pointer must be 16-byte aligned");
-        mode = latok::kModeBytes;
+        if (((uintptr_t)d_u8 & 15) != 0)
+            return fail(LATOK_ERR_INVALID, unit_kind ? "device code-unit pointer must be 16-byte aligned" : "device UTF-8 pointer must be 16-byte aligned");
+        mode = unit_kind == 1 ? latok::kModeLatin1 : (unit_kind == 2 ? latok::kModeUcs2 : latok::kModeBytes);
     }
     if (g.rules_on) {
         if (mode == latok::kModeValues)
@@ -508,7 +509,7 @@ static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t
 static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
-                          bool byte_space = false) {
+                          bool byte_space = false, int unit_kind = 0) {
     const bool feats = features_out != nullptr;
     int rc = need_init();
     if (rc) return rc;
@@ -521,21 +522,31 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     const int64_t* d_row = row_off;
     const uint8_t* d_u8 = nullptr;   // byte space: the tile kernel reads the UTF-8 bytes itself, results are byte offsets
     if (utf8 && byte_space) {
+        // UTF-8 in byte space, or (unit_kind 1 / 2) PEP 393 code units: `total` positions of unit_bytes each
+        const size_t unit_bytes = unit_kind ? (size_t)unit_kind : 1;
         if (dev) {
             if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
             d_u8 = utf8;
         } else {
             if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
             if (n_str > 0) {
-                if ((rc = g.u_bytes.ensure((size_t)total + 16))) return rc;
+                if ((rc = g.u_bytes.ensure((size_t)total * unit_bytes + 16))) return rc;
                 if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
-                if (total > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total, hipMemcpyHostToDevice, st));
+                if (total > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total * unit_bytes, hipMemcpyHostToDevice, st));
                 HIP_TRY(hipMemcpyAsync(g.u_boff.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
                 d_u8 = (const uint8_t*)g.u_bytes.p;
                 d_row = (const int64_t*)g.u_boff.p;
             }
         }
         d_cps = nullptr;
+        if (unit_kind && (feats || g.rules_on) && n_str > 0 && total > 0) {
+            // featurize re-reads the code points and the rule interpreter has no narrow-unit form: widen once, on the device
+            if (total > 0 && ((uintptr_t)d_u8 & (unit_bytes - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
+            if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
+            HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)g.h_cps.p, st));
+            d_cps = (const uint32_t*)g.h_cps.p;
+            d_u8 = nullptr;
+        }
     } else if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
         BytesRoute br;
         if ((rc = decode_utf8_to_workspace(utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
@@ -599,7 +610,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
     int64_t* d_tile_first = (int64_t*)g.tile_first.p;
     if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first, d_u8)))
+                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind)))
         return rc;
     const int64_t* d_tcnt = (const int64_t*)g.wcnt.p;
     const uint16_t* d_pref = (const uint16_t*)g.wpref.p;
@@ -810,6 +821,106 @@ int latok_token_spans_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_
     static const uint8_t empty = 0;
     return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
                           flags, stream, nullptr, utf8 ? utf8 : &empty, true);
+}
+
+/* PEP 393 buffers (the reference's own input, latok.c:53-55,79): fixed-width code units of 1, 2 or 4 bytes */
+static int check_kind(int kind) {
+    if (kind != 1 && kind != 2 && kind != 4) return fail(LATOK_ERR_INVALID, "kind must be 1 (Latin-1), 2 (UCS-2) or 4 (UCS-4), got %d", kind);
+    return LATOK_OK;
+}
+
+int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                uint64_t* mask_bits_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = check_kind(kind);
+    if (rc) return rc;
+    if (kind == 4) return split_common((const uint32_t*)units, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
+    if ((rc = need_init())) return rc;
+    StreamTurn turn(stream);
+    hipStream_t st = turn.st;
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    int64_t total = total_chars;
+    if (dev) {
+        if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
+    } else if ((rc = check_csr_host(row_off, n_str, &total))) {
+        return rc;
+    }
+    if (total == 0) return LATOK_OK;
+    if (!units || !mask_bits_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    const uint8_t* d_units = (const uint8_t*)units;
+    const int64_t* d_row = row_off;
+    uint64_t* d_bits = mask_bits_out;
+    const size_t out_bytes = (size_t)((total + 63) / 64) * 8;
+    if (!dev) {
+        if ((rc = g.u_bytes.ensure((size_t)total * kind + 16))) return rc;
+        if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+        if ((rc = g.h_out.ensure(out_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(g.u_bytes.p, units, (size_t)total * kind, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.u_boff.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+        d_units = (const uint8_t*)g.u_bytes.p;
+        d_row = (const int64_t*)g.u_boff.p;
+        d_bits = (uint64_t*)g.h_out.p;
+    }
+    if (g.rules_on) {   // the rule interpreter reads code points: widen on the device
+        if (((uintptr_t)d_units & (size_t)(kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
+        if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
+        HIP_TRY(latok::launch_widen_units(d_units, kind, total, (uint32_t*)g.h_cps.p, st));
+        rc = run_pipeline((const uint32_t*)g.h_cps.p, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st);
+    } else {
+        rc = run_pipeline(nullptr, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, d_units, kind);
+    }
+    if (rc) return rc;
+    if (!dev) {
+        HIP_TRY(hipMemcpyAsync(mask_bits_out, d_bits, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LATOK_OK;
+}
+
+int latok_split_offsets_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                   int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
+                                   int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = check_kind(kind);
+    if (rc) return rc;
+    if (kind == 4)
+        return compact_common(false, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap,
+                              n_offsets_out, flags, stream);
+    static const uint8_t empty = 0;
+    return compact_common(false, nullptr, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap, n_offsets_out,
+                          flags, stream, nullptr, units ? (const uint8_t*)units : &empty, true, kind);
+}
+
+int latok_token_spans_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                 int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
+                                 int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = check_kind(kind);
+    if (rc) return rc;
+    if (kind == 4)
+        return compact_common(true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans_out, spans_cap,
+                              n_tokens_out, flags, stream);
+    static const uint8_t empty = 0;
+    return compact_common(true, nullptr, row_off, n_str, total_chars, counts_out, spans_out, spans_cap, n_tokens_out, flags,
+                          stream, nullptr, units ? (const uint8_t*)units : &empty, true, kind);
+}
+
+int latok_token_features_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
+                                    int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
+                                    int64_t* n_tokens_out, int flags, void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = check_kind(kind);
+    if (rc) return rc;
+    if (!features_out && cap > 0) return fail(LATOK_ERR_INVALID, "features_out is NULL");
+    static int8_t dummy = 0;
+    int8_t* f = features_out ? features_out : &dummy;
+    if (kind == 4)
+        return compact_common(true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out,
+                              flags, stream, f);
+    static const uint8_t empty = 0;
+    return compact_common(true, nullptr, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
+                          f, units ? (const uint8_t*)units : &empty, true, kind);
 }
 
 int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,

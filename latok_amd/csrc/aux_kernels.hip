@@ -368,6 +368,28 @@ hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* b
     return hipGetLastError();
 }
 
+// ---- PEP 393 code units -> UTF-32 (the entry points that need code points in HBM: featurize, run-time rule tables) ----
+template <typename T>
+__global__ void k_widen_units(const T* __restrict__ units, int64_t n, uint32_t* __restrict__ cps) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 + 4 <= n && ((uintptr_t)units & (4 * sizeof(T) - 1)) == 0) {
+        T u[4];
+        if (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(u) = *reinterpret_cast<const uint32_t*>(units + i0);
+        else *reinterpret_cast<uint2*>(u) = *reinterpret_cast<const uint2*>(units + i0);
+        *reinterpret_cast<uint4*>(cps + i0) = make_uint4(u[0], u[1], u[2], u[3]);
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + 4; ++i) cps[i] = units[i];
+    }
+}
+
+hipError_t launch_widen_units(const void* units, int kind, int64_t n, uint32_t* cps, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    if (kind == 1) hipLaunchKernelGGL(k_widen_units<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)units, n, cps);
+    else hipLaunchKernelGGL(k_widen_units<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)units, n, cps);
+    return hipGetLastError();
+}
+
 // ---- synthetic corpus ------------------------------------------------------------------------------------------
 __global__ void k_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str,
                               const int64_t* __restrict__ row_off, uint32_t* __restrict__ cps) {

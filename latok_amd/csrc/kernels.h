@@ -24,7 +24,12 @@ constexpr int kModeBlockMask = 2;        // compat _gen_block_mask: planes from 
 constexpr int kModeRules = 3;            // kModeBits with caller-supplied C_SPLIT / C_MASK / C_SYM (SplitParams::rules)
 constexpr int kModeBytes = 4;            // kModeBits in BYTE space: input = UTF-8 bytes (SplitParams::u8), row_off = byte
                                          // offsets, bit i of the mask = byte i (set at the lead byte of a boundary char)
-constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules || mode == kModeBytes; }
+constexpr int kModeLatin1 = 5;           // kModeBits on PEP 393 kind-1 input: SplitParams::u8 = one BYTE per char (U+0000..U+00FF)
+constexpr int kModeUcs2 = 6;             // kModeBits on PEP 393 kind-2 input: SplitParams::u8 = one uint16 per char
+// modes whose input is SplitParams::u8 and whose tiles use the byte-space LDS layout (pads, 16-byte halo)
+constexpr bool mode_is_bytes(int mode) { return mode == kModeBytes || mode == kModeLatin1 || mode == kModeUcs2; }
+constexpr bool mode_is_units(int mode) { return mode == kModeLatin1 || mode == kModeUcs2; }
+constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules || mode_is_bytes(mode); }
 
 constexpr long long kNegInf64 = -(1ll << 60);
 constexpr int kWPB = 12;                 // waves per workgroup: 768 threads -> 168 VGPRs per lane, one workgroup per CU
@@ -40,7 +45,7 @@ struct Hd64 {        // head descriptor of a run of tiles: starts before its fir
 
 struct SplitParams {
     const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
-    const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); cps is unused
+    const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); kModeLatin1 / kModeUcs2: the code units; cps is unused
     const int64_t* row_off;     // [n_str + 1]
     int64_t n_str, total, n_tiles;
     int seg_tiles;              // tiles per segment (16..1024)
@@ -109,6 +114,7 @@ hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* b
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,
                               const int64_t* block_base, uint16_t* chunk_pref, int64_t total_cps, uint32_t* cps,
                               int64_t* cp_off, hipStream_t st);
+hipError_t launch_widen_units(const void* units, int kind, int64_t n, uint32_t* cps, hipStream_t st);   // kind 1 / 2 -> UTF-32
 hipError_t launch_corpus_fill(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off,
                               uint32_t* cps, hipStream_t st);
 hipError_t launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int n_cu, hipStream_t st);

@@ -168,6 +168,100 @@ struct ByteCarry {
     int left;
 };
 
+// kModeLatin1 / kModeUcs2 (PEP 393 kinds 1 / 2: Latin-1 / UCS-2 code units), phase 1: the tile is 4096 CHARS of 1 or
+// 2 bytes each.  Nothing is decoded and there are no continuation bytes, so the staging buffer receives plain codes and
+// phase 2 evaluates the char-space rules (lk_rules), exactly like a UTF-32 tile; only the LDS layout is the byte-space one.
+// Halo: halo[0] = code of unit t0-1, halo[8], halo[9] = codes of units t0+4096, t0+4097 (0 where there is no such char).
+template <int KIND>
+__device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
+    const int64_t total = P.total;
+    if (lane < 2) *reinterpret_cast<lk_u64*>(L.halo + 8u * lane) = 0ull;
+    uint32_t halo_u = 0xFFFFFFFFu;                                              // out of range -> class 0
+    if (lane < 3) {
+        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
+        if (hp >= 0 && hp < total)
+            halo_u = KIND == 1 ? (uint32_t)P.u8[hp] : (uint32_t)reinterpret_cast<const uint16_t*>(P.u8)[hp];
+    }
+    if (KIND == 1) {
+        // Latin-1: U+0000..U+00FF live in the first two stage-2 blocks -> one lookup per byte
+        const uint32_t off0 = (uint32_t)L.t1[0] << kTblShift, off1 = ((uint32_t)L.t1[1] << kTblShift) - 128u;
+        auto code_of = [&](uint32_t b) -> uint32_t { return L.t2[b + ((b & 0x80u) ? off1 : off0)]; };
+        u32x4 v[4];
+        if (t0 + kTile <= total) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(P.u8 + t0) + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                uint32_t d[4] = {0, 0, 0, 0};
+                const int64_t p = t0 + 1024 * i + 16 * lane;
+                for (int j = 0; j < 16; ++j)
+                    if (p + j < total) d[j >> 2] |= (uint32_t)P.u8[p + j] << (8 * (j & 3));
+                v[i].x = d[0]; v[i].y = d[1]; v[i].z = d[2]; v[i].w = d[3];
+            }
+        }
+        wave_lds_sync();   // the zero stores to the halo are ordered before the halo stores below
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t cc[4];
+            if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cc[j] = (uint32_t)L.t2[off0 + (d[j] & 0xFFu)] | ((uint32_t)L.t2[off0 + ((d[j] >> 8) & 0xFFu)] << 8) |
+                            ((uint32_t)L.t2[off0 + ((d[j] >> 16) & 0xFFu)] << 16) | ((uint32_t)L.t2[off0 + (d[j] >> 24)] << 24);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cc[j] = code_of(d[j] & 0xFFu) | (code_of((d[j] >> 8) & 0xFFu) << 8) | (code_of((d[j] >> 16) & 0xFFu) << 16) |
+                            (code_of(d[j] >> 24) << 24);
+            }
+            // positions past the end of the batch hold unit 0 here; their codes are masked by `valid` in phase 2
+            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+        }
+        if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = (uint8_t)code_of(halo_u);
+    } else {
+        // UCS-2: 8 units per 16-byte load, row i of the tile = units 512 i + 8 lane ..
+        u32x4 v[8];
+        if (t0 + kTile <= total) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(P.u8) + t0) + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        } else {
+            const uint16_t* __restrict__ u16 = reinterpret_cast<const uint16_t*>(P.u8);
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                uint32_t d[4] = {0, 0, 0, 0};   // units past the end read as 0, like the bytes of a UTF-8 tail tile
+                const int64_t p = t0 + 512 * i + 8 * lane;
+                for (int j = 0; j < 8; ++j)
+                    if (p + j < total) d[j >> 1] |= (uint32_t)u16[p + j] << (16 * (j & 1));
+                v[i].x = d[0]; v[i].y = d[1]; v[i].z = d[2]; v[i].w = d[3];
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            uint32_t lo, hi;
+            if (__all(((d[0] | d[1] | d[2] | d[3]) & 0xFF80FF80u) == 0u)) {      // 512 ASCII chars: stage-2 block of U+0000
+                const uint32_t off0 = (uint32_t)L.t1[0] << kTblShift;
+                lo = (uint32_t)L.t2[off0 + (d[0] & 0xFFFFu)] | ((uint32_t)L.t2[off0 + (d[0] >> 16)] << 8) |
+                     ((uint32_t)L.t2[off0 + (d[1] & 0xFFFFu)] << 16) | ((uint32_t)L.t2[off0 + (d[1] >> 16)] << 24);
+                hi = (uint32_t)L.t2[off0 + (d[2] & 0xFFFFu)] | ((uint32_t)L.t2[off0 + (d[2] >> 16)] << 8) |
+                     ((uint32_t)L.t2[off0 + (d[3] & 0xFFFFu)] << 16) | ((uint32_t)L.t2[off0 + (d[3] >> 16)] << 24);
+            } else {
+                lo = classify1(L.t1, L.t2, d[0] & 0xFFFFu) | (classify1(L.t1, L.t2, d[0] >> 16) << 8) |
+                     (classify1(L.t1, L.t2, d[1] & 0xFFFFu) << 16) | (classify1(L.t1, L.t2, d[1] >> 16) << 24);
+                hi = classify1(L.t1, L.t2, d[2] & 0xFFFFu) | (classify1(L.t1, L.t2, d[2] >> 16) << 8) |
+                     (classify1(L.t1, L.t2, d[3] & 0xFFFFu) << 16) | (classify1(L.t1, L.t2, d[3] >> 16) << 24);
+            }
+            *reinterpret_cast<uint2*>(L.stage + stage_addr(512u * i + 8u * lane)) = make_uint2(lo, hi);
+        }
+        if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = (uint8_t)classify1(L.t1, L.t2, halo_u);
+    }
+}
+
 __device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
     const int64_t total = P.total;
     const uint8_t* __restrict__ u8 = P.u8;
@@ -394,7 +488,16 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
         lk_bitslice64(d, plane);
-        if (MODE == kModeBytes) {
+        if (mode_is_units(MODE)) {
+            // one code per char like a UTF-32 tile, in the byte-space layout: the two chars after my row are the next row's
+            // first codes (lane 63: halo[8], halo[9])
+            lk_halo ha;
+            ha.prev = h.prev;
+            ha.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[8];
+            ha.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[9];
+            loc = lk_rules(lk_decode(plane), ha, B, Bn);
+            space_plane = loc.S;
+        } else if (MODE == kModeBytes) {
             // byte space: continuation bits of my row / of the 8 bytes after it, smeared codes of those 8 bytes
             const lk_u64 C = *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 64u);
             lk_halo_bytes hb;
@@ -494,7 +597,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         if (mode_writes_bits(MODE)) {
             out_word = ((loc.raw & keep) | loc.sym | B) & valid;
             if (!DEFER) P.bits_out[base >> 6] = out_word;
-            if (P.space_out) P.space_out[base >> 6] = (MODE == kModeBytes ? space_plane : loc.S) & valid;   // token-span mode only
+            if (P.space_out) P.space_out[base >> 6] = (mode_is_bytes(MODE) ? space_plane : loc.S) & valid;   // token-span mode only
         } else {
             // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
             // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the
@@ -556,7 +659,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     // the next 64 strings and the three halo characters
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
-    if (MODE != kModeBlockMask && MODE != kModeBytes && lane < 3) {
+    if (MODE != kModeBlockMask && !mode_is_bytes(MODE) && lane < 3) {
         const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
         if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
     }
@@ -564,6 +667,10 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
+    } else if (MODE == kModeLatin1) {
+        units_phase1<1>(P, L, t0, lane);
+    } else if (MODE == kModeUcs2) {
+        units_phase1<2>(P, L, t0, lane);
     } else if (MODE == kModeBytes) {
         bytes_phase1(P, L, t0, lane);
     } else if (t0 + kTile <= total) {
@@ -591,7 +698,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
-    if (MODE != kModeBlockMask && MODE != kModeBytes && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
+    if (MODE != kModeBlockMask && !mode_is_bytes(MODE) && lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
     L.bw[lane] = 0;
     if (lane == 0) L.bw[64] = 0;
     LATOK_STAMP(2);
@@ -1080,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
             if (q_in != 0 || tz != tz0) {
                 const int geom = s.w;
                 // (byte mode: only tiles without multi-byte chars, where "last char of a block" = "last position")
-                if ((MODE == kModeBits || MODE == kModeBytes) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
+                if ((MODE == kModeBits || mode_is_bytes(MODE)) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
                     (q_in == 0 || s.z == 0)) {
                     // Patch in place: one pending start entering a tile whose head block has no start of its own
                     // zeroes that head block; a tail block that turns out to be zeroed is cleared.  What stays in a
@@ -1645,6 +1752,8 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
     else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);
+    else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, block, 0, st, P);
+    else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
@@ -1663,6 +1772,14 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
         if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 2>), grid, dim3(128), 0, st, P);
         else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 4>), grid, dim3(256), 0, st, P);
         else hipLaunchKernelGGL((k_resolve_fix<kModeBytes, kWPB>), grid, block, 0, st, P);
+    } else if (mode == kModeLatin1) {
+        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeLatin1, 2>), grid, dim3(128), 0, st, P);
+        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeLatin1, 4>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((k_resolve_fix<kModeLatin1, kWPB>), grid, block, 0, st, P);
+    } else if (mode == kModeUcs2) {
+        if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeUcs2, 2>), grid, dim3(128), 0, st, P);
+        else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeUcs2, 4>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((k_resolve_fix<kModeUcs2, kWPB>), grid, block, 0, st, P);
     } else hipLaunchKernelGGL((k_resolve_fix<kModeBlockMask, kWPB>), grid, block, 0, st, P);
     return hipGetLastError();
 }

@@ -56,6 +56,10 @@ ALPHABETS = {
     "nospace_at": list("abcdefgh@"),
     "rare_space_at": list("abcdefgh@") + [" "],
     "words": list("abc ") + ["#x", "http://a", ".@u", "a@b"],
+    # PEP 393 kind 1 (every char <= U+00FF, with Latin-1 letters, symbols and the no-break space) and kind 2 (BMP only,
+    # with a lone surrogate, a noncharacter, a combining mark and the ideographic space)
+    "latin1": list("abcXYZ  \t.,:/@#$1 9\xe9\xc9\xd7\xb5\xa0\xff\xbf\xaa") + ["http://\xe9", "a@\xf1"],
+    "bmp": list("abcXYZ  \t.,:/@#1 9\xe9\u3042\u65e5\u0301\u2167\u3000\ud800\uffff\u0416\u03b4") + ["http://\u65e5", "a@\u0436"],
 }
 
 

@@ -520,6 +520,112 @@ def test_positions_beyond_int32(gpu, oracle):
             lib.latok_dev_free(p)
 
 
+@pytest.mark.parametrize("alpha,dtype", [("latin1", np.uint8), ("bmp", np.uint16), ("words", np.uint8), ("mixed", np.uint32)])
+def test_pep393_kinds(gpu, oracle, alpha, dtype):
+    """The reference's own input format (PyUnicode_KIND 1 / 2 / 4, latok.c:53-55,79): the narrow code units go to the
+    device as they are.  Mask against the oracle on the same text; offsets / spans / featurize against the UTF-32 entry
+    points; run-time rule tables; tiny, ragged, empty and multi-tile batches (tile tails, halo chars across tiles)."""
+    from latok_amd import batch
+    from conftest import RULE_SETS, oracle_rule_bits
+    rng = random.Random(393 + len(alpha))
+    A = ALPHABETS[alpha]
+    batches = [
+        [G1 if alpha != "bmp" else G1 + "\u65e5\u672c"],
+        random_strings(rng, 300, 0, 60, A) + ["", ""],
+        random_strings(rng, 700, 0, 90, A) + random_strings(rng, 3, 3000, 9000, A) + ["", "x"],
+        random_strings(rng, 2, 4096, 4096, A) + random_strings(rng, 1, 4095, 4095, A) + random_strings(rng, 3, 1, 2, A),
+        random_strings(rng, 2000, 1, 3, A),
+    ]
+    for texts in batches:
+        units, row = batch.pack_kind(texts)
+        if sum(map(len, texts)) > 200:
+            assert units.dtype == dtype
+        cps, row32 = pack(texts)
+        assert np.array_equal(row, row32) and np.array_equal(units.astype(np.uint32), cps)
+        ov, ob = oracle.split_batch(cps, row)
+        assert np.array_equal(batch.split_mask_kind_csr(units, row), ob)
+        c1, o1 = batch.split_offsets_kind_csr(units, row)
+        exp = [np.nonzero(ov[row[s]:row[s + 1]])[0] for s in range(len(texts))]
+        assert np.array_equal(c1, [len(e) for e in exp]) and np.array_equal(o1, np.concatenate(exp))
+        c2, s2 = batch.token_spans_kind_csr(units, row)
+        w2 = batch.token_spans_csr(cps, row)
+        assert np.array_equal(c2, w2[0]) and np.array_equal(s2, w2[1])
+        c3, s3, f3 = batch.token_features_kind_csr(units, row)
+        w3 = batch.token_features_csr(cps, row)
+        assert np.array_equal(c3, w3[0]) and np.array_equal(s3, w3[1]) and np.array_equal(f3, w3[2])
+        if int(row[-1]) < 40000:
+            tables = RULE_SETS["sym_everywhere"]
+            batch.set_rules(*tables)
+            try:
+                assert np.array_equal(batch.split_mask_kind_csr(units, row), oracle_rule_bits(oracle, texts, tables))
+                c4, o4 = batch.split_offsets_kind_csr(units, row)
+                w4 = batch.split_offsets_csr(cps, row)
+                assert np.array_equal(c4, w4[0]) and np.array_equal(o4, w4[1])
+            finally:
+                batch.reset_rules()
+    # all-empty batch, no strings, bad kind
+    u0 = np.zeros(0, dtype)
+    assert batch.split_mask_kind_csr(u0, np.zeros(4, np.int64)).size == 0
+    c, o = batch.split_offsets_kind_csr(u0, np.zeros(4, np.int64))
+    assert c.tolist() == [0, 0, 0] and o.size == 0
+    assert batch.token_spans_kind_csr(u0, np.zeros(1, np.int64))[0].size == 0
+    from latok_amd import _lib
+    with pytest.raises(ValueError):
+        _lib.check(gpu.latok_split_mask_kind_batch(None, 3, None, 0, 0, None, 0, None))
+
+
+def test_pep393_kinds_device_pointers(gpu, oracle):
+    """Kind 1 / 2 units resident in HBM (LATOK_DEVICE_PTRS), outputs in HBM: same results as the host-pointer forms."""
+    from latok_amd import _lib, batch
+    lib = gpu
+    D = _lib.DEVICE_PTRS
+    rng = random.Random(3932)
+    for alpha in ("latin1", "bmp"):
+        A = ALPHABETS[alpha]
+        texts = random_strings(rng, 900, 0, 120, A) + random_strings(rng, 4, 5000, 9000, A) + ["", "y"]
+        units, row = batch.pack_kind(texts)
+        kind = units.dtype.itemsize
+        n, total = len(texts), int(row[-1])
+        ptrs = []
+
+        def dev(a=None, nbytes=0):
+            p = lib.latok_dev_alloc((a.nbytes if a is not None else nbytes) + 64)
+            assert p
+            ptrs.append(p)
+            if a is not None:
+                _lib.check(lib.latok_memcpy_h2d(p, a.ctypes.data, a.nbytes))
+            return p
+
+        def back(p, shape, dtype):
+            out = np.empty(shape, dtype)
+            if out.nbytes:
+                _lib.check(lib.latok_memcpy_d2h(out.ctypes.data, p, out.nbytes))
+            return out
+
+        try:
+            d_units, d_row = dev(units), dev(row)
+            words = (total + 63) // 64
+            d_bits, d_counts, d_items, d_feat = dev(nbytes=words * 8), dev(nbytes=n * 8), dev(nbytes=total * 32), dev(nbytes=total * 25)
+            nout = C.c_int64(0)
+            _lib.check(lib.latok_split_mask_kind_batch(d_units, kind, d_row, n, total, d_bits, D, None))
+            _lib.check(lib.latok_sync())
+            assert np.array_equal(back(d_bits, words, np.uint64), batch.split_mask_kind_csr(units, row))
+            _lib.check(lib.latok_split_offsets_kind_batch(d_units, kind, d_row, n, -1, d_counts, d_items, total, C.byref(nout), D, None))
+            hc, ho = batch.split_offsets_kind_csr(units, row)
+            assert nout.value == ho.size and np.array_equal(back(d_counts, n, np.int64), hc)
+            assert np.array_equal(back(d_items, nout.value, np.int64), ho)
+            _lib.check(lib.latok_token_spans_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, total, C.byref(nout), D, None))
+            hc, hs = batch.token_spans_kind_csr(units, row)
+            assert nout.value == len(hs) and np.array_equal(back(d_items, (nout.value, 2), np.int64), hs)
+            _lib.check(lib.latok_token_features_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, d_feat, total, C.byref(nout), D, None))
+            hc, hs, hf = batch.token_features_kind_csr(units, row)
+            assert nout.value == len(hs) and np.array_equal(back(d_items, (nout.value, 4), np.int64), hs)
+            assert np.array_equal(back(d_feat, (nout.value, 25), np.int8), hf)
+        finally:
+            for p in ptrs:
+                lib.latok_dev_free(p)
+
+
 def test_utf8_ingest(gpu, oracle):
     """UTF-8 CSR input: device decode == Python's decoder, and offsets / spans equal the UTF-32 path."""
     from latok_amd import batch

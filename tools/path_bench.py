@@ -10,6 +10,9 @@
   utf8_spans      latok_token_spans_utf8_batch
   bytes_mask / bytes_offsets / bytes_spans   latok_*_utf8_bytes_batch (8f-3 fused: the tile kernel reads the bytes)
   rules_mask      latok_split_mask_batch after latok_set_rules(built-in tables)   (8f-4)
+  kind_mask / kind_offsets / kind_spans      latok_*_kind_batch on PEP 393 code units: kind 1 (uint8) when every char
+                  of the corpus is <= U+00FF (C2), else kind 2 (uint16) with the corpus' astral chars folded into the BMP
+                  (cp & 0xFFFF; timing only -- C3 as CPython would store it without its emoji)
 
 Every line carries: ms per call (wall clock around `--iters` blocking calls, inputs and outputs in HBM; the
 compaction calls contain one 8-byte blocking read of the item total), the UTF-8 GB/s of the corpus through that path,
@@ -58,7 +61,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
     ap.add_argument("--paths", default="mask,offsets,spans,features,utf8_mask,utf8_offsets,utf8_spans,"
-                                       "bytes_mask,bytes_offsets,bytes_spans,rules_mask")
+                                       "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_spans")
     args = ap.parse_args()
     lib = _lib.ensure_init()
     model, seed, lo, hi = WORKLOADS[args.workload]
@@ -153,6 +156,23 @@ def main():
                 lambda: 4 * total + csr + words * 8, "as mask; tables interpreted at run time")
         finally:
             batch.reset_rules()
+
+    if any(p.startswith("kind_") for p in paths):
+        kind = 1 if int(cps.max()) < 256 else 2
+        units = cps.astype(np.uint8) if kind == 1 else (cps & 0xFFFF).astype(np.uint16)
+        d_units = lib.latok_dev_alloc(units.nbytes + 64)
+        _lib.check(lib.latok_memcpy_h2d(d_units, units.ctypes.data, units.nbytes))
+        note = f"{kind} B/char + 8 B/string read"
+        if "kind_mask" in paths:
+            nout.value = 0
+            run("kind_mask", lambda: lib.latok_split_mask_kind_batch(d_units, kind, d_row, n, total, d_bits, D, None),
+                lambda: kind * total + csr + words * 8, note + "; 1 bit/char written")
+        if "kind_offsets" in paths:
+            run("kind_offsets", lambda: lib.latok_split_offsets_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+                lambda: kind * total + csr + 8 * n + 8 * nout.value, note + "; 8 B/string counts + 8 B/boundary written")
+        if "kind_spans" in paths:
+            run("kind_spans", lambda: lib.latok_token_spans_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
+                lambda: kind * total + csr + 8 * n + 16 * nout.value, note + "; 8 B/string counts + 16 B/token written")
 
     if args.cpu > 0:   # baseline only: the reference's own C (oracle/_ref) under its restated glue, one string at a time
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

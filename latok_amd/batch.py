@@ -69,12 +69,23 @@ def split_offsets_csr(cps, row_off):
     return counts, offsets[:n_off.value].copy()
 
 
+# host batches beyond the library's small-batch path (api.cpp: kSmallChars / kSmallStrings, served from pinned memory
+# in UTF-32) are shipped as the narrowest PEP 393 kind: 1 or 2 bytes per char over the bus instead of 4
+_SMALL_CHARS, _SMALL_STRINGS = 16384, 512
+
+
+def _narrow_pays(texts):
+    return len(texts) > _SMALL_STRINGS or sum(map(len, texts)) > _SMALL_CHARS
+
+
 def split_offsets_batch(texts):
     """list[str] -> list of int64 arrays = np.nonzero(split mask)[0] of every string ('' -> empty array)."""
     if len(texts) == 0:
         return []
-    cps, row_off = pack(texts)
-    counts, offsets = split_offsets_csr(cps, row_off)
+    if _narrow_pays(texts):
+        counts, offsets = split_offsets_kind_csr(*pack_kind(texts))
+    else:
+        counts, offsets = split_offsets_csr(*pack(texts))
     return np.split(offsets, np.cumsum(counts)[:-1])
 
 
@@ -115,8 +126,10 @@ def featurize_batch(texts):
     from .core.latok_utils import LaToken
     if len(texts) == 0:
         return []
-    cps, row_off = pack(texts)
-    counts, spans, feats = token_features_csr(cps, row_off)
+    if _narrow_pays(texts):
+        counts, spans, feats = token_features_kind_csr(*pack_kind(texts))
+    else:
+        counts, spans, feats = token_features_csr(*pack(texts))
     out, k = [], 0
     for text, n in zip(texts, counts.tolist()):
         out.append([LaToken(text[c:d], a, b, feats[k + j]) for j, (a, b, c, d) in enumerate(spans[k:k + n].tolist())])
@@ -356,8 +369,10 @@ def tokenize_batch(texts):
     an empty string yields [] instead of the reference's IndexError."""
     if len(texts) == 0:
         return []
-    cps, row_off = pack(texts)
-    counts, spans = token_spans_csr(cps, row_off)
+    if _narrow_pays(texts):
+        counts, spans = token_spans_kind_csr(*pack_kind(texts))
+    else:
+        counts, spans = token_spans_csr(*pack(texts))
     out, k = [], 0
     for text, n in zip(texts, counts.tolist()):
         out.append([text[a:b] for a, b in spans[k:k + n].tolist()])

@@ -4,7 +4,7 @@
 Worker processes build random batches from adversarial alphabets in several shape regimes (many tiny strings, tweets,
 multi-tile documents, no-whitespace documents with starts, dense starts) and compute the oracle's split values / bitmask on
 the CPU; the main process runs the same batch through the C ABI (values, bitmask, offsets, token spans, the bitmask
-under run-time rule tables, featurize sums, and the UTF-8 entry points in byte space and in code-point units) and compares bit for bit.  Stops after --seconds.
+under run-time rule tables, featurize sums, the UTF-8 entry points in byte space and in code-point units, and the PEP 393 kind-1 / kind-2 entry points) and compares bit for bit.  Stops after --seconds.
 
 usage: tools/soak.py [--seconds 120] [--workers 12] [--seed 1]
 """
@@ -27,6 +27,8 @@ REGIMES = [
     ("mixed", (1, 3000), (0, 12)), ("mixed", (1, 400), (0, 200)), ("words", (1, 300), (0, 400)),
     ("starts", (1, 200), (0, 600)), ("mixed", (1, 4), (3000, 30000)), ("nospace_at", (1, 4), (4000, 40000)),
     ("rare_space_at", (1, 4), (4000, 40000)), ("starts", (500, 4000), (1, 3)), ("words", (1, 6), (8000, 20000)),
+    ("latin1", (1, 400), (0, 200)), ("bmp", (1, 400), (0, 200)), ("latin1", (1, 4), (3000, 30000)), ("bmp", (1, 4), (3000, 30000)),
+    ("bmp", (500, 3000), (1, 3)),
 ]
 
 
@@ -112,7 +114,7 @@ def main():
     args = ap.parse_args()
     from latok_amd import batch
     t_end = time.time() + args.seconds
-    n_batches = n_chars = n_rules = n_spans = n_u8 = n_feat = 0
+    n_batches = n_chars = n_rules = n_spans = n_u8 = n_feat = n_kind = 0
     seed = args.seed * 1_000_003
     last = time.time()
     with mp.Pool(args.workers) as pool:
@@ -150,6 +152,26 @@ def main():
                 assert ff.shape == feats[0].shape and np.array_equal(ff, feats[0]), "featurize sums differ: " + tag
                 assert np.array_equal(fs, feats[1]), "featurize span records differ: " + tag
                 n_feat += 1
+            if cps.size > 0 and int(cps.max()) < 65536:
+                # PEP 393 kinds: the same text as 1- or 2-byte code units
+                units = cps.astype(np.uint8 if int(cps.max()) < 256 else np.uint16)
+                assert np.array_equal(batch.split_mask_kind_csr(units, row), bits), "kind bitmask differs: " + tag
+                kc, ko = batch.split_offsets_kind_csr(units, row)
+                assert np.array_equal(kc, counts) and np.array_equal(ko, offs), "kind offsets differ: " + tag
+                if cps.size < 20000:
+                    kc, ks = batch.token_spans_kind_csr(units, row)
+                    assert np.array_equal(kc, wc) and np.array_equal(ks, ws), "kind token spans differ: " + tag
+                if rules is not None:
+                    batch.set_rules(*rules)
+                    try:
+                        rb = batch.split_mask_kind_csr(units, row)
+                    finally:
+                        batch.reset_rules()
+                    assert np.array_equal(rb, rule_bits), "kind rule-table bitmask differs: " + tag
+                if feats is not None:
+                    fc, fs, ff = batch.token_features_kind_csr(units, row)
+                    assert np.array_equal(ff, feats[0]) and np.array_equal(fs, feats[1]), "kind featurize differs: " + tag
+                n_kind += 1
             if u8 is not None and cps.size > 0:
                 # byte space: boundaries at the lead byte of every boundary char; staged path: code-point units
                 flags = np.zeros(u8.size, bool)
@@ -168,10 +190,10 @@ def main():
             n_chars += cps.size
             if time.time() - last > 30:
                 last = time.time()
-                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8, {n_feat} featurize ... ok",
+                print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8, {n_feat} featurize, {n_kind} PEP 393 kinds ... ok",
                       flush=True)
     print(f"soak passed: {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
-          f"{n_u8} UTF-8 (byte space + code-point) checks, {n_feat} featurize checks, {args.seconds:.0f} s")
+          f"{n_u8} UTF-8 (byte space + code-point) checks, {n_feat} featurize checks, {n_kind} PEP 393 kind checks, {args.seconds:.0f} s")
 
 
 if __name__ == "__main__":

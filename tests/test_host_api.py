@@ -93,6 +93,23 @@ def test_pack_and_token_materialisation(oracle):
         batch._csr(np.zeros(3, np.uint32), np.array([0, 5], np.int64))
 
 
+def test_pack_kind_picks_the_narrowest_pep393_kind():
+    """batch.pack_kind: the code units CPython itself would store for the joined text (kind 1 / 2 / 4), same chars as pack()."""
+    from latok_amd import batch
+    cases = [(["abc", "", "d\xe9\xff"], np.uint8), (["abc", "\u65e5\u672c", "\ud800x"], np.uint16),
+             (["abc", "\u65e5", "\U0001f913"], np.uint32), ([], np.uint8), (["", ""], np.uint8)]
+    for texts, dtype in cases:
+        units, row = batch.pack_kind(texts)
+        cps, row32 = batch.pack(texts)
+        assert units.dtype == dtype and np.array_equal(row, row32)
+        assert np.array_equal(units.astype(np.uint32), cps)
+    with pytest.raises(ValueError):
+        batch._csr_kind(np.zeros(3, np.int32), np.array([0, 3], np.int64))
+    with pytest.raises(ValueError):
+        batch._csr_kind(np.zeros(3, np.uint16), np.array([0, 5], np.int64))
+    assert batch._narrow_pays(["x" * 20000]) and batch._narrow_pays([""] * 600) and not batch._narrow_pays(["abc"])
+
+
 def test_compat_argument_errors_do_not_need_a_gpu():
     from latok_amd import latok as ext
     with pytest.raises(ValueError, match="must specify string"):

@@ -189,6 +189,10 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
+    if (!d_tile_first) {   // the per-tile string index lives in the workspace unless the caller (compaction) wants to keep it
+        if ((rc = g.tile_first.ensure((size_t)n_tiles * 8 + 8))) return rc;
+        d_tile_first = (int64_t*)g.tile_first.p;
+    }
     P.tile_first = d_tile_first;
     P.summ = (int4*)g.summ.p;
     P.seg_fn = (latok::Fn64*)g.seg_agg.p;
@@ -197,6 +201,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.bm_a1 = bm_a1;
     P.bm_a2 = bm_a2;
     P.bm_flags = bm_flags;
+    HIP_TRY(latok::launch_tile_index(P, st));
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
     HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
     if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));

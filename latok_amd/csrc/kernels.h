@@ -55,7 +55,7 @@ struct SplitParams {
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
     uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
-    int64_t* tile_first;        // optional [n_tiles]: first string that starts at or after each tile's first char
+    int64_t* tile_first;        // [n_tiles]: first string that starts at or after each tile's first char (k_tile_index; also read by the compaction passes)
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
     Fn64* seg_fn;               // [n_segs] segment aggregates
     Hd64* seg_hd;               // [n_segs]
@@ -88,6 +88,7 @@ struct FeatParams {
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
 
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs);
+hipError_t launch_tile_index(const SplitParams& P, hipStream_t st);   // stage 0: P.tile_first (must be set)
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st);

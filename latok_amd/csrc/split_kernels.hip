@@ -998,57 +998,20 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 
 template <int MODE>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
-                                            int wave LATOK_STAMP_PARAM) {
+                                            int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
     const TileLds L = wave_lds(lds, wave);
-    int* tf = reinterpret_cast<int*>(lds + kLdsTf);
     int4* sm = reinterpret_cast<int4*>(lds + kLdsSumm);
     ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
-    int* misc = reinterpret_cast<int*>(lds + kLdsMisc);
 
     const int64_t T0 = seg * S;
     const int64_t T1 = min(T0 + S, P.n_tiles);
     const int n_seg = (int)(T1 - T0);
-    // (a) first string of each tile of the segment.  One trip to memory when the row offsets are roughly evenly spaced:
-    //     a window of row_off around the range an even spacing predicts is read once and every entry fills the tiles it
-    //     is the first string of; if a tile stays unfilled the window missed, and the bounds are searched instead.
-    int64_t s_lo;
-    {
-        const int64_t n_entries = P.n_str + 1;
-        auto guess = [&](int64_t c) -> int64_t {
-            int64_t g = P.total > 0 ? (int64_t)((double)c * (double)P.n_str / (double)P.total) : 0;
-            return g < 0 ? 0 : (g > P.n_str ? P.n_str : g);
-        };
-        constexpr int64_t kMargin = 1536;
-        int64_t wlo = guess(T0 * kTile) - kMargin, whi = guess(T1 * kTile) + kMargin + 1;
-        if (wlo < 0) wlo = 0;
-        if (whi > n_entries) whi = n_entries;
-        if (tid < n_seg) tf[tid] = -1;
-        __syncthreads();
-        auto fill = [&](int64_t first, int64_t last_incl, int64_t base) {
-            for (int64_t s = first + tid; s <= last_incl && s <= P.n_str; s += kWPB * 64) {
-                const int64_t p = P.row_off[s];
-                const int64_t prev = s > 0 ? P.row_off[s - 1] : -1;
-                int64_t w0 = (prev < 0 ? 0 : prev / kTile + 1);
-                int64_t w1 = p / kTile;
-                if (w0 < T0) w0 = T0;
-                if (w1 > T1 - 1) w1 = T1 - 1;
-                for (int64_t w = w0; w <= w1; ++w) tf[w - T0] = (int)(s - base);
-            }
-        };
-        wlo = to_scalar64(wlo);
-        fill(wlo, whi - 1, wlo);
-        __syncthreads();
-        s_lo = wlo;
-        if (!__syncthreads_and(tid >= n_seg || tf[tid] >= 0)) {
-            int64_t lb0, lb1;
-            block_lower_bound_pair<kWPB * 64>(P.row_off, n_entries, P.total, T0 * kTile, T1 * kTile, misc, &lb0, &lb1);
-            s_lo = to_scalar64(lb0);
-            fill(s_lo, to_scalar64(lb1), s_lo);
-        }
-    }
-    __syncthreads();   // tables (first segment) and tf are in place
-    if (P.tile_first && tid < n_seg) P.tile_first[T0 + tid] = s_lo + tf[tid];   // the compaction passes reuse the index
+    // (a) first string of each tile: P.tile_first, written by k_tile_index before this kernel.  A wave takes the tiles
+    //     wave, wave + kWPB, ... of the segment -- at most 64 -- so one load per lane holds the whole segment's worth.
+    int64_t tfv = 0;
+    if (wave + kWPB * lane < n_seg) tfv = P.tile_first[T0 + wave + kWPB * lane];
+    if (tables) __syncthreads();   // the class tables (first segment of the workgroup) are in LDS
     // (b) the tiles
     // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
     // One 512-byte store per 16 KiB tile, interleaved with the read stream, costs ~5 % of HBM throughput.
@@ -1072,8 +1035,8 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
         if (++slot == 8) flush();
     };
-    for (int k = wave; k < n_seg; k += kWPB) {
-        const lk_u64 w = process_tile<MODE, kDefer>(P, L, T0 + k, s_lo + to_scalar(tf[k]), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
+    for (int k = wave, j = 0; k < n_seg; k += kWPB, ++j) {
+        const lk_u64 w = process_tile<MODE, kDefer>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
         stamp_acc[0] += 1;
@@ -1108,12 +1071,16 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar tile arithmetic
     if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
 
-    if (MODE != kModeBlockMask) load_tables(lds, P);   // the first segment's barriers publish the tables
+    bool tables = MODE != kModeBlockMask;
+    if (tables) load_tables(lds, P);   // published by the barrier at the top of the workgroup's first segment
 #ifdef LATOK_STAMPS
     unsigned long long stamp_acc[16];
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
 #endif
-    for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) run_segment<MODE>(P, lds, seg, tid, lane, wave LATOK_STAMP_ARG);
+    for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
+        run_segment<MODE>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
+        tables = false;
+    }
 #ifdef LATOK_STAMPS
     if (lane == 0)
         for (int i = 0; i < 9; ++i) atomicAdd(&g_stamp_sum[i], stamp_acc[i]);
@@ -1730,6 +1697,45 @@ hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st) 
 // ---------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// stage 0: the per-tile string index.  tile_first[t] = first s in [0, n_str] with row_off[s] >= t * kTile (row_off[n_str]
+// = total closes the list).  One thread per entry: entry s is the first string of every tile that begins in
+// (row_off[s-1], row_off[s]].  Entries that cover many tiles (a long document, the tail of the batch) are written by
+// the whole wave.  ~3 us for 1 M strings; inside k_tiles_main the same work was a ~9 us serial prologue of every segment
+// (tables -> row_off window -> barriers -> first tile: three dependent trips to memory before the stream started).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_index(const int64_t* __restrict__ row_off, int64_t n_str, int64_t n_tiles,
+                                                   int64_t* __restrict__ tile_first) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t w0 = 0, w1 = -1;
+    if (s <= n_str) {
+        const int64_t p = row_off[s];
+        const int64_t prev = s > 0 ? row_off[s - 1] : -1;
+        w0 = prev < 0 ? 0 : prev / kTile + 1;
+        w1 = p / kTile;
+        if (w1 > n_tiles - 1) w1 = n_tiles - 1;
+    }
+    const bool wide = w1 - w0 >= 16;
+    if (!wide)
+        for (int64_t w = w0; w <= w1; ++w) tile_first[w] = s;
+    unsigned long long m = __ballot(wide);
+    while (m) {   // wave-uniform
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int64_t a = lane_read64(w0, src), b = lane_read64(w1, src), v = lane_read64(s, src);
+        for (int64_t w = a + lane; w <= b; w += 64) tile_first[w] = v;
+    }
+}
+
+hipError_t launch_tile_index(const SplitParams& P, hipStream_t st) {
+    if (P.n_tiles <= 0) return hipSuccess;
+    const int64_t entries = P.n_str + 1;
+    hipLaunchKernelGGL(k_tile_index, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, P.row_off, P.n_str, P.n_tiles,
+                       P.tile_first);
+    return hipGetLastError();
+}
+
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
     // every workgroup gets the same number of (almost) equally sized segments: `rounds` segments of
     // ceil(n_tiles / (n_cu * rounds)) tiles, rounds = smallest count that keeps a segment within kSegMax tiles

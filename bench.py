@@ -188,7 +188,8 @@ def main():
     else:
         utf8_all, chars_all, strs_all = utf8.value, total, n_str
 
-    # ---- dominant kernel alone (HIP events around every launch, on the launch stream), outside the timed region ---
+    # ---- dominant kernel alone: `steps` back-to-back launches of k_tiles_main between one pair of HIP events on the launch
+    #      stream (per-launch event pairs charge each interval with ~6 us of marker dispatch), outside the timed region ---
     ms_tiles, n_fix = C.c_float(0), C.c_int64(0)
     _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, args.steps, None, C.byref(ms_tiles),
                                           C.byref(n_fix)))
@@ -229,6 +230,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_read, "kernel_ms": t_kernel * 1e3,
+                         "kernel_timing": f"{args.steps} back-to-back launches between one HIP event pair on the launch stream",
                          "pipeline_frac": alg_read / (ms_events.value / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS,
                          "measured_stream_read": measured_read,
                          "frac_of_measured_read": (achieved / measured_read) if measured_read else None},

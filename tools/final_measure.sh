@@ -16,7 +16,7 @@ for w in C2 C3 C5; do timeout -k 10 600 python bench.py --workload $w --steps 20
 timeout -k 10 600 python bench.py --workload C2 --strings 12500000 --steps 10 --warmup 2 --no-cpu-baseline >> $O/bench_all.jsonl 2>> $O/bench_all.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b /tmp/pmc_f /tmp/pmc_w
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_under_rocprof.json 2>/dev/null || exit 1
 cp /tmp/prof_b/b_kernel_stats.csv $O/kernel_stats_bench_c2.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_f -o f --output-format csv -- python3 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc_w -o w --output-format csv -- python3 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1

@@ -831,84 +831,8 @@ __device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// lower_bound over the row offsets: smallest s in [0, n_entries] with row_off[s] >= c (n_entries if none).
-// k-ary search: every thread of the block (or lane of the wave) probes one position per round, so 1 M strings need
-// two rounds (block) / four rounds (wave) of one L2 access each.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int64_t block_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
-                                                     int* scratch /* >= blockDim.x / 64 ints of LDS */) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NT = blockDim.x, NW = NT >> 6;
-    int64_t lo = 0, hi = n_entries;
-    while (hi > lo) {
-        const int64_t len = hi - lo;
-        const int64_t step = (len + NT - 1) / NT;
-        const int64_t p = lo + (int64_t)tid * step;
-        const bool pred = p < hi && row_off[p] >= c;
-        const lk_u64 m = __ballot(pred);
-        __syncthreads();
-        if (lane == 0) scratch[wave] = m ? wave * 64 + lk_ctz(m) : NT;
-        __syncthreads();
-        int f = NT;
-        for (int w = 0; w < NW; ++w) f = min(f, scratch[w]);
-        if (f == NT) {
-            const int64_t n_valid = (len + step - 1) / step;
-            lo = min(lo + (n_valid - 1) * step + 1, hi);   // everything probed is < c
-        } else {
-            hi = lo + (int64_t)f * step;                   // row_off[hi] >= c
-            if (f > 0) lo = lo + (int64_t)(f - 1) * step + 1;
-        }
-    }
-    return lo;
-}
-
-// Both lower bounds of a segment (first string at or after c0 and at or after c1) in ONE round of loads when the row
-// offsets are roughly evenly spaced: each half of the workgroup looks at a window of row_off around the position an
-// even spacing predicts, and counts the entries below its target.  The searched k-ary form above needs 2 dependent
-// rounds per bound, and at the start of a kernel every round is a trip to HBM (the segment prologue was ~9 us of a
-// 107 us kernel).  Falls back to the search for a bound that is not inside its window.  scratch: >= 2 * waves ints.
-template <int NT>
-__device__ __forceinline__ void block_lower_bound_pair(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t total,
-                                                       int64_t c0, int64_t c1, int* scratch, int64_t* lb0, int64_t* lb1) {
-    constexpr int kHalf = NT / 2, kE = 8, kWin = kHalf * kE;     // 384 threads x 8 entries = 3072 per window
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int which = tid >= kHalf;
-    const int64_t c = which ? c1 : c0;
-    int64_t guess = total > 0 ? (int64_t)((double)c * (double)(n_entries - 1) / (double)total) : 0;
-    int64_t wlo = guess - kWin / 2;
-    if (wlo > n_entries - kWin) wlo = n_entries - kWin;
-    if (wlo < 0) wlo = 0;
-    const int64_t e0 = wlo + (int64_t)(tid - which * kHalf) * kE;
-    int below = 0;
-#pragma unroll
-    for (int j = 0; j < kE; ++j)
-        if (e0 + j < n_entries && row_off[e0 + j] < c) ++below;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
-    __syncthreads();
-    if (lane == 0) scratch[wave] = below;
-    __syncthreads();
-    int cnt[2] = {0, 0};
-    for (int w = 0; w < NT / 64; ++w) cnt[w >= kHalf / 64] += scratch[w];
-    int64_t res[2];
-    bool ok[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int64_t ck = k ? c1 : c0;
-        int64_t g = total > 0 ? (int64_t)((double)ck * (double)(n_entries - 1) / (double)total) : 0;
-        int64_t lo = g - kWin / 2;
-        if (lo > n_entries - kWin) lo = n_entries - kWin;
-        if (lo < 0) lo = 0;
-        const int64_t hi = min(lo + kWin, n_entries);
-        res[k] = lo + cnt[k];
-        ok[k] = (cnt[k] > 0 || lo == 0) && (lo + cnt[k] < hi || hi == n_entries);   // the bound lies inside the window
-    }
-    __syncthreads();   // scratch is reused by the fallback
-    *lb0 = ok[0] ? res[0] : block_lower_bound(row_off, n_entries, c0, scratch);
-    *lb1 = ok[1] ? res[1] : block_lower_bound(row_off, n_entries, c1, scratch);
-}
-
+// lower_bound over the row offsets: smallest s in [0, n_entries] with row_off[s] >= c (n_entries if none).  64-ary
+// search by one wave: every lane probes one pivot, the ballot picks the sub-range (the resolve stage's rare recomputations).
 __device__ __forceinline__ int64_t wave_lower_bound(const int64_t* __restrict__ row_off, int64_t n_entries, int64_t c,
                                                     int lane) {
     int64_t lo = 0, hi = n_entries;
@@ -934,7 +858,7 @@ __device__ __forceinline__ int64_t wave_lower_bound(const int64_t* __restrict__ 
 // LDS map of both kernels (one workgroup of kWPB waves per CU)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kLdsWaves = kTablesLdsBytes;                         // 16 x kWaveLdsBytes
-constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSegMax]: first string of each tile of the segment
+constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSegMax]: k_resolve_fix's list of tiles to recompute
 constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
 constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
 constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
@@ -983,8 +907,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 // ---------------------------------------------------------------------------------------------------------------
 // stage 1: the tiles.  The tile range is cut into segments of P.seg_tiles (<= 1024) consecutive tiles; a workgroup
 // owns whole segments (grid-stride), its kWPB waves take the segment's tiles round-robin.  Per segment the workgroup
-//   (a) finds the first string of the segment with a block-wide k-ary search over row_off and derives, in LDS, the
-//       first string of every tile (this replaces a separate indexing pass over row_off),
+//   (a) fetches the first string of each of its tiles from the index stage 0 (k_tile_index) left in P.tile_first,
 //   (b) runs the tiles, each publishing its 16-byte summary to LDS and to global memory,
 //   (c) composes the segment's transfer function / head descriptor with a block-wide scan -> one aggregate per segment.
 // ---------------------------------------------------------------------------------------------------------------
@@ -1105,7 +1028,7 @@ __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
     const int S = P.seg_tiles;
     ScanLdsT<NW>& scan = *reinterpret_cast<ScanLdsT<NW>*>(lds + kLdsScan);
     int* misc = reinterpret_cast<int*>(lds + kLdsMisc);          // misc[0] = number of tiles to recompute
-    int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment
+    int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment (tiles to recompute)
     int2* fix_in = reinterpret_cast<int2*>(lds + kLdsSumm);      // {q_in, tail_zero}
     bool tables_loaded = false;
 

@@ -14,7 +14,9 @@
  *     (a hipStream_t, NULL = the library's own stream) and returns as soon as the work is enqueued.  Otherwise they
  *     are host pointers: the library stages through its own device buffers and the call is synchronous.
  *   - a batch is CSR: `cps` = packed UTF-32 code points of all strings, `row_off[n_str + 1]` = start of each string
- *     (row_off[0] == 0, non-decreasing).  Device `cps` pointers must be 16-byte aligned.
+ *     (row_off[0] == 0, non-decreasing).  Device `cps` pointers must be 16-byte aligned.  Host-pointer calls check
+ *     row_off and fail with LATOK_ERR_INVALID; device-resident row offsets cannot be checked without a copy, so a caller
+ *     that passes device pointers guarantees them (results are undefined otherwise).
  *   - `total_chars` = row_off[n_str]; the caller normally knows it.  Pass -1 to let the library read it (in device
  *     mode that costs one blocking 8-byte device->host copy).
  *   - threads and streams: host calls are serialised by an internal lock; all calls share one set of device workspaces,

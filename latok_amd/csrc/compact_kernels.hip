@@ -169,6 +169,7 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const int64_t t0 = w0 << 6;
     // first string starting at or after t0: published by the tile kernel (one wave = one tile), else searched
     int64_t idx0 = tile_first ? tile_first[w0 >> 6] : scatter_lower_bound(row_off, n_str, t0, lane);
+    idx0 = idx0 < 0 ? 0 : (idx0 > n_str ? n_str : idx0);
     if (idx0 > n_str) idx0 = n_str;
     const int64_t start_before = idx0 > 0 ? row_off[idx0 - 1] : 0;
     unsigned long long* bw = reinterpret_cast<unsigned long long*>(smax);

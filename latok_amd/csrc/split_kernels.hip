@@ -934,6 +934,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     //     wave, wave + kWPB, ... of the segment -- at most 64 -- so one load per lane holds the whole segment's worth.
     int64_t tfv = 0;
     if (wave + kWPB * lane < n_seg) tfv = P.tile_first[T0 + wave + kWPB * lane];
+    tfv = tfv < 0 ? 0 : (tfv > P.n_str ? P.n_str : tfv);   // (row offsets that are not non-decreasing leave holes in the index)
     if (tables) __syncthreads();   // the class tables (first segment of the workgroup) are in LDS
     // (b) the tiles
     // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
@@ -1203,6 +1204,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // ---- classify the tile into rule codes (mirror of process_tile phase 1) ---------------------------------------
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);
     int64_t idx0 = P.tile_first[t];
+    idx0 = idx0 < 0 ? 0 : (idx0 > P.n_str ? P.n_str : idx0);
     // start of the string that is open when the tile begins (spans are string relative)
     const int64_t start_before = idx0 > 0 ? P.row_off[idx0 - 1] : 0;
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;

@@ -1,7 +1,7 @@
 // api.cpp -- host side of liblatok_hip.so: the C ABI declared in include/latok_hip.h.
 //
 // Thin by design: argument checks, workspace management, H2D/D2H staging for host-pointer calls, and the launch
-// sequence of the two-stage pipeline (tiles -> resolve/repair).  No compute happens on the
+// sequence of the pipeline (tile index -> tiles -> resolve/repair).  No compute happens on the
 // host and there is no CPU fallback: without a HIP device every compute entry point fails.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>

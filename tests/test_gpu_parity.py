@@ -326,6 +326,31 @@ def test_long_documents(gpu, oracle):
     assert np.array_equal(ob, bits)
 
 
+def test_one_huge_document_between_small_strings(gpu, oracle):
+    """One 24 M-char document (5 860 tiles: several segments per workgroup, its entry of the tile index is written by a
+    whole wave) between tiny strings and empty ones: mask, offsets and token spans against the oracle / the small-batch
+    forms of the same strings."""
+    from latok_amd import batch
+    big_cps, _ = _device_corpus(gpu, 0x1A70C0E1, 0, 1, 24_000_000, 24_000_000)
+    small = ["ab c", "", "x@y.z", "", "#tag http://a.b"]
+    head, _ = pack(small[:3])
+    tail, _ = pack(small[3:])
+    cps = np.concatenate([head, big_cps, tail])
+    lens = [len(t) for t in small[:3]] + [big_cps.size] + [len(t) for t in small[3:]]
+    row = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=row[1:])
+    ov, ob = oracle.split_batch(cps, row)
+    assert np.array_equal(batch.split_mask_batch(cps, row), ob)
+    counts, offs = batch.split_offsets_csr(cps, row)
+    exp = [np.nonzero(ov[row[s]:row[s + 1]])[0] for s in range(len(lens))]
+    assert np.array_equal(counts, [len(e) for e in exp]) and np.array_equal(offs, np.concatenate(exp))
+    # token spans of the document alone == its spans inside the batch (string relative)
+    c_all, s_all = batch.token_spans_csr(cps, row)
+    c_doc, s_doc = batch.token_spans_csr(big_cps, np.array([0, big_cps.size], np.int64))
+    k0 = int(c_all[:3].sum())
+    assert c_all[3] == c_doc[0] and np.array_equal(s_all[k0:k0 + int(c_doc[0])], s_doc)
+
+
 def test_token_spans_on_device(gpu, oracle):
     """latok_token_spans_batch == the reference's slice/strip/drop-empty loop (default_tokenizer.py:149-158)."""
     from latok_amd import batch

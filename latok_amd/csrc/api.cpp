@@ -125,6 +125,7 @@ int ensure_workspace(int64_t n_tiles) {
     if ((rc = g.summ.ensure(t * 16))) return rc;
     if ((rc = g.seg_agg.ensure((t / 16 + 2) * 32))) return rc;   // <= one 32-byte aggregate pair per 16 tiles
     if ((rc = g.fix_count.ensure(8))) return rc;
+    if ((rc = g.tile_first.ensure(t * 8 + 8))) return rc;   // per-tile string index (stage 0)
     return LATOK_OK;
 }
 
@@ -189,10 +190,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
-    if (!d_tile_first) {   // the per-tile string index lives in the workspace unless the caller (compaction) wants to keep it
-        if ((rc = g.tile_first.ensure((size_t)n_tiles * 8 + 8))) return rc;
-        d_tile_first = (int64_t*)g.tile_first.p;
-    }
+    if (!d_tile_first) d_tile_first = (int64_t*)g.tile_first.p;   // the per-tile string index lives in the workspace
     P.tile_first = d_tile_first;
     P.summ = (int4*)g.summ.p;
     P.seg_fn = (latok::Fn64*)g.seg_agg.p;

@@ -123,7 +123,9 @@ int ensure_workspace(int64_t n_tiles) {
     const size_t t = (size_t)(n_tiles > 0 ? n_tiles : 1);
     int rc;
     if ((rc = g.summ.ensure(t * 16))) return rc;
-    if ((rc = g.seg_agg.ensure((t / 16 + 2) * 32))) return rc;   // <= one 32-byte aggregate pair per 16 tiles
+    // one Fn64 + Hd64 pair per segment; plan_segments never makes a segment shorter than kWPB tiles (unless it is the
+    // only one), so n_segs <= t / kWPB + 1
+    if ((rc = g.seg_agg.ensure((t / latok::kWPB + 2) * (sizeof(latok::Fn64) + sizeof(latok::Hd64))))) return rc;
     if ((rc = g.fix_count.ensure(8))) return rc;
     if ((rc = g.tile_first.ensure(t * 8 + 8))) return rc;   // per-tile string index (stage 0)
     return LATOK_OK;
@@ -182,6 +184,8 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
     P.total = total;
     P.n_tiles = n_tiles;
     latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
+    if ((size_t)P.n_segs * (sizeof(latok::Fn64) + sizeof(latok::Hd64)) > g.seg_agg.cap || (size_t)n_tiles * 16 > g.summ.cap)
+        return fail(LATOK_ERR_INVALID, "internal: workspace too small for %lld segments / %lld tiles", (long long)P.n_segs, (long long)n_tiles);
     const uint8_t* tables = (const uint8_t*)(mode == latok::kModeRules ? g.t1rule.p : g.t1.p);
     P.t1 = tables;
     P.t2 = tables + latok::kStage1Pad;

@@ -48,7 +48,7 @@ struct SplitParams {
     const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); kModeLatin1 / kModeUcs2: the code units; cps is unused
     const int64_t* row_off;     // [n_str + 1]
     int64_t n_str, total, n_tiles;
-    int seg_tiles;              // tiles per segment (16..1024)
+    int seg_tiles;              // tiles per segment (kWPB..kSegMax, see plan_segments)
     int64_t n_segs;             // ceil(n_tiles / seg_tiles)
     const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
     const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)

@@ -40,6 +40,12 @@ def _worker(rank, world, port, q):
         total_chars = bench.reduce_sum_int(dist, int(row[-1]))
         total_bound = bench.reduce_sum_int(dist, int(np.count_nonzero(vals)))
         slowest = bench.reduce_max_seconds(dist, 0.25 * (rank + 1))
+        # per-rank times as bench.py reports them (every rank sees every rank's HIP-event time, in rank order)
+        assert bench.gather_per_rank(dist, 1.5 + rank, rank, world) == [1.5 + r for r in range(world)]
+        # strong-scaling workloads (C4 / C5): the batch's string ids are cut into contiguous ranges that tile it exactly
+        cuts = [bench.split_string_ids(1001, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and sum(n_ for _, n_ in cuts) == 1001
+        assert all(cuts[r][0] + cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
         # product sharding helper: rank r tokenizes its char-balanced slice of one common batch; the shards' boundary
         # counts add up to the whole batch's (no exchange on the data path, only this reduction for the check)
         from latok_amd import shard

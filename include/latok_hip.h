@@ -19,10 +19,13 @@
  *     that passes device pointers guarantees them (results are undefined otherwise).
  *   - `total_chars` = row_off[n_str]; the caller normally knows it.  Pass -1 to let the library read it (in device
  *     mode that costs one blocking 8-byte device->host copy).
- *   - threads and streams: host calls are serialised by an internal lock; all calls share one set of device workspaces,
- *     so work submitted on different streams is ordered on the device (a call waits for the previous call's last
- *     kernel before its own first one) -- calls never overlap, whatever stream they use.  The compaction entry
- *     points (offsets / spans / features) read one 8-byte total back and therefore block even in device mode.
+ *   - contexts, threads and streams: every entry point works on the calling thread's CURRENT CONTEXT (see "contexts"
+ *     below; default = the process-wide one latok_init creates).  A context owns one device, one stream, one set of
+ *     device workspaces and one lock: calls on the same context are serialised and ordered on the device (a call waits
+ *     for the previous call's last kernel before its own first one, whatever stream it uses); calls on DIFFERENT
+ *     contexts share nothing and run concurrently -- one host thread + one context per GPU is how a batch is sharded
+ *     over the GPUs of a node (SURVEY 8b "Threading", 8e).  The compaction entry points (offsets / spans / features)
+ *     read one 8-byte total back and therefore block even in device mode.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H
@@ -47,10 +50,25 @@ extern "C" {
 
 /* ---- lifecycle ------------------------------------------------------------------------------------------------ */
 int latok_device_count(void);          /* number of HIP devices, 0 when none (never fails) */
-int latok_init(int device);            /* bind this process to `device`, upload the Unicode tables, create the stream */
-int latok_shutdown(void);
+int latok_init(int device);            /* create the DEFAULT context on `device`: Unicode tables, stream, workspaces */
+int latok_shutdown(void);              /* destroy the default context */
 const char* latok_last_error(void);    /* message of the last failure on this thread */
 const char* latok_version(void);
+
+/* ---- contexts: one per GPU (or several per GPU) in one process -------------------------------------------------------
+ * The reference holds the GIL for a whole call and has no state (latok.c:373-378: three pure functions), so it is
+ * re-entrant but never concurrent.  Here the state a call needs (device, stream, tables, workspaces, run-time rule
+ * tables) lives in a context.  latok_ctx_create binds a new context to `device`; latok_ctx_set_current makes it the
+ * calling THREAD's current context (NULL = back to the default one) -- the model of hipSetDevice -- and every entry point
+ * of this header then runs on it: its device, its stream, its rule tables (latok_set_rules is per context).  The
+ * caller's current HIP device is never changed by a call.  A context must not be destroyed while another thread still
+ * has it current.  Device memory from latok_dev_alloc belongs to the device of the context that was current. */
+typedef struct latok_ctx latok_ctx;
+int latok_ctx_create(int device, latok_ctx** ctx_out);
+int latok_ctx_destroy(latok_ctx* ctx);
+int latok_ctx_set_current(latok_ctx* ctx);   /* NULL = the default context */
+latok_ctx* latok_ctx_get_current(void);      /* NULL when the thread runs on the default context */
+int latok_ctx_device(latok_ctx* ctx);        /* device of a context (NULL = the default one), -1 when not initialised */
 
 /* Grow the library-owned workspace (tile summaries, segment aggregates) for batches of up to
  * `max_chars` code points / `max_strings` strings, so that later calls allocate nothing. */
@@ -209,7 +227,7 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
  * recipe run on the same tables.  Each table is a row-major int8 [rows x cols] matrix of column ids, -1 padding short
  * rows; limits: <= 16 rows per table, ids 0..24, a row must not START with -1 (the reference would reuse the previous
  * row's product there).  rows = 0 gives the all-zero vector.  latok_split_values_batch refuses to run while custom
- * tables are installed (per-term values exist for the built-in tables only).  Process-wide state, like the device. */
+ * tables are installed (per-term values exist for the built-in tables only).  State of the current context. */
 int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const int8_t* c_mask, int mask_rows,
                     int mask_cols, const int8_t* c_sym, int sym_rows, int sym_cols);
 int latok_reset_rules(void);   /* back to the built-in default_tokenizer.py tables */

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -26,7 +27,6 @@ static_assert(LATOK_TILE_CHARS == latok::kTile, "tile size");
 namespace {
 
 thread_local std::string g_err;
-std::mutex g_mu;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -98,7 +98,12 @@ struct PinBuf {
 constexpr int64_t kSmallChars = 16384;
 constexpr int64_t kSmallStrings = 512;
 
+// One context = one device, one stream, one set of tables / workspaces / staging buffers, one rule-table state and one
+// lock.  Calls on the same context are serialised by its lock; calls on different contexts (other devices, or the same
+// device twice) share nothing and run concurrently.  Every entry point works on the calling thread's CURRENT context
+// (latok_ctx_set_current; default: the process-wide one that latok_init creates) -- the same model as hipSetDevice.
 struct Ctx {
+    std::mutex mu;
     bool inited = false;
     int device = -1, n_cu = 0;
     hipStream_t stream = nullptr;
@@ -117,9 +122,29 @@ struct Ctx {
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
     bool turn_stream_valid = false;
-} g;
+};
+Ctx g_default;                       // latok_init / latok_shutdown
+thread_local Ctx* tl_ctx = nullptr;  // latok_ctx_set_current; nullptr = g_default
+Ctx* current_ctx() { return tl_ctx ? tl_ctx : &g_default; }
 
-int ensure_workspace(int64_t n_tiles) {
+// HIP's current device is per host thread: whatever thread a call arrives on, allocations, events and launches of a
+// context must happen with ITS device current (a worker thread starts on device 0).  Restores the caller's device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const Ctx& c) {
+        if (c.inited && hipGetDevice(&prev) == hipSuccess && prev != c.device) switched = hipSetDevice(c.device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define LATOK_ENTER()                        \
+    Ctx& g = *current_ctx();                 \
+    std::lock_guard<std::mutex> lk(g.mu);    \
+    DeviceGuard device_guard_(g)
+
+int ensure_workspace(Ctx& g, int64_t n_tiles) {
     const size_t t = (size_t)(n_tiles > 0 ? n_tiles : 1);
     int rc;
     if ((rc = g.summ.ensure(t * 16))) return rc;
@@ -131,17 +156,18 @@ int ensure_workspace(int64_t n_tiles) {
     return LATOK_OK;
 }
 
-int need_init() {
+int need_init(const Ctx& g) {
     if (!g.inited) return fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called (no CPU fallback exists)");
     return LATOK_OK;
 }
 
-// The workspaces (tile summaries, bitmasks, ranks, staging) are shared by all calls.  Host calls are serialised by g_mu,
+// The workspaces (tile summaries, bitmasks, ranks, staging) are shared by all calls of a context.  Host calls are serialised by its lock,
 // but with caller streams the kernels of two calls could still overlap on the device: a call that runs on another
 // stream than the previous one first waits (on the device) for that call's last kernel.
 struct StreamTurn {
+    Ctx& g;
     hipStream_t st;
-    explicit StreamTurn(void* stream) : st(stream ? (hipStream_t)stream : g.stream) {
+    StreamTurn(Ctx& ctx, void* stream) : g(ctx), st(stream ? (hipStream_t)stream : ctx.stream) {
         if (g.inited && g.turn_event && g.turn_stream_valid && g.turn_stream != st)
             (void)hipStreamWaitEvent(st, g.turn_event, 0);
     }
@@ -155,7 +181,7 @@ struct StreamTurn {
 };
 
 // enqueue the pipeline on device-resident data
-int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
+int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
@@ -174,7 +200,7 @@ int run_pipeline(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int
         if (mode == latok::kModeBits) mode = latok::kModeRules;
     }
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
-    int rc = ensure_workspace(n_tiles);
+    int rc = ensure_workspace(g, n_tiles);
     if (rc) return rc;
     latok::SplitParams P;
     P.cps = d_cps;
@@ -234,18 +260,18 @@ int resolve_total_device(const int64_t* d_row, int64_t n_str, int64_t* total_io,
     return LATOK_OK;
 }
 
-int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, void* out, int mode,
+int split_common(Ctx& g, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, void* out, int mode,
                  int flags, void* stream) {
-    int rc = need_init();
+    int rc = need_init(g);
     if (rc) return rc;
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
         if (total == 0) return LATOK_OK;
         if (!cps || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
         if (((uintptr_t)cps & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
-        return run_pipeline(cps, row_off, n_str, total, mode == latok::kModeBits ? (uint64_t*)out : nullptr,
+        return run_pipeline(g, cps, row_off, n_str, total, mode == latok::kModeBits ? (uint64_t*)out : nullptr,
                             mode == latok::kModeValues ? (uint8_t*)out : nullptr, mode, st);
     }
     if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
@@ -259,7 +285,7 @@ int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int
         memcpy(g.pin.h, cps, (size_t)total * 4);
         memcpy((char*)g.pin.h + o_row, row_off, (size_t)(n_str + 1) * 8);
         char* d = (char*)g.pin.d;
-        rc = run_pipeline((const uint32_t*)d, (const int64_t*)(d + o_row), n_str, total,
+        rc = run_pipeline(g, (const uint32_t*)d, (const int64_t*)(d + o_row), n_str, total,
                           mode == latok::kModeBits ? (uint64_t*)(d + o_out) : nullptr,
                           mode == latok::kModeValues ? (uint8_t*)(d + o_out) : nullptr, mode, st);
         if (rc) return rc;
@@ -272,7 +298,7 @@ int split_common(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int
     if ((rc = g.h_out.ensure(out_bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(g.h_row.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.h_row.p, n_str, total,
+    rc = run_pipeline(g, (const uint32_t*)g.h_cps.p, (const int64_t*)g.h_row.p, n_str, total,
                       mode == latok::kModeBits ? (uint64_t*)g.h_out.p : nullptr,
                       mode == latok::kModeValues ? (uint8_t*)g.h_out.p : nullptr, mode, st);
     if (rc) return rc;
@@ -294,15 +320,30 @@ int latok_device_count(void) {
 const char* latok_last_error(void) { return g_err.c_str(); }
 const char* latok_version(void) { return "latok_hip 0.1 (gfx950)"; }
 
-int latok_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g.inited) {
-        if (g.device == device) return LATOK_OK;
-        return fail(LATOK_ERR_INVALID, "already initialised on device %d (one process per GPU)", g.device);
+// ---- context lifecycle ---------------------------------------------------------------------------------------------
+static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+    g.pin.release();
+    g.pin_tot.release();
+    g.rules_on = false;
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
+                      &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
+                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux})
+        b->release();
+    for (auto& e : g.ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
     }
-    int n = latok_device_count();
-    if (n <= 0) return fail(LATOK_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= n) return fail(LATOK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    if (g.turn_event) (void)hipEventDestroy(g.turn_event);
+    g.turn_event = nullptr;
+    g.turn_stream_valid = false;
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    g.stream = nullptr;
+    g.inited = false;
+    g.device = -1;
+}
+
+static int ctx_init_body(Ctx& g, int device) {
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -336,36 +377,93 @@ int latok_init(int device) {
     return LATOK_OK;
 }
 
-int latok_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.inited) return LATOK_OK;
-    (void)hipStreamSynchronize(g.stream);
-    g.pin.release();
-    g.pin_tot.release();
-    g.rules_on = false;
-    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out, &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes, &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar,
-                      &g.h_aux})
-        b->release();
-    for (auto& e : g.ev) {
-        if (e) (void)hipEventDestroy(e);
-        e = nullptr;
+// bind a context to `device`: stream, events, Unicode tables.  The caller's current HIP device is left as it was.
+static int ctx_init(Ctx& g, int device) {   // caller holds g.mu
+    int n = latok_device_count();
+    if (n <= 0) return fail(LATOK_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(LATOK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    const int rc = ctx_init_body(g, device);
+    if (rc) {   // a partly built context leaks nothing
+        const std::string msg = g_err;
+        ctx_release(g);
+        g_err = msg;
     }
-    if (g.turn_event) (void)hipEventDestroy(g.turn_event);
-    g.turn_event = nullptr;
-    g.turn_stream_valid = false;
-    (void)hipStreamDestroy(g.stream);
-    g.stream = nullptr;
-    g.inited = false;
-    g.device = -1;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+int latok_init(int device) {
+    Ctx& g = g_default;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.inited) {
+        if (g.device == device) return LATOK_OK;
+        return fail(LATOK_ERR_INVALID, "the default context is already on device %d; use latok_ctx_create for other devices", g.device);
+    }
+    return ctx_init(g, device);
+}
+
+int latok_shutdown(void) {
+    Ctx& g = g_default;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g.inited) return LATOK_OK;
+    DeviceGuard dg(g);
+    ctx_release(g);
     return LATOK_OK;
 }
 
+int latok_ctx_create(int device, latok_ctx** ctx_out) {
+    if (!ctx_out) return fail(LATOK_ERR_INVALID, "ctx_out is NULL");
+    *ctx_out = nullptr;
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return fail(LATOK_ERR_NOMEM, "out of host memory");
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        rc = ctx_init(*c, device);
+    }
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    *ctx_out = reinterpret_cast<latok_ctx*>(c);
+    return LATOK_OK;
+}
+
+int latok_ctx_destroy(latok_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return LATOK_OK;
+    if (c == &g_default) return fail(LATOK_ERR_INVALID, "the default context is destroyed by latok_shutdown()");
+    if (tl_ctx == c) tl_ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);   // waits for a call that is still running on it
+        DeviceGuard dg(*c);
+        ctx_release(*c);
+    }
+    delete c;
+    return LATOK_OK;
+}
+
+int latok_ctx_set_current(latok_ctx* ctx) {
+    tl_ctx = reinterpret_cast<Ctx*>(ctx);   // NULL = the default context
+    if (tl_ctx == &g_default) tl_ctx = nullptr;
+    return LATOK_OK;
+}
+
+latok_ctx* latok_ctx_get_current(void) { return reinterpret_cast<latok_ctx*>(tl_ctx); }
+
+int latok_ctx_device(latok_ctx* ctx) {
+    const Ctx* c = ctx ? reinterpret_cast<const Ctx*>(ctx) : &g_default;
+    return c->inited ? c->device : -1;
+}
+
 int latok_reserve(int64_t max_chars, int64_t max_strings) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (max_chars < 0 || max_strings < 0) return fail(LATOK_ERR_INVALID, "negative size");
-    return ensure_workspace((max_chars + latok::kTile - 1) / latok::kTile);
+    return ensure_workspace(g, (max_chars + latok::kTile - 1) / latok::kTile);
 }
 
 // one rule table: row-major int8 [rows x cols] as build_combo_matrix returns it -> per-row column sets
@@ -394,8 +492,8 @@ static int pack_rule_table(const char* name, const int8_t* idx, int rows, int co
 
 int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const int8_t* c_mask, int mask_rows,
                     int mask_cols, const int8_t* c_sym, int sym_rows, int sym_cols) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     lk_rule_tables R;
     memset(&R, 0, sizeof(R));
@@ -411,23 +509,26 @@ int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const
 }
 
 int latok_reset_rules(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     g.rules_on = false;
     return LATOK_OK;
 }
 
-int latok_rules_active(void) { return g.rules_on ? 1 : 0; }
+int latok_rules_active(void) {
+    LATOK_ENTER();
+    return g.rules_on ? 1 : 0;
+}
 
 int latok_split_mask_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_bits_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return split_common(cps, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
+    LATOK_ENTER();
+    return split_common(g, cps, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
 }
 
 int latok_split_values_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                              uint8_t* values_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return split_common(cps, row_off, n_str, total_chars, values_out, latok::kModeValues, flags, stream);
+    LATOK_ENTER();
+    return split_common(g, cps, row_off, n_str, total_chars, values_out, latok::kModeValues, flags, stream);
 }
 
 // UTF-8 ingest: decode a CSR batch of UTF-8 strings into the library's device buffers (g.h_cps = packed code points,
@@ -439,7 +540,7 @@ struct BytesRoute {
     const uint8_t* d_u8 = nullptr;
     const int64_t* d_boff = nullptr;
 };
-static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
+static int decode_utf8_to_workspace(Ctx& g, const uint8_t* u8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                     bool dev, hipStream_t st, int64_t* total_cps_out, BytesRoute* bytes_route = nullptr) {
     int rc;
     *total_cps_out = 0;
@@ -488,7 +589,7 @@ static int decode_utf8_to_workspace(const uint8_t* u8, const int64_t* byte_off, 
 }
 
 // featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
-static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
+static int enqueue_features(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
                             const uint64_t* d_space, const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt,
                             const uint16_t* d_pref, const int64_t* d_tile_first, int64_t* d_spans4, int8_t* d_feat,
                             hipStream_t st) {
@@ -513,16 +614,16 @@ static int enqueue_features(const uint32_t* d_cps, const int64_t* d_row, int64_t
 }
 
 // shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
-static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
+static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
                           bool byte_space = false, int unit_kind = 0) {
     const bool feats = features_out != nullptr;
-    int rc = need_init();
+    int rc = need_init(g);
     if (rc) return rc;
     if (!n_items_out) return fail(LATOK_ERR_INVALID, "the total-count output pointer is NULL");
     *n_items_out = 0;
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
@@ -556,7 +657,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         }
     } else if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
         BytesRoute br;
-        if ((rc = decode_utf8_to_workspace(utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
+        if ((rc = decode_utf8_to_workspace(g, utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
         if (br.d_u8) {   // no multi-byte char in the batch: byte space == code-point space, skip the decode
             d_u8 = br.d_u8;
             d_row = br.d_boff;
@@ -616,7 +717,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
     int64_t* d_rank = (int64_t*)g.bases.p;
     if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
     int64_t* d_tile_first = (int64_t*)g.tile_first.p;
-    if ((rc = run_pipeline(d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+    if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
                            nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind)))
         return rc;
     const int64_t* d_tcnt = (const int64_t*)g.wcnt.p;
@@ -633,7 +734,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
         int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
         if (feats) {   // spans and sums come from one kernel
-            if ((rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
+            if ((rc = enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
                                        d_items, d_feat, st)))
                 return rc;
         } else {
@@ -669,7 +770,7 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
         }
     }
     if (feats) {   // spans and sums come from one kernel
-        if ((rc = enqueue_features(d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
+        if ((rc = enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
                                    d_feat, st)))
             return rc;
     } else {
@@ -687,30 +788,30 @@ static int compact_common(bool spans, const uint32_t* cps, const int64_t* row_of
 int latok_split_offsets_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                               int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
                               int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return compact_common(false, cps, row_off, n_str, total, counts_out, offsets_out, offsets_cap, n_offsets_out, flags,
+    LATOK_ENTER();
+    return compact_common(g, false, cps, row_off, n_str, total, counts_out, offsets_out, offsets_cap, n_offsets_out, flags,
                           stream);
 }
 
 int latok_token_spans_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                             int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out, int flags,
                             void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return compact_common(true, cps, row_off, n_str, total, counts_out, spans_out, spans_cap, n_tokens_out, flags, stream);
+    LATOK_ENTER();
+    return compact_common(g, true, cps, row_off, n_str, total, counts_out, spans_out, spans_cap, n_tokens_out, flags, stream);
 }
 
 int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                             uint32_t* cps_out, int64_t cps_cap, int64_t* cp_row_off_out, int64_t* total_cps_out, int flags,
                             void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total_cps = 0;
-    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total_cps))) return rc;
+    if ((rc = decode_utf8_to_workspace(g, utf8, byte_off, n_str, total_bytes, dev, st, &total_cps))) return rc;
     *total_cps_out = total_cps;
     if (n_str == 0) return LATOK_OK;
     if (total_cps > cps_cap) return fail(LATOK_ERR_INVALID, "cps_cap too small: need %lld", (long long)total_cps);
@@ -725,16 +826,16 @@ int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_
 int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                 uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out,
                                 int64_t* total_cps_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (!total_cps_out) return fail(LATOK_ERR_INVALID, "total_cps_out is NULL");
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total = 0;
     BytesRoute br;
-    if ((rc = decode_utf8_to_workspace(utf8, byte_off, n_str, total_bytes, dev, st, &total, &br))) return rc;
+    if ((rc = decode_utf8_to_workspace(g, utf8, byte_off, n_str, total_bytes, dev, st, &total, &br))) return rc;
     *total_cps_out = total;
     if (n_str == 0) return LATOK_OK;
     const int64_t words = (total + 63) / 64;
@@ -746,10 +847,10 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
         d_bits = (uint64_t*)g.h_out.p;
     }
     if (br.d_u8) {   // no multi-byte char: the byte-space kernel on the bytes, code-point offsets = byte offsets
-        if ((rc = run_pipeline(nullptr, br.d_boff, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr,
+        if ((rc = run_pipeline(g, nullptr, br.d_boff, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr,
                                nullptr, nullptr, nullptr, nullptr, nullptr, br.d_u8)))
             return rc;
-    } else if ((rc = run_pipeline((const uint32_t*)g.h_cps.p, (const int64_t*)g.u_row.p, n_str, total, d_bits, nullptr,
+    } else if ((rc = run_pipeline(g, (const uint32_t*)g.h_cps.p, (const int64_t*)g.u_row.p, n_str, total, d_bits, nullptr,
                                   latok::kModeBits, st))) {
         return rc;
     }
@@ -764,34 +865,34 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
 int latok_split_offsets_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                    int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
                                    int64_t* n_offsets_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     static const uint8_t empty = 0;
-    return compact_common(false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
+    return compact_common(g, false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
                           n_offsets_out, flags, stream, nullptr, utf8 ? utf8 : &empty);
 }
 
 int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                  int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                                  int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     static const uint8_t empty = 0;
-    return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
+    return compact_common(g, true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
                           flags, stream, nullptr, utf8 ? utf8 : &empty);
 }
 
 /* byte-space UTF-8 entry points: the tile kernel reads the bytes (1 B/char for ASCII), all positions are byte offsets */
 int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                       uint64_t* mask_bits_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         if ((rc = resolve_total_device(byte_off, n_str, &total_bytes, st))) return rc;
         if (total_bytes == 0) return LATOK_OK;
         if (!utf8 || !mask_bits_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
-        return run_pipeline(nullptr, byte_off, n_str, total_bytes, mask_bits_out, nullptr, latok::kModeBits, st, nullptr, nullptr,
+        return run_pipeline(g, nullptr, byte_off, n_str, total_bytes, mask_bits_out, nullptr, latok::kModeBits, st, nullptr, nullptr,
                             nullptr, nullptr, nullptr, nullptr, nullptr, utf8);
     }
     if ((rc = check_csr_host(byte_off, n_str, &total_bytes))) return rc;
@@ -803,7 +904,7 @@ int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_o
     if ((rc = g.h_out.ensure(out_bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
-    if ((rc = run_pipeline(nullptr, (const int64_t*)g.u_boff.p, n_str, total_bytes, (uint64_t*)g.h_out.p, nullptr,
+    if ((rc = run_pipeline(g, nullptr, (const int64_t*)g.u_boff.p, n_str, total_bytes, (uint64_t*)g.h_out.p, nullptr,
                            latok::kModeBits, st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                            (const uint8_t*)g.u_bytes.p)))
         return rc;
@@ -815,18 +916,18 @@ int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_o
 int latok_split_offsets_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                          int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap,
                                          int64_t* n_offsets_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     static const uint8_t empty = 0;
-    return compact_common(false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
+    return compact_common(g, false, nullptr, byte_off, n_str, total_bytes, counts_out, offsets_out, offsets_cap,
                           n_offsets_out, flags, stream, nullptr, utf8 ? utf8 : &empty, true);
 }
 
 int latok_token_spans_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                        int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                                        int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     static const uint8_t empty = 0;
-    return compact_common(true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
+    return compact_common(g, true, nullptr, byte_off, n_str, total_bytes, counts_out, spans_out, spans_cap, n_tokens_out,
                           flags, stream, nullptr, utf8 ? utf8 : &empty, true);
 }
 
@@ -838,12 +939,12 @@ static int check_kind(int kind) {
 
 int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                                 uint64_t* mask_bits_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     int rc = check_kind(kind);
     if (rc) return rc;
-    if (kind == 4) return split_common((const uint32_t*)units, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
-    if ((rc = need_init())) return rc;
-    StreamTurn turn(stream);
+    if (kind == 4) return split_common(g, (const uint32_t*)units, row_off, n_str, total_chars, mask_bits_out, latok::kModeBits, flags, stream);
+    if ((rc = need_init(g))) return rc;
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     int64_t total = total_chars;
@@ -872,9 +973,9 @@ int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_
         if (((uintptr_t)d_units & (size_t)(kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
         if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
         HIP_TRY(latok::launch_widen_units(d_units, kind, total, (uint32_t*)g.h_cps.p, st));
-        rc = run_pipeline((const uint32_t*)g.h_cps.p, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st);
+        rc = run_pipeline(g, (const uint32_t*)g.h_cps.p, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st);
     } else {
-        rc = run_pipeline(nullptr, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+        rc = run_pipeline(g, nullptr, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
                           nullptr, nullptr, nullptr, nullptr, d_units, kind);
     }
     if (rc) return rc;
@@ -888,66 +989,66 @@ int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_
 int latok_split_offsets_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                                    int64_t* counts_out, int64_t* offsets_out, int64_t offsets_cap, int64_t* n_offsets_out,
                                    int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     int rc = check_kind(kind);
     if (rc) return rc;
     if (kind == 4)
-        return compact_common(false, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap,
+        return compact_common(g, false, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap,
                               n_offsets_out, flags, stream);
     static const uint8_t empty = 0;
-    return compact_common(false, nullptr, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap, n_offsets_out,
+    return compact_common(g, false, nullptr, row_off, n_str, total_chars, counts_out, offsets_out, offsets_cap, n_offsets_out,
                           flags, stream, nullptr, units ? (const uint8_t*)units : &empty, true, kind);
 }
 
 int latok_token_spans_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                                  int64_t* counts_out, int64_t* spans_out, int64_t spans_cap, int64_t* n_tokens_out,
                                  int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     int rc = check_kind(kind);
     if (rc) return rc;
     if (kind == 4)
-        return compact_common(true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans_out, spans_cap,
+        return compact_common(g, true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans_out, spans_cap,
                               n_tokens_out, flags, stream);
     static const uint8_t empty = 0;
-    return compact_common(true, nullptr, row_off, n_str, total_chars, counts_out, spans_out, spans_cap, n_tokens_out, flags,
+    return compact_common(g, true, nullptr, row_off, n_str, total_chars, counts_out, spans_out, spans_cap, n_tokens_out, flags,
                           stream, nullptr, units ? (const uint8_t*)units : &empty, true, kind);
 }
 
 int latok_token_features_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                                     int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
                                     int64_t* n_tokens_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     int rc = check_kind(kind);
     if (rc) return rc;
     if (!features_out && cap > 0) return fail(LATOK_ERR_INVALID, "features_out is NULL");
     static int8_t dummy = 0;
     int8_t* f = features_out ? features_out : &dummy;
     if (kind == 4)
-        return compact_common(true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out,
+        return compact_common(g, true, (const uint32_t*)units, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out,
                               flags, stream, f);
     static const uint8_t empty = 0;
-    return compact_common(true, nullptr, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
+    return compact_common(g, true, nullptr, row_off, n_str, total_chars, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
                           f, units ? (const uint8_t*)units : &empty, true, kind);
 }
 
 int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                                int64_t* counts_out, int64_t* spans4_out, int8_t* features_out, int64_t cap,
                                int64_t* n_tokens_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    LATOK_ENTER();
     if (!features_out && cap > 0) return fail(LATOK_ERR_INVALID, "features_out is NULL");
     int8_t dummy = 0;
-    return compact_common(true, cps, row_off, n_str, total, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
+    return compact_common(g, true, cps, row_off, n_str, total, counts_out, spans4_out, cap, n_tokens_out, flags, stream,
                           features_out ? features_out : &dummy);
 }
 
 int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
     if (n == 0) return LATOK_OK;
     if (!cps || !matrix_out) return fail(LATOK_ERR_INVALID, "NULL buffer");
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const uint8_t* t1 = (const uint8_t*)g.t1.p;
     const uint8_t* t2 = (const uint8_t*)g.t2cls.p;
@@ -968,15 +1069,15 @@ int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int f
 int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64_t stride_r, int64_t stride_c,
                               const int8_t* idx, int idx_ndim, int irows, int icols, int8_t* out, int flags,
                               void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (idx_ndim != 1 && idx_ndim != 2) return fail(LATOK_ERR_INVALID, "must specify 2d numpy array args");
     if (rows < 0 || cols < 0 || irows < 0 || icols < 0) return fail(LATOK_ERR_INVALID, "negative shape");
     if (cols == 0) return LATOK_OK;
     if (!m || !idx || !out) return fail(LATOK_ERR_INVALID, "NULL buffer");
     const int n_idx = idx_ndim == 2 ? irows * icols : icols;
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     if (flags & LATOK_DEVICE_PTRS) {
         HIP_TRY(latok::launch_combine_rows((const uint8_t*)m, stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out, st));
@@ -1004,13 +1105,13 @@ int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64
 }
 
 int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out, int flags, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (n < 0) return fail(LATOK_ERR_INVALID, "n must be >= 0");
     if (n == 0) return LATOK_OK;
     if (!a1 || !a2 || !out) return fail(LATOK_ERR_INVALID, "must specify two aligning 1d numpy array args");
-    StreamTurn turn(stream);
+    StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     // the block mask of ONE array pair is the batch pipeline over a single "string" [0, n) whose planes are a1 / a2
@@ -1034,7 +1135,7 @@ int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out,
     }
     int* d_flags = (int*)((char*)g.scalar.p + 16);
     HIP_TRY(latok::launch_any_nonzero(d1, d2, n, d_flags, st));
-    if ((rc = run_pipeline(nullptr, (const int64_t*)g.h_row.p, 1, n, nullptr, (uint8_t*)dout, latok::kModeBlockMask, st,
+    if ((rc = run_pipeline(g, nullptr, (const int64_t*)g.h_row.p, 1, n, nullptr, (uint8_t*)dout, latok::kModeBlockMask, st,
                            nullptr, nullptr, d1, d2, d_flags)))
         return rc;
     if (!dev) {
@@ -1045,6 +1146,7 @@ int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out,
 }
 
 void* latok_dev_alloc(size_t bytes) {
+    LATOK_ENTER();
     void* p = nullptr;
     if (!g.inited) { fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called"); return nullptr; }
     hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
@@ -1052,37 +1154,43 @@ void* latok_dev_alloc(size_t bytes) {
     return p;
 }
 int latok_dev_free(void* p) {
+    LATOK_ENTER();
     if (p) HIP_TRY(hipFree(p));
     return LATOK_OK;
 }
 int latok_memcpy_h2d(void* d, const void* s, size_t n) {
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return LATOK_OK;
 }
 int latok_memcpy_d2h(void* d, const void* s, size_t n) {
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     return LATOK_OK;
 }
 int latok_memset_dev(void* d, int v, size_t n) {
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(d, v, n, g.stream));
     return LATOK_OK;
 }
 int latok_sync(void) {
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(g.stream));
     return LATOK_OK;
 }
 int latok_device_props(int* n_cu, int64_t* hbm_bytes, char* name_out, int name_cap) {
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, g.device));
@@ -1112,8 +1220,8 @@ int latok_corpus_fill_host(uint64_t seed, int model, uint64_t sid0, int64_t n_st
 }
 int latok_corpus_fill_device(uint64_t seed, int model, uint64_t sid0, int64_t n_str, const int64_t* row_off_dev,
                              uint32_t* cps_out_dev, void* stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(latok::launch_corpus_fill(seed, model, sid0, n_str, row_off_dev, cps_out_dev,
                                       stream ? (hipStream_t)stream : g.stream));
@@ -1127,8 +1235,8 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
         *bytes_out = t;
         return LATOK_OK;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(latok::launch_utf8_bytes(cps, n, (unsigned long long*)g.scalar.p, g.stream));
     unsigned long long t = 0;
@@ -1139,13 +1247,13 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
 }
 
 int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (!buf_dev || !ms_out || bytes < 16384 || iters <= 0 || warmup < 0)
         return fail(LATOK_ERR_INVALID, "stream_read: need a device buffer of >= 16 KiB, iters > 0");
     if (((uintptr_t)buf_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device pointer must be 16-byte aligned");
-    StreamTurn turn(nullptr);
+    StreamTurn turn(g, nullptr);
     hipStream_t st = turn.st;
     uint32_t* sink = (uint32_t*)g.scalar.p + 8;
     for (int i = 0; i < warmup; ++i) HIP_TRY(latok::launch_stream_read(buf_dev, bytes, sink, g.n_cu, st));
@@ -1160,21 +1268,21 @@ int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int 
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total,
                            uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
                            int64_t* n_fix_tiles_out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = need_init();
+    LATOK_ENTER();
+    int rc = need_init(g);
     if (rc) return rc;
     if (iters < 0 || warmup < 0) return fail(LATOK_ERR_INVALID, "iters and warmup must be >= 0");
     if (((uintptr_t)cps_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
-    StreamTurn turn(nullptr);
+    StreamTurn turn(g, nullptr);
     hipStream_t st = turn.st;
     if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
     for (int i = 0; i < warmup; ++i)
-        if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+        if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
     // (1) whole pipeline, `iters` passes between one pair of events on the launch stream
     if (ms_total_out) {
         HIP_TRY(hipEventRecord(g.ev[0], st));
         for (int i = 0; i < iters; ++i)
-            if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+            if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
         HIP_TRY(hipEventRecord(g.ev[1], st));
         HIP_TRY(hipEventSynchronize(g.ev[1]));
         float ms = 0.f;
@@ -1189,7 +1297,7 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
     if (ms_tiles_out) {
         HIP_TRY(hipEventRecord(g.ev[2], st));
         for (int i = 0; i < iters; ++i)
-            if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st, nullptr, nullptr,
+            if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st, nullptr, nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2)))
                 return rc;
         HIP_TRY(hipEventRecord(g.ev[3], st));
@@ -1198,7 +1306,7 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
         HIP_TRY(hipEventElapsedTime(&ms, g.ev[2], g.ev[3]));
         *ms_tiles_out = ms;
         // leave a resolved mask behind
-        if ((rc = run_pipeline(cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+        if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(st));
     if (n_fix_tiles_out) {

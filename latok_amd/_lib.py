@@ -29,6 +29,11 @@ SIGNATURES = {
     "latok_shutdown": (ci, []),
     "latok_last_error": (C.c_char_p, []),
     "latok_version": (C.c_char_p, []),
+    "latok_ctx_create": (ci, [ci, C.POINTER(vp)]),
+    "latok_ctx_destroy": (ci, [vp]),
+    "latok_ctx_set_current": (ci, [vp]),
+    "latok_ctx_get_current": (vp, []),
+    "latok_ctx_device": (ci, [vp]),
     "latok_reserve": (ci, [i64, i64]),
     "latok_split_mask_batch": (ci, [vp, vp, i64, i64, vp, ci, vp]),
     "latok_split_values_batch": (ci, [vp, vp, i64, i64, vp, ci, vp]),
@@ -112,13 +117,51 @@ def default_device() -> int:
 
 
 def ensure_init(device=None):
-    """Initialise the library on first use (one process per GPU)."""
+    """Initialise the default context on first use.  A thread that runs inside ``with Context(...)`` needs no default
+    context: its calls go to the current one."""
     global _inited
     lib = load()
-    if not _inited:
+    if not _inited and not lib.latok_ctx_get_current():
         check(lib.latok_init(default_device() if device is None else int(device)))
         _inited = True
     return lib
+
+
+class Context:
+    """One library context (include/latok_hip.h "contexts"): a device, a stream, a workspace set and a lock of its own.
+    ``with ctx:`` makes it the calling THREAD's current context, so every ``latok_amd.batch`` call inside runs on it;
+    contexts on different devices (or two on one device) run concurrently from different threads -- ctypes releases the
+    GIL for the duration of a call."""
+
+    def __init__(self, device: int):
+        lib = load()
+        h = vp()
+        check(lib.latok_ctx_create(int(device), C.byref(h)))
+        self._lib, self.handle, self.device = lib, h, int(device)
+        self._prev = []
+
+    def make_current(self):
+        check(self._lib.latok_ctx_set_current(self.handle))
+
+    def __enter__(self):
+        self._prev.append(self._lib.latok_ctx_get_current())
+        self.make_current()
+        return self
+
+    def __exit__(self, *exc):
+        check(self._lib.latok_ctx_set_current(self._prev.pop()))
+        return False
+
+    def destroy(self):
+        if self.handle:
+            check(self._lib.latok_ctx_destroy(self.handle))
+            self.handle = vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def shutdown():

@@ -78,10 +78,14 @@ def _narrow_pays(texts):
     return len(texts) > _SMALL_STRINGS or sum(map(len, texts)) > _SMALL_CHARS
 
 
-def split_offsets_batch(texts):
-    """list[str] -> list of int64 arrays = np.nonzero(split mask)[0] of every string ('' -> empty array)."""
+def split_offsets_batch(texts, devices=None):
+    """list[str] -> list of int64 arrays = np.nonzero(split mask)[0] of every string ('' -> empty array).
+    devices: a multi.DevicePool or a list of device ids -> the strings are sharded over them (latok_amd.multi)."""
     if len(texts) == 0:
         return []
+    if devices is not None:
+        from . import multi
+        return multi.split_offsets_batch(texts, devices)
     if _narrow_pays(texts):
         counts, offsets = split_offsets_kind_csr(*pack_kind(texts))
     else:
@@ -121,11 +125,15 @@ def token_features_csr(cps, row_off):
     return counts, spans[:n_tok.value].copy(), feats[:n_tok.value].copy()
 
 
-def featurize_batch(texts):
-    """list[str] -> list[list[LaToken]], each as list(featurize(text)) of the reference."""
+def featurize_batch(texts, devices=None):
+    """list[str] -> list[list[LaToken]], each as list(featurize(text)) of the reference.
+    devices: a multi.DevicePool or a list of device ids -> the strings are sharded over them."""
     from .core.latok_utils import LaToken
     if len(texts) == 0:
         return []
+    if devices is not None:
+        from . import multi
+        return multi.featurize_batch(texts, devices)
     if _narrow_pays(texts):
         counts, spans, feats = token_features_kind_csr(*pack_kind(texts))
     else:
@@ -364,11 +372,16 @@ def spans_from_offsets(text, nz):
     return toks
 
 
-def tokenize_batch(texts):
+def tokenize_batch(texts, devices=None):
     """list[str] -> list[list[str]], each as list(tokenize(text)) of the reference (default_tokenizer.py:137-160);
-    an empty string yields [] instead of the reference's IndexError."""
+    an empty string yields [] instead of the reference's IndexError.
+    devices: a multi.DevicePool or a list of device ids -> the strings are sharded over them, one host thread and one
+    library context per entry (latok_amd.multi); the result is the same list."""
     if len(texts) == 0:
         return []
+    if devices is not None:
+        from . import multi
+        return multi.tokenize_batch(texts, devices)
     if _narrow_pays(texts):
         counts, spans = token_spans_kind_csr(*pack_kind(texts))
     else:
@@ -387,6 +400,8 @@ def _rule_table(name, idx):
     a = np.asarray(idx)
     if a.size and not np.issubdtype(a.dtype, np.integer):
         raise ValueError(f"{name}: feature ids must be integers")
+    if a.size and not ((a == -1) | ((a >= 0) & (a < _lib.FEATURE_COUNT))).all():
+        raise ValueError(f"{name}: feature ids must be -1 (padding) or 0..{_lib.FEATURE_COUNT - 1}")
     a = a.astype(np.int8)
     if a.ndim == 1:
         a = a[a != -1].reshape(-1, 1)

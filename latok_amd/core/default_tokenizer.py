@@ -3,6 +3,11 @@
 ``tokenize`` / ``featurize`` get their boundary offsets from the fused HIP kernel (one string = a batch of one);
 ``gen_split_mask`` stays the generic, user-editable recipe over the three native functions exactly as in the reference
 (default_tokenizer.py:113-134), so customised combo matrices keep working through the compat kernels.
+
+Extension point: the reference's ``tokenize`` / ``featurize`` evaluate the module-level ``C_SPLIT`` / ``C_MASK`` /
+``C_SYM`` (default_tokenizer.py:108-110,123-129), so a user customises them by rebinding those names.  The same works
+here: before every call the three names are compared with the built-in tables and, when they differ, installed in the
+fused kernel as run-time rule tables (``batch.set_rules``) -- and removed again when they are restored.
 """
 import numpy as np
 
@@ -59,12 +64,33 @@ def gen_split_mask(m: np.ndarray):
     return splits
 
 
+_BUILTIN = (C_SPLIT.copy(), C_MASK.copy(), C_SYM.copy())
+_installed = {}   # context handle -> the tables THIS module installed there (an explicit batch.set_rules is left alone)
+
+
+def _sync_rules():
+    """Make the fused kernel evaluate whatever C_SPLIT / C_MASK / C_SYM are bound to right now."""
+    from .. import _lib
+    key = _lib.load().latok_ctx_get_current()
+    cur = (np.asarray(C_SPLIT), np.asarray(C_MASK), np.asarray(C_SYM))
+    custom = not all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cur, _BUILTIN))
+    have = _installed.get(key)
+    if custom:
+        if have is None or not all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cur, have)):
+            _batch.set_rules(*cur)
+            _installed[key] = tuple(np.array(x, copy=True) for x in cur)
+    elif have is not None:
+        _batch.reset_rules()
+        del _installed[key]
+
+
 def _boundaries(text: str) -> np.ndarray:
     """np.nonzero(gen_split_mask(_gen_parse_matrix(text)))[0] (reference default_tokenizer.py:146-148), computed by
     the fused kernel."""
     if len(text) == 0:
         # the reference fails at ``splits[0] = 1`` on an empty array (default_tokenizer.py:132)
         raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    _sync_rules()
     return _batch.split_offsets_batch([text])[0]
 
 
@@ -97,4 +123,5 @@ def featurize(text: str):
     rows with ``np.arange(..., dtype=np.int8)`` and therefore breaks past character 127 -- any position works here."""
     if len(text) == 0:
         raise IndexError("index 0 is out of bounds for axis 0 with size 0")
+    _sync_rules()
     yield from _batch.featurize_batch([text])[0]

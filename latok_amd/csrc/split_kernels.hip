@@ -657,7 +657,11 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
     // the next 64 strings and the three halo characters
+#ifdef LATOK_AB_NO_RO
+    int64_t ro = INT64_MAX;
+#else
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
+#endif
     uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
     if (MODE != kModeBlockMask && !mode_is_bytes(MODE) && lane < 3) {
         const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
@@ -703,6 +707,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     if (lane == 0) L.bw[64] = 0;
     LATOK_STAMP(2);
     wave_lds_sync();
+#ifndef LATOK_AB_NO_BW
     for (;;) {
         const int64_t rel = ro - t0;
         if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
@@ -712,6 +717,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     }
     wave_lds_sync();
+#endif
     LATOK_STAMP(3);
 
     return tile_phase2<MODE, DEFER>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane
@@ -1679,6 +1685,13 @@ static inline int grid_for(const SplitParams& P, int n_cu) {
 
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
+#ifdef LATOK_AB_COOP
+    if (mode == kModeBits) {   // experiment: what a cooperative launch of the same kernel costs
+        SplitParams Pc = P;
+        void* args[] = {&Pc};
+        return hipLaunchCooperativeKernel((const void*)(k_tiles_main<kModeBits>), grid, block, args, 0, st);
+    }
+#endif
     if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);

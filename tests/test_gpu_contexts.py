@@ -1,0 +1,168 @@
+"""Per-device contexts of the C ABI (include/latok_hip.h "contexts") and the in-process sharding driver
+(latok_amd.multi) on the GPU: contexts share nothing, so calls on two of them overlap -- also two on ONE device, which is
+what a 1-GPU box can show -- and every result is still the oracle's."""
+import ctypes as C
+import random
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ALPHABETS, pack, random_strings
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_offsets(oracle, cps, row):
+    vals, bits = oracle.split_batch(cps, row)
+    per = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(row) - 1)]
+    return np.array([len(p) for p in per], np.int64), np.concatenate(per), bits
+
+
+def test_two_contexts_on_one_device_run_concurrently_and_exactly(gpu, oracle):
+    from latok_amd import _lib, batch
+    rng = random.Random(99)
+    # different batches per thread, sized so that the workspaces of the two contexts would collide if they were shared
+    work = []
+    for k in range(2):
+        texts = random_strings(rng, 3000, 0, 200, ALPHABETS["mixed"]) + random_strings(rng, 3, 20000, 60000, ALPHABETS["rare_space_at"])
+        rng.shuffle(texts)
+        cps, row = pack(texts)
+        work.append((cps, row, _oracle_offsets(oracle, cps, row)))
+    errors = []
+    gate = threading.Barrier(2, timeout=60)
+
+    def run(k):
+        try:
+            with _lib.Context(0) as ctx:
+                assert ctx.device == 0 and gpu.latok_ctx_device(ctx.handle) == 0
+                cps, row, (wc, wo, wb) = work[k]
+                gate.wait()
+                for _ in range(40):
+                    assert np.array_equal(batch.split_mask_batch(cps, row), wb)
+                    c, o = batch.split_offsets_csr(cps, row)
+                    assert np.array_equal(c, wc) and np.array_equal(o, wo)
+                    cs, sp = batch.token_spans_csr(cps, row)
+                    assert int(cs.sum()) == len(sp) <= len(o)
+            ctx.destroy()
+        except BaseException as exc:   # noqa: BLE001 - reported to the main thread
+            errors.append(exc)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errors, errors[0]
+    # the default context is untouched and still works from this thread
+    cps, row, (wc, wo, wb) = work[0]
+    assert gpu.latok_ctx_get_current() is None
+    assert np.array_equal(batch.split_mask_batch(cps, row), wb)
+
+
+def test_device_pool_equals_single_context(gpu, oracle):
+    from latok_amd import batch, multi
+    rng = random.Random(5)
+    texts = random_strings(rng, 20000, 0, 120, ALPHABETS["mixed"]) + ["", "日本語のテキスト、です。 🤓 ok"] + \
+        random_strings(rng, 2, 100000, 200000, ALPHABETS["words"])
+    cps, row = pack(texts)
+    wc, wo, wb = _oracle_offsets(oracle, cps, row)
+    with multi.DevicePool([0, 0, 0]) as pool:          # three contexts on the one GPU of this box
+        c, o = multi.split_offsets_csr(cps, row, pool)
+        assert np.array_equal(c, wc) and np.array_equal(o, wo)
+        assert np.array_equal(multi.split_mask_batch(cps, row, pool), wb)
+        assert multi.tokenize_batch(texts, pool) == batch.tokenize_batch(texts)
+        cs, sp = multi.token_spans_csr(cps, row, pool)
+        cs1, sp1 = batch.token_spans_csr(cps, row)
+        assert np.array_equal(cs, cs1) and np.array_equal(sp, sp1)
+        f = multi.token_features_csr(cps, row, pool)
+        f1 = batch.token_features_csr(cps, row)
+        assert all(np.array_equal(a, b) for a, b in zip(f, f1))
+        small = texts[:50]
+        assert [[t.text for t in toks] for toks in multi.featurize_batch(small, pool)] == \
+               [[t.text for t in toks] for toks in batch.featurize_batch(small)]
+    # the keyword form of the batch API: a list of device ids makes a temporary pool
+    assert batch.tokenize_batch(texts[:500], devices=[0, 0]) == batch.tokenize_batch(texts[:500])
+    offs = batch.split_offsets_batch(texts[:500], devices=[0, 0])
+    assert all(np.array_equal(a, b) for a, b in zip(offs, batch.split_offsets_batch(texts[:500])))
+
+
+def test_rule_tables_belong_to_their_context(gpu, oracle):
+    from conftest import RULE_SETS, oracle_rule_bits
+    from latok_amd import _lib, batch, multi
+    rng = random.Random(31)
+    texts = random_strings(rng, 400, 1, 90, ALPHABETS["mixed"])
+    cps, row = pack(texts)
+    tables = RULE_SETS["sym_everywhere"]
+    want_custom = oracle_rule_bits(oracle, texts, tables)
+    _, want_default = oracle.split_batch(cps, row, want_values=False)
+    assert not np.array_equal(want_custom, want_default)
+    with _lib.Context(0) as ctx:
+        batch.set_rules(*tables)
+        assert batch.rules_active()
+        assert np.array_equal(batch.split_mask_batch(cps, row), want_custom)
+    ctx.destroy()
+    assert not batch.rules_active()                                    # the default context never saw them
+    assert np.array_equal(batch.split_mask_batch(cps, row), want_default)
+    with multi.DevicePool([0, 0]) as pool:
+        pool.set_rules(*tables)
+        assert np.array_equal(multi.split_mask_batch(cps, row, pool), want_custom)
+        pool.reset_rules()
+        assert np.array_equal(multi.split_mask_batch(cps, row, pool), want_default)
+
+
+def test_calls_from_a_thread_that_did_not_init(gpu, oracle):
+    """HIP's current device is per thread; a worker thread that never called latok_init must still
+    allocate and launch on the context's device (DeviceGuard in every entry point)."""
+    from latok_amd import batch
+    cps, row = pack(["worker thread: a@b.c http://x.y/z #tag camelCase"] * 2000)
+    _, want = oracle.split_batch(cps, row, want_values=False)
+    got = []
+    t = threading.Thread(target=lambda: got.append(batch.split_mask_batch(cps, row)))
+    t.start()
+    t.join(120)
+    assert got and np.array_equal(got[0], want)
+    p = []
+    t = threading.Thread(target=lambda: p.append(gpu.latok_dev_alloc(1 << 20)))
+    t.start()
+    t.join(60)
+    assert p and p[0]
+    assert gpu.latok_dev_free(p[0]) == 0
+
+
+def test_context_lifecycle_errors(gpu):
+    from latok_amd import _lib
+    h = C.c_void_p()
+    assert gpu.latok_ctx_create(10_000, C.byref(h)) == _lib.ERR_INVALID and not h
+    assert gpu.latok_ctx_create(0, None) == _lib.ERR_INVALID
+    assert gpu.latok_ctx_create(0, C.byref(h)) == 0 and h
+    assert gpu.latok_ctx_set_current(h) == 0 and gpu.latok_ctx_get_current() == h.value
+    assert gpu.latok_ctx_destroy(h) == 0                  # destroying the current context falls back to the default one
+    assert gpu.latok_ctx_get_current() is None
+    assert gpu.latok_ctx_destroy(None) == 0
+
+
+def test_rebinding_the_module_level_tables_changes_tokenize(gpu, oracle):
+    """the reference's extension point is rebinding default_tokenizer.C_SPLIT / C_MASK / C_SYM
+    (default_tokenizer.py:108-110,123-129); tokenize() / featurize() must follow it like gen_split_mask does."""
+    from conftest import RULE_SETS
+    from latok_amd import batch
+    from latok_amd.core import default_tokenizer as dt
+    text = "see http://a.b/c, mail me@x.org! #ok camelCase 1 2"
+    base = list(dt.tokenize(text))
+    assert base == oracle.tokenize(text)
+    saved = (dt.C_SPLIT, dt.C_MASK, dt.C_SYM)
+    try:
+        dt.C_SPLIT, dt.C_MASK, dt.C_SYM = RULE_SETS["no_mask"]
+        want = np.nonzero(oracle.split_values_rules(text, *RULE_SETS["no_mask"]))[0]
+        assert np.array_equal(dt._boundaries(text), want)
+        assert np.array_equal(np.nonzero(dt.gen_split_mask(dt._gen_parse_matrix(text)))[0], want)
+        assert list(dt.tokenize(text)) != base and batch.rules_active()
+        assert [t.text for t in dt.featurize(text)] == list(dt.tokenize(text))
+    finally:
+        dt.C_SPLIT, dt.C_MASK, dt.C_SYM = saved
+    assert list(dt.tokenize(text)) == base and not batch.rules_active()

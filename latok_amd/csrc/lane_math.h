@@ -50,24 +50,9 @@ LATOK_HD lk_u64 lk_transpose8(lk_u64 x) {
 
 // 64 code bytes (d[k] = chars 4k..4k+3, little endian) -> 8 planes; plane[b] bit i = bit b of char i's code.
 #if defined(__HIP_DEVICE_COMPILE__)
-// Device form: the same three delta-swap stages written on 32-bit halves, then the byte regrouping done with
-// v_perm_b32 (one instruction per output dword half-pair) instead of shift/mask chains.
-__device__ __forceinline__ void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
-    uint32_t lo[8], hi[8];   // after the transposes: byte b of lo[g] = plane b (b < 4), of hi[g] = plane 4 + b, chars 8g..8g+7
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        uint32_t a = d[2 * g], b = d[2 * g + 1], t;
-        t = (a ^ (a >> 7)) & 0x00AA00AAu;  a ^= t ^ (t << 7);
-        t = (b ^ (b >> 7)) & 0x00AA00AAu;  b ^= t ^ (t << 7);
-        t = (a ^ (a >> 14)) & 0x0000CCCCu; a ^= t ^ (t << 14);
-        t = (b ^ (b >> 14)) & 0x0000CCCCu; b ^= t ^ (t << 14);
-        // stage 3 of the 64-bit form: t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0 ; x ^= t ^ (t << 28)
-        t = (a ^ ((a >> 28) | (b << 4))) & 0xF0F0F0F0u;
-        a ^= t ^ (t << 28);
-        b ^= (t >> 4);
-        lo[g] = a;
-        hi[g] = b;
-    }
+// Second half of the bit-slicing: lo[g] / hi[g] hold, for chars 8g..8g+7, plane b in byte b (lo: planes 0..3, hi: 4..7;
+// bit j of the byte = char 8g + j).  4x4 byte transposes regroup them into the 64-bit planes.
+__device__ __forceinline__ void lk_planes_from_groups(const uint32_t lo[8], const uint32_t hi[8], lk_u64 plane[8]) {
     // 4x4 byte transposes: out[b] = {x0.byte b, x1.byte b, x2.byte b, x3.byte b}
 #define LK_T4(x0, x1, x2, x3, o0, o1, o2, o3)                                   \
     {                                                                           \
@@ -89,7 +74,34 @@ __device__ __forceinline__ void lk_bitslice64(const uint32_t d[16], lk_u64 plane
 #pragma unroll
     for (int b = 0; b < 8; ++b) plane[b] = (lk_u64)pl[b] | ((lk_u64)ph[b] << 32);
 }
+// Device form: the same three delta-swap stages written on 32-bit halves, then the byte regrouping done with
+// v_perm_b32 (one instruction per output dword half-pair) instead of shift/mask chains.
+__device__ __forceinline__ void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
+    uint32_t lo[8], hi[8];   // after the transposes: byte b of lo[g] = plane b (b < 4), of hi[g] = plane 4 + b, chars 8g..8g+7
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        uint32_t a = d[2 * g], b = d[2 * g + 1], t;
+        t = (a ^ (a >> 7)) & 0x00AA00AAu;  a ^= t ^ (t << 7);
+        t = (b ^ (b >> 7)) & 0x00AA00AAu;  b ^= t ^ (t << 7);
+        t = (a ^ (a >> 14)) & 0x0000CCCCu; a ^= t ^ (t << 14);
+        t = (b ^ (b >> 14)) & 0x0000CCCCu; b ^= t ^ (t << 14);
+        // stage 3 of the 64-bit form: t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0 ; x ^= t ^ (t << 28)
+        t = (a ^ ((a >> 28) | (b << 4))) & 0xF0F0F0F0u;
+        a ^= t ^ (t << 28);
+        b ^= (t >> 4);
+        lo[g] = a;
+        hi[g] = b;
+    }
+    lk_planes_from_groups(lo, hi, plane);
+}
 #else
+LATOK_HD void lk_planes_from_groups(const uint32_t lo[8], const uint32_t hi[8], lk_u64 plane[8]) {
+    for (int b = 0; b < 8; ++b) {
+        lk_u64 p = 0;
+        for (int g = 0; g < 8; ++g) p |= (lk_u64)(((b < 4 ? lo[g] : hi[g]) >> (8 * (b & 3))) & 0xFFu) << (8 * g);
+        plane[b] = p;
+    }
+}
 LATOK_HD void lk_bitslice64(const uint32_t d[16], lk_u64 plane[8]) {
     lk_u64 y[8];
 #pragma unroll

@@ -140,7 +140,70 @@ struct TileLds {
     uint8_t* stage;        // kStageBytes, wave private
     uint8_t* halo;         // 16 bytes, wave private
     lk_u64* bw;            // 65 words of string-start bits, wave private
+    const uint8_t* lut;    // kModeLatin1: slice LUT (kSliceLutBytes) in place of the Unicode tables
+    const uint8_t* ctab;   // kModeLatin1: split code of each of the 256 Latin-1 chars
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Latin-1 input: classification and bit-slicing by ONE table.  A lane holds 64 raw bytes; what phase 2 needs from
+// them are the 8 planes of their split codes.  Looking a byte up in the code table and then transposing 8 x 64 bits
+// with shifts and masks costs ~7 VALU instructions per char; instead the table itself holds the code already spread
+// out -- entry c = {lo, hi}: bit 8 b of lo = bit b of code(c) (b < 4), of hi = bit 4 + b -- so that OR-ing the entries
+// of 8 consecutive chars, each shifted by its position, gives exactly the byte-per-plane words lk_bitslice64 has
+// after its three delta-swap stages.  The shift is folded into the table: 8 pre-shifted copies (2 KiB each), the
+// copy is selected by the immediate offset of the LDS instruction -> per char one address computation, two
+// ds_read_b32 and one v_or3 shared by two values.  (The narrow-input kernels are VALU-bound, not HBM-bound: 1 B/char
+// in, and the rule algebra per char is the same as for UTF-32.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSliceHiOff = 1024 + 64;                   // hi[c] sits 16 banks away from lo[c]: the two reads of a char never collide
+constexpr int kSliceCopyBytes = kSliceHiOff + 1024;      // {lo[256], pad, hi[256]} as uint32
+constexpr int kSliceLutBytes = 8 * kSliceCopyBytes;      // copy j = entries << j
+static_assert(kSliceLutBytes + 256 <= kTablesLdsBytes, "the Latin-1 tables live where the Unicode tables would");
+
+__device__ __forceinline__ void slice_lut64(const uint32_t (&d)[16], const uint8_t* lut, lk_u64 (&plane)[8]) {
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        uint32_t l = 0, h = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = d[2 * g + (j >> 2)];
+            const uint32_t off = ((w >> (8 * (j & 3))) & 0xFFu) << 2;
+            const uint8_t* e = lut + j * kSliceCopyBytes + off;
+            l |= *reinterpret_cast<const uint32_t*>(e);
+            h |= *reinterpret_cast<const uint32_t*>(e + kSliceHiOff);
+        }
+        // pin the two words here: without it the compiler requests all 128 lookups first (one result register each, spills)
+        // and ORs them afterwards; 16 in flight per group is plenty
+        asm volatile("" : "+v"(l), "+v"(h));
+        lo[g] = l;
+        hi[g] = h;
+    }
+    lk_planes_from_groups(lo, hi, plane);
+}
+
+// split code of Latin-1 char c from the global tables (U+0000..U+00FF live in the first two stage-2 blocks)
+__device__ __forceinline__ uint32_t latin1_code_global(const SplitParams& P, uint32_t c) {
+    const uint32_t blk = P.t1[c >> kTblShift];
+    return P.t2[(blk << kTblShift) | (c & ((1u << kTblShift) - 1u))];
+}
+
+// build [slice LUT | code table] in LDS (NT threads)
+template <int NT>
+__device__ __forceinline__ void build_latin1_tables(uint8_t* lds, const SplitParams& P) {   // lds = where the LUT goes
+    for (int c = threadIdx.x; c < 256; c += NT) {
+        const uint32_t code = latin1_code_global(P, (uint32_t)c);
+        lds[kSliceLutBytes + c] = (uint8_t)code;
+        const uint32_t lo = ((code & 15u) * 0x00204081u) & 0x01010101u;
+        const uint32_t hi = ((code >> 4) * 0x00204081u) & 0x01010101u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t* copy = reinterpret_cast<uint32_t*>(lds + j * kSliceCopyBytes);
+            copy[c] = lo << j;
+            copy[kSliceHiOff / 4 + c] = hi << j;
+        }
+    }
+}
 
 // One tile = 4096 chars, one wave.  (Register prefetch of the next tile -- full, half, quarter; 8/10/12/16 waves per
 // CU -- was measured and gives nothing: see DESIGN.md, so the tile function stays simple.)
@@ -183,9 +246,8 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
             halo_u = KIND == 1 ? (uint32_t)P.u8[hp] : (uint32_t)reinterpret_cast<const uint16_t*>(P.u8)[hp];
     }
     if (KIND == 1) {
-        // Latin-1: U+0000..U+00FF live in the first two stage-2 blocks -> one lookup per byte
-        const uint32_t off0 = (uint32_t)L.t1[0] << kTblShift, off1 = ((uint32_t)L.t1[1] << kTblShift) - 128u;
-        auto code_of = [&](uint32_t b) -> uint32_t { return L.t2[b + ((b & 0x80u) ? off1 : off0)]; };
+        // Latin-1: the RAW bytes go to the staging buffer (phase 2 classifies and bit-slices them with one table,
+        // slice_lut64); only the three halo chars are classified here
         u32x4 v[4];
         if (t0 + kTile <= total) {
             const u32x4* src = reinterpret_cast<const u32x4*>(P.u8 + t0) + lane;
@@ -202,25 +264,11 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
             }
         }
         wave_lds_sync();   // the zero stores to the halo are ordered before the halo stores below
+        // positions past the end of the batch hold unit 0 here; their codes are masked by `valid` in phase 2
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            uint32_t cc[4];
-            if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cc[j] = (uint32_t)L.t2[off0 + (d[j] & 0xFFu)] | ((uint32_t)L.t2[off0 + ((d[j] >> 8) & 0xFFu)] << 8) |
-                            ((uint32_t)L.t2[off0 + ((d[j] >> 16) & 0xFFu)] << 16) | ((uint32_t)L.t2[off0 + (d[j] >> 24)] << 24);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cc[j] = code_of(d[j] & 0xFFu) | (code_of((d[j] >> 8) & 0xFFu) << 8) | (code_of((d[j] >> 16) & 0xFFu) << 16) |
-                            (code_of(d[j] >> 24) << 24);
-            }
-            // positions past the end of the batch hold unit 0 here; their codes are masked by `valid` in phase 2
-            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
-        }
-        if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = (uint8_t)code_of(halo_u);
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(v[i].x, v[i].y, v[i].z, v[i].w);
+        if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = L.ctab[halo_u & 0xFFu];
     } else {
         // UCS-2: 8 units per 16-byte load, row i of the tile = units 512 i + 8 lane ..
         u32x4 v[8];
@@ -262,7 +310,7 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
     }
 }
 
-__device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
+__device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
     const int64_t total = P.total;
     const uint8_t* __restrict__ u8 = P.u8;
     // the tile: 4 x 16 bytes per lane (row i covers bytes 1024 i + 16 lane ..)
@@ -321,11 +369,20 @@ __device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds
         L.halo[0] = L.t2[hb & 0xFFu];
     }
 
+    if (all_ascii) {
+        // no multi-byte char in or around the tile (the common case): the RAW bytes go to the staging buffer and phase 2
+        // classifies and bit-slices them with one table (slice_lut64), exactly like a Latin-1 tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(v[i].x, v[i].y, v[i].z, v[i].w);
+        if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.t2[hb & 0xFFu];
+        return true;
+    }
     ByteCarry row_in = in0;                             // state entering lane 0 of the current row (wave-uniform use)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-        if (all_ascii || __all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
+        if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
             // this 1 KiB row is pure ASCII (no char reaches into it or out of it): one lookup per byte
             uint32_t cc[4];
 #pragma unroll
@@ -391,10 +448,6 @@ __device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds
         row_in.code = __shfl(cur, 63);
         row_in.left = __shfl(left, 63);
     }
-    if (all_ascii) {
-        if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.t2[hb & 0xFFu];
-        return;
-    }
     // the 8 bytes after the tile: smeared codes into halo[8..15], continuation bits into halo[3].  Lane k+1 owns byte k.
     {
         const int k = lane - 1;
@@ -425,6 +478,7 @@ __device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds
             L.halo[8 + k] = (uint8_t)own;
         }
     }
+    return false;
 }
 
 // Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
@@ -432,7 +486,7 @@ __device__ __forceinline__ void bytes_phase1(const SplitParams& P, const TileLds
 // the two phases in different waves; see DESIGN.md, negative results.)
 template <int MODE, bool DEFER = false>
 __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
-                                            bool write_summary, int4* summ_l, int lane
+                                            bool write_summary, int4* summ_l, int lane, bool raw_stage
 #ifdef LATOK_STAMPS
                                             , unsigned long long* stamp_acc, unsigned long long& stamp_prev
 #endif
@@ -487,14 +541,39 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
-        lk_bitslice64(d, plane);
+        if (MODE == kModeLatin1 || (MODE == kModeBytes && raw_stage)) {
+            // d = raw bytes: classify + slice through the LUT; the neighbour bytes become codes through the code table
+            LATOK_STAMP(9);    // (share of stamp 4: the four ds_read_b128 + neighbour bytes)
+#if defined(LATOK_AB_NO_SLICE)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) plane[b] = (lk_u64)d[2 * b] | ((lk_u64)d[2 * b + 1] << 32);
+#elif defined(LATOK_AB_ARITH_SLICE)
+            lk_bitslice64(d, plane);
+#else
+            slice_lut64(d, L.lut, plane);
+#endif
+            LATOK_STAMP(10);   // (share of stamp 4: LUT slicing)
+            h.prev = lane > 0 ? L.ctab[h.prev] : h.prev;
+            h.next0 = lane < 63 ? L.ctab[h.next0] : h.next0;
+            h.next1 = lane < 63 ? L.ctab[h.next1] : h.next1;
+        } else {
+            lk_bitslice64(d, plane);
+        }
         if (mode_is_units(MODE)) {
             // one code per char like a UTF-32 tile, in the byte-space layout: the two chars after my row are the next row's
             // first codes (lane 63: halo[8], halo[9])
             lk_halo ha;
             ha.prev = h.prev;
-            ha.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[8];
-            ha.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[9];
+            ha.next0 = lane < 63 ? h.next0 : L.halo[8];
+            ha.next1 = lane < 63 ? h.next1 : L.halo[9];
+            loc = lk_rules(lk_decode(plane), ha, B, Bn);
+            space_plane = loc.S;
+        } else if (MODE == kModeBytes && raw_stage) {
+            // all-ASCII tile: byte positions are char positions, the plain rules apply (codes of the neighbours: above)
+            lk_halo ha;
+            ha.prev = h.prev;
+            ha.next0 = lane < 63 ? h.next0 : L.halo[8];
+            ha.next1 = lane < 63 ? h.next1 : L.halo[9];
             loc = lk_rules(lk_decode(plane), ha, B, Bn);
             space_plane = loc.S;
         } else if (MODE == kModeBytes) {
@@ -526,6 +605,15 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         }
     }
     LATOK_STAMP(4);
+#ifdef LATOK_AB_NO_BLOCK
+    if (mode_writes_bits(MODE)) {   // ablation: no block mask at all (wrong results, timing only)
+        const lk_u64 o = loc.raw | loc.sym | B;
+        if (write_summary && lane == 0) *summ_l = make_int4(0, 0, 0, 0);
+        if (!DEFER && base < total) P.bits_out[base >> 6] = o;
+        wave_lds_sync();
+        return o;
+    }
+#endif
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
 
     // forward: inclusive (max,+) scan of the per-word queue transfer functions over the 64 lanes
@@ -653,6 +741,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
+    bool raw_stage = MODE == kModeLatin1;   // the staging buffer holds raw bytes, not codes (Latin-1; all-ASCII tiles of byte mode)
     LATOK_STAMP(0);
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
@@ -676,7 +765,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     } else if (MODE == kModeUcs2) {
         units_phase1<2>(P, L, t0, lane);
     } else if (MODE == kModeBytes) {
-        bytes_phase1(P, L, t0, lane);
+        raw_stage = bytes_phase1(P, L, t0, lane);
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
@@ -720,7 +809,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #endif
     LATOK_STAMP(3);
 
-    return tile_phase2<MODE, DEFER>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane
+    return tile_phase2<MODE, DEFER>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage
 #ifdef LATOK_STAMPS
                                     , stamp_acc, stamp_prev
 #endif
@@ -868,16 +957,25 @@ constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSeg
 constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
 constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
 constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
-constexpr int kLdsTotal = kLdsMisc + 256;
+constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: [slice LUT | code table] (ASCII tiles); Latin-1 has it at 0
+constexpr int kLdsTotalBase = kLdsSlice;
+constexpr int kLdsTotalBytes = kLdsSlice + kSliceLutBytes + 256;
+constexpr int lds_total(int mode) { return mode == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
+constexpr int kLdsTotal = kLdsTotalBytes;
 static_assert(sizeof(ScanLds) <= 512, "scan scratch");
 static_assert(kSegMax == kWPB * 64, "one tile per thread in the block-wide scans");
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
-static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0, "alignment");
+static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0 && kLdsSlice % 16 == 0, "alignment");
 
 // Both tables are contiguous in LDS ([stage1 | stage2]) and in global memory (api.cpp uploads them back to back), so the
 // copy is one stream of kTablesLdsBytes / 16 vectors; all of a thread's loads are issued before its first LDS write.
-template <int NT = kWPB * 64>
+template <int NT = kWPB * 64, int MODE = kModeBits>
 __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) {
+    if (MODE == kModeLatin1) {
+        build_latin1_tables<NT>(lds, P);
+        return;
+    }
+    if (MODE == kModeBytes) build_latin1_tables<NT>(lds + kLdsSlice, P);   // for its all-ASCII tiles
     constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
     constexpr int kPer = (kVec + NT - 1) / NT;                    // 4 with 768 threads
     const uint4* src = reinterpret_cast<const uint4*>(P.t1);
@@ -899,6 +997,7 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
     }
 }
 
+template <int MODE = kModeBits>
 __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     TileLds L;
     L.t1 = lds;
@@ -907,6 +1006,8 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.stage = mine;
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
+    L.lut = lds + (MODE == kModeBytes ? kLdsSlice : 0);   // build_latin1_tables: kModeLatin1 at 0, kModeBytes behind the rest
+    L.ctab = L.lut + kSliceLutBytes;
     return L;
 }
 
@@ -929,7 +1030,7 @@ template <int MODE>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
                                             int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
-    const TileLds L = wave_lds(lds, wave);
+    const TileLds L = wave_lds<MODE>(lds, wave);
     int4* sm = reinterpret_cast<int4*>(lds + kLdsSumm);
     ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
 
@@ -995,14 +1096,14 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
 
 template <int MODE>
 __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsTotal];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar tile arithmetic
     if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
 
     bool tables = MODE != kModeBlockMask;
-    if (tables) load_tables(lds, P);   // published by the barrier at the top of the workgroup's first segment
+    if (tables) load_tables<kWPB * 64, MODE>(lds, P);   // published by the barrier at the top of the workgroup's first segment
 #ifdef LATOK_STAMPS
     unsigned long long stamp_acc[16];
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
@@ -1013,7 +1114,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
     }
 #ifdef LATOK_STAMPS
     if (lane == 0)
-        for (int i = 0; i < 9; ++i) atomicAdd(&g_stamp_sum[i], stamp_acc[i]);
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_stamp_sum[i], stamp_acc[i]);
 #endif
 }
 
@@ -1028,7 +1129,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
 // are short (C2: 122 tiles) run it with 2 or 4 waves instead of 12 -- the stage is all latency, fewer waves start faster.
 template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsTotal];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1106,11 +1207,11 @@ __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
         const int n_fix = misc[0];
         if (n_fix > 0) {
             if (!tables_loaded && MODE != kModeBlockMask) {
-                load_tables<NW * 64>(lds, P);
+                load_tables<NW * 64, MODE>(lds, P);
                 tables_loaded = true;
                 __syncthreads();
             }
-            const TileLds L = wave_lds(lds, wave);
+            const TileLds L = wave_lds<MODE>(lds, wave);
             for (int i = wave; i < n_fix; i += NW) {
                 const int64_t tt = T0 + fix_t[i];
                 const int2 in = fix_in[i];

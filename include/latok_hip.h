@@ -25,7 +25,8 @@
  *     for the previous call's last kernel before its own first one, whatever stream it uses); calls on DIFFERENT
  *     contexts share nothing and run concurrently -- one host thread + one context per GPU is how a batch is sharded
  *     over the GPUs of a node (SURVEY 8b "Threading", 8e).  The compaction entry points (offsets / spans / features)
- *     read one 8-byte total back and therefore block even in device mode.
+ *     return the item total to the host and therefore block even in device mode: everything is enqueued first (the
+ *     kernels write the records only if the total fits the caller's capacity) and the call synchronises once.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H
@@ -44,6 +45,12 @@ extern "C" {
 #define LATOK_ERR_NOMEM (-4)
 
 #define LATOK_DEVICE_PTRS 1
+/* Compaction entry points (offsets / spans / features): counts_out and the offsets / spans / spans4 records are int32
+ * arrays instead of int64 (the parameters keep their int64_t* type: pass the int32 buffer through a cast; capacities stay
+ * in ELEMENTS / tokens).  The records are most of the bytes these calls write and send over the bus -- 8 B per boundary,
+ * 16 B per token -- so the 32-bit form halves that.  Every value is relative to its own string, so it fits unless a
+ * single string has 2^31 chars or more: then the call fails with LATOK_ERR_INVALID and the 64-bit form has to be used. */
+#define LATOK_OUT_INT32 2
 
 #define LATOK_FEATURE_COUNT 25 /* reference latok/core/offsets.py:49 */
 #define LATOK_TILE_CHARS 4096  /* chars per wavefront tile (64 lanes x 64-bit words) */

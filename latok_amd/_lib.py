@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("LATOK_HIP_LIB", os.path.join(_HERE, "liblatok_hip.so"
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOT_INIT, ERR_NOMEM = 0, -1, -2, -3, -4
 DEVICE_PTRS = 1
+OUT_INT32 = 2
 FEATURE_COUNT = 25
 TILE_CHARS = 4096
 CORPUS_ASCII, CORPUS_UNICODE = 0, 1

@@ -33,6 +33,31 @@ def _csr(cps, row_off):
     return cps, row_off
 
 
+
+def _out_dtype(dtype):
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.int64), np.dtype(np.int32)):
+        raise ValueError("dtype must be int64 or int32")
+    return dt, (_lib.OUT_INT32 if dt == np.dtype(np.int32) else 0)
+
+
+def _compact(fn, lead, n_str, total, width, dtype, feats=False):
+    """Shared body of the compaction wrappers: fn(*lead, n_str, total, counts, items[, features], cap, &n, flags, stream).
+    Returns (counts[n_str], items[n] or items[n, width][, features int8[n, 25]]); counts / items in `dtype` (int64, or
+    int32 = LATOK_OUT_INT32: half the bytes written on the device and moved over the bus)."""
+    dt, flags = _out_dtype(dtype)
+    counts = np.zeros(n_str, dt)
+    cap = max(total, 1)                                  # a string has at most len items
+    items = np.empty((cap, width) if width > 1 else cap, dt)
+    feat = np.empty((cap, _lib.FEATURE_COUNT), np.int8) if feats else None
+    n = C.c_int64(0)
+    args = list(lead) + [n_str, total, _ptr(counts), _ptr(items)] + ([_ptr(feat)] if feats else []) + [cap, C.byref(n), flags, None]
+    _lib.check(fn(*args))
+    if feats:
+        return counts, items[:n.value].copy(), feat[:n.value].copy()
+    return counts, items[:n.value].copy()
+
+
 def split_mask_batch(cps, row_off) -> np.ndarray:
     """Boundary bitmask uint64[ceil(total/64)]: bit i = packed char i starts a token."""
     cps, row_off = _csr(cps, row_off)
@@ -55,23 +80,22 @@ def split_values_batch(cps, row_off) -> np.ndarray:
     return vals
 
 
-def split_offsets_csr(cps, row_off):
-    """(counts int64[n], offsets int64[sum(counts)]): per-string boundary offsets, concatenated."""
+def split_offsets_csr(cps, row_off, dtype=np.int64):
+    """(counts[n], offsets[sum(counts)]): per-string boundary offsets, concatenated (dtype int64 or int32)."""
     cps, row_off = _csr(cps, row_off)
     n_str = row_off.size - 1
     total = int(row_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    offsets = np.empty(max(total, 1), np.int64)  # a string has at most len boundaries
-    n_off = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_split_offsets_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(offsets),
-                                             offsets.size, C.byref(n_off), 0, None))
-    return counts, offsets[:n_off.value].copy()
+    return _compact(_lib.ensure_init().latok_split_offsets_batch, [_ptr(cps), _ptr(row_off)], n_str, total, 1, dtype)
 
 
 # host batches beyond the library's small-batch path (api.cpp: kSmallChars / kSmallStrings, served from pinned memory
 # in UTF-32) are shipped as the narrowest PEP 393 kind: 1 or 2 bytes per char over the bus instead of 4
 _SMALL_CHARS, _SMALL_STRINGS = 16384, 512
+
+
+def _record_dtype(row_off):
+    """int32 records (LATOK_OUT_INT32: half the device writes and bus traffic) unless a string has 2^31 chars or more"""
+    return np.int32 if row_off.size < 2 or int(np.diff(row_off).max()) <= 0x7FFFFFFF else np.int64
 
 
 def _narrow_pays(texts):
@@ -93,36 +117,22 @@ def split_offsets_batch(texts, devices=None):
     return np.split(offsets, np.cumsum(counts)[:-1])
 
 
-def token_spans_csr(cps, row_off):
-    """(counts int64[n], spans int64[n_tokens, 2]): [start, end) of every token of every string, already stripped and
-    with whitespace-only tokens dropped -- everything reference tokenize() does after np.nonzero, on the device."""
+def token_spans_csr(cps, row_off, dtype=np.int64):
+    """(counts[n], spans[n_tokens, 2]): [start, end) of every token of every string, already stripped and with
+    whitespace-only tokens dropped -- everything reference tokenize() does after np.nonzero, on the device."""
     cps, row_off = _csr(cps, row_off)
     n_str = row_off.size - 1
     total = int(row_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    spans = np.empty((max(total, 1), 2), np.int64)   # at most one token per char
-    n_tok = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_token_spans_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
-                                           spans.shape[0], C.byref(n_tok), 0, None))
-    return counts, spans[:n_tok.value].copy()
+    return _compact(_lib.ensure_init().latok_token_spans_batch, [_ptr(cps), _ptr(row_off)], n_str, total, 2, dtype)
 
 
-def token_features_csr(cps, row_off):
-    """(counts int64[n], spans int64[n_tokens, 4] = {raw_start, raw_end, strip_start, strip_end},
-    features int8[n_tokens, 25]): reference featurize() for a whole batch, without the n x 25 matrix."""
+def token_features_csr(cps, row_off, dtype=np.int64):
+    """(counts[n], spans[n_tokens, 4] = {raw_start, raw_end, strip_start, strip_end}, features int8[n_tokens, 25]):
+    reference featurize() for a whole batch, without the n x 25 matrix."""
     cps, row_off = _csr(cps, row_off)
     n_str = row_off.size - 1
     total = int(row_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    cap = max(total, 1)
-    spans = np.empty((cap, 4), np.int64)
-    feats = np.empty((cap, _lib.FEATURE_COUNT), np.int8)
-    n_tok = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_token_features_batch(_ptr(cps), _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
-                                              _ptr(feats), cap, C.byref(n_tok), 0, None))
-    return counts, spans[:n_tok.value].copy(), feats[:n_tok.value].copy()
+    return _compact(_lib.ensure_init().latok_token_features_batch, [_ptr(cps), _ptr(row_off)], n_str, total, 4, dtype, feats=True)
 
 
 def featurize_batch(texts, devices=None):
@@ -135,9 +145,11 @@ def featurize_batch(texts, devices=None):
         from . import multi
         return multi.featurize_batch(texts, devices)
     if _narrow_pays(texts):
-        counts, spans, feats = token_features_kind_csr(*pack_kind(texts))
+        units, row_off = pack_kind(texts)
+        counts, spans, feats = token_features_kind_csr(units, row_off, dtype=_record_dtype(row_off))
     else:
-        counts, spans, feats = token_features_csr(*pack(texts))
+        cps, row_off = pack(texts)
+        counts, spans, feats = token_features_csr(cps, row_off, dtype=_record_dtype(row_off))
     out, k = [], 0
     for text, n in zip(texts, counts.tolist()):
         out.append([LaToken(text[c:d], a, b, feats[k + j]) for j, (a, b, c, d) in enumerate(spans[k:k + n].tolist())])
@@ -190,33 +202,21 @@ def split_mask_utf8_csr(utf8, byte_off):
     return bits[:(n.value + 63) // 64], row
 
 
-def split_offsets_utf8_csr(utf8, byte_off):
+def split_offsets_utf8_csr(utf8, byte_off, dtype=np.int64):
     """(counts, offsets) like split_offsets_csr, input handed over as UTF-8 (1 byte per ASCII char over PCIe).
     Offsets are code-point indices, as the reference reports them for the decoded str."""
     utf8, byte_off = _csr_u8(utf8, byte_off)
     n_str = byte_off.size - 1
     total = int(byte_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    offsets = np.empty(max(total, 1), np.int64)
-    n_off = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_split_offsets_utf8_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(offsets),
-                                                  offsets.size, C.byref(n_off), 0, None))
-    return counts, offsets[:n_off.value].copy()
+    return _compact(_lib.ensure_init().latok_split_offsets_utf8_batch, [_ptr(utf8), _ptr(byte_off)], n_str, total, 1, dtype)
 
 
-def token_spans_utf8_csr(utf8, byte_off):
+def token_spans_utf8_csr(utf8, byte_off, dtype=np.int64):
     """(counts, spans[n_tokens, 2]) like token_spans_csr for a UTF-8 CSR batch; spans are code-point indices."""
     utf8, byte_off = _csr_u8(utf8, byte_off)
     n_str = byte_off.size - 1
     total = int(byte_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    spans = np.empty((max(total, 1), 2), np.int64)
-    n_tok = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_token_spans_utf8_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(spans),
-                                                spans.shape[0], C.byref(n_tok), 0, None))
-    return counts, spans[:n_tok.value].copy()
+    return _compact(_lib.ensure_init().latok_token_spans_utf8_batch, [_ptr(utf8), _ptr(byte_off)], n_str, total, 2, dtype)
 
 
 # byte-space forms: the tile kernel reads the UTF-8 bytes itself; every position is a BYTE position in `utf8`
@@ -231,32 +231,20 @@ def split_mask_utf8_bytes_csr(utf8, byte_off) -> np.ndarray:
     return bits
 
 
-def split_offsets_utf8_bytes_csr(utf8, byte_off):
+def split_offsets_utf8_bytes_csr(utf8, byte_off, dtype=np.int64):
     """(counts, offsets): boundary BYTE offsets relative to each string's first byte."""
     utf8, byte_off = _csr_u8(utf8, byte_off)
     n_str = byte_off.size - 1
     total = int(byte_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    offsets = np.empty(max(total, 1), np.int64)
-    n_off = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_split_offsets_utf8_bytes_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts),
-                                                        _ptr(offsets), offsets.size, C.byref(n_off), 0, None))
-    return counts, offsets[:n_off.value].copy()
+    return _compact(_lib.ensure_init().latok_split_offsets_utf8_bytes_batch, [_ptr(utf8), _ptr(byte_off)], n_str, total, 1, dtype)
 
 
-def token_spans_utf8_bytes_csr(utf8, byte_off):
+def token_spans_utf8_bytes_csr(utf8, byte_off, dtype=np.int64):
     """(counts, spans[n_tokens, 2]): [start, end) BYTE ranges of the stripped, non-empty tokens of each string."""
     utf8, byte_off = _csr_u8(utf8, byte_off)
     n_str = byte_off.size - 1
     total = int(byte_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    spans = np.empty((max(total, 1), 2), np.int64)
-    n_tok = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_token_spans_utf8_bytes_batch(_ptr(utf8), _ptr(byte_off), n_str, total, _ptr(counts), _ptr(spans),
-                                                      spans.shape[0], C.byref(n_tok), 0, None))
-    return counts, spans[:n_tok.value].copy()
+    return _compact(_lib.ensure_init().latok_token_spans_utf8_bytes_batch, [_ptr(utf8), _ptr(byte_off)], n_str, total, 2, dtype)
 
 
 def tokenize_utf8_batch(blobs):
@@ -265,7 +253,7 @@ def tokenize_utf8_batch(blobs):
     if len(blobs) == 0:
         return []
     utf8, byte_off = pack_utf8(blobs)
-    counts, spans = token_spans_utf8_bytes_csr(utf8, byte_off)
+    counts, spans = token_spans_utf8_bytes_csr(utf8, byte_off, dtype=_record_dtype(byte_off))
     out, k = [], 0
     for blob, n in zip(blobs, counts.tolist()):
         out.append([blob[a:b] for a, b in spans[k:k + n].tolist()])
@@ -315,43 +303,26 @@ def split_mask_kind_csr(units, row_off) -> np.ndarray:
     return bits
 
 
-def _compact_kind(fn, width, units, row_off):
+def _compact_kind(fn, width, units, row_off, dtype, feats=False):
     units, row_off, kind = _csr_kind(units, row_off)
     n_str = row_off.size - 1
     total = int(row_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    items = np.empty((max(total, 1), width), np.int64)
-    n_out = C.c_int64(0)
-    _lib.check(fn(_ptr(units), kind, _ptr(row_off), n_str, total, _ptr(counts), _ptr(items), items.shape[0],
-                  C.byref(n_out), 0, None))
-    return counts, items[:n_out.value].copy()
+    return _compact(fn, [_ptr(units), kind, _ptr(row_off)], n_str, total, width, dtype, feats)
 
 
-def split_offsets_kind_csr(units, row_off):
+def split_offsets_kind_csr(units, row_off, dtype=np.int64):
     """(counts, offsets) like split_offsets_csr for PEP 393 code units."""
-    counts, items = _compact_kind(_lib.ensure_init().latok_split_offsets_kind_batch, 1, units, row_off)
-    return counts, items.reshape(-1)
+    return _compact_kind(_lib.ensure_init().latok_split_offsets_kind_batch, 1, units, row_off, dtype)
 
 
-def token_spans_kind_csr(units, row_off):
+def token_spans_kind_csr(units, row_off, dtype=np.int64):
     """(counts, spans[n_tokens, 2]) like token_spans_csr for PEP 393 code units."""
-    return _compact_kind(_lib.ensure_init().latok_token_spans_kind_batch, 2, units, row_off)
+    return _compact_kind(_lib.ensure_init().latok_token_spans_kind_batch, 2, units, row_off, dtype)
 
 
-def token_features_kind_csr(units, row_off):
+def token_features_kind_csr(units, row_off, dtype=np.int64):
     """(counts, spans[n_tokens, 4], features int8[n_tokens, 25]) like token_features_csr for PEP 393 code units."""
-    units, row_off, kind = _csr_kind(units, row_off)
-    n_str = row_off.size - 1
-    total = int(row_off[-1]) if n_str > 0 else 0
-    counts = np.zeros(n_str, np.int64)
-    cap = max(total, 1)
-    spans = np.empty((cap, 4), np.int64)
-    feats = np.empty((cap, _lib.FEATURE_COUNT), np.int8)
-    n_tok = C.c_int64(0)
-    lib = _lib.ensure_init()
-    _lib.check(lib.latok_token_features_kind_batch(_ptr(units), kind, _ptr(row_off), n_str, total, _ptr(counts), _ptr(spans),
-                                                   _ptr(feats), cap, C.byref(n_tok), 0, None))
-    return counts, spans[:n_tok.value].copy(), feats[:n_tok.value].copy()
+    return _compact_kind(_lib.ensure_init().latok_token_features_kind_batch, 4, units, row_off, dtype, feats=True)
 
 
 def spans_from_offsets(text, nz):
@@ -383,9 +354,11 @@ def tokenize_batch(texts, devices=None):
         from . import multi
         return multi.tokenize_batch(texts, devices)
     if _narrow_pays(texts):
-        counts, spans = token_spans_kind_csr(*pack_kind(texts))
+        units, row_off = pack_kind(texts)
+        counts, spans = token_spans_kind_csr(units, row_off, dtype=_record_dtype(row_off))
     else:
-        counts, spans = token_spans_csr(*pack(texts))
+        cps, row_off = pack(texts)
+        counts, spans = token_spans_csr(cps, row_off, dtype=_record_dtype(row_off))
     out, k = [], 0
     for text, n in zip(texts, counts.tolist()):
         out.append([text[a:b] for a, b in spans[k:k + n].tolist()])

@@ -118,6 +118,9 @@ struct Ctx {
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, wpref, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
+    DevBuf chain, chain_ctl;   // k_word_counts_scan: look-back state per workgroup, {ticket counter}
+    unsigned scan_epoch = 0;
+    bool chain_ready = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
@@ -328,7 +331,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
                       &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
-                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux})
+                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl})
         b->release();
     for (auto& e : g.ev) {
         if (e) (void)hipEventDestroy(e);
@@ -337,6 +340,8 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     if (g.turn_event) (void)hipEventDestroy(g.turn_event);
     g.turn_event = nullptr;
     g.turn_stream_valid = false;
+    g.chain_ready = false;
+    g.scan_epoch = 0;
     if (g.stream) (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
     g.inited = false;
@@ -591,8 +596,8 @@ static int decode_utf8_to_workspace(Ctx& g, const uint8_t* u8, const int64_t* by
 // featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
 static int enqueue_features(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
                             const uint64_t* d_space, const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt,
-                            const uint16_t* d_pref, const int64_t* d_tile_first, int64_t* d_spans4, int8_t* d_feat,
-                            hipStream_t st) {
+                            const uint16_t* d_pref, const int64_t* d_tile_first, void* d_spans4, int8_t* d_feat, bool out32,
+                            const int64_t* d_n_tokens, int64_t cap, hipStream_t st) {
     latok::FeatParams F;
     F.cps = d_cps;
     F.row_off = d_row;
@@ -609,23 +614,59 @@ static int enqueue_features(Ctx& g, const uint32_t* d_cps, const int64_t* d_row,
     F.space = d_space;
     F.features = d_feat;
     F.spans4 = d_spans4;
+    F.out32 = out32;
+    F.n_tokens_dev = d_n_tokens;
+    F.cap = cap;
     HIP_TRY(latok::launch_features_tiles(F, g.n_cu, st));
     return LATOK_OK;
 }
 
-// shared body of the two compaction entry points: per-string boundary offsets (spans = false) or token spans
+// the single-pass scan of k_word_counts_scan keeps its state between launches: entries carry an epoch, so the array is
+// cleared only when it is (re)allocated or when the 18-bit epoch wraps
+static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* epoch_out) {
+    int rc;
+    const size_t old_cap = g.chain.cap;
+    if ((rc = g.chain.ensure((size_t)n_blocks * 8 + 64))) return rc;
+    if ((rc = g.chain_ctl.ensure(64))) return rc;
+    g.scan_epoch = (g.scan_epoch + 1) & 0x3FFFFu;
+    if (g.chain.cap != old_cap || g.scan_epoch == 0 || !g.chain_ready) {
+        HIP_TRY(hipMemsetAsync(g.chain.p, 0, g.chain.cap, st));
+        HIP_TRY(hipMemsetAsync(g.chain_ctl.p, 0, 64, st));
+        g.scan_epoch = 1;
+        g.chain_ready = true;
+    }
+    *epoch_out = g.scan_epoch;
+    return LATOK_OK;
+}
+
+// Shared body of the compaction entry points: per-string boundary offsets (spans = false), token spans, or token spans +
+// feature sums (features_out).  Launch sequence on device-resident data:
+//   tile index -> tiles -> resolve            the two bitmasks (boundaries, SPACE)
+//   k_word_counts_scan                        items per word / tile, tile ranks (scan) and the total, one launch
+//   k_counts_scatter (or k_string_counts + k_features_tiles)     per-string counts + the records, one launch, written
+//                                             only if the total fits the caller's capacity
+//   one synchronisation: the total (and the error flag) are read from pinned memory
+// With host pointers the records are staged on the device, so the total has to be known before the staging buffer can be
+// sized: one more synchronisation in the middle (that path is bound by the bus anyway).
 static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
-                          int64_t* counts_out, int64_t* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
+                          void* counts_out, void* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
                           bool byte_space = false, int unit_kind = 0) {
     const bool feats = features_out != nullptr;
+    const bool o32 = (flags & LATOK_OUT_INT32) != 0;
     int rc = need_init(g);
     if (rc) return rc;
     if (!n_items_out) return fail(LATOK_ERR_INVALID, "the total-count output pointer is NULL");
     *n_items_out = 0;
+    if (items_cap < 0) return fail(LATOK_ERR_INVALID, "negative capacity");
+    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    if (o32 && !dev && row_off && n_str > 0) {   // before anything is staged (device-resident row offsets: the kernel checks)
+        for (int64_t s = 0; s < n_str; ++s)
+            if (row_off[s + 1] - row_off[s] > 0x7FFFFFFFll)
+                return fail(LATOK_ERR_INVALID, "string %lld is too long for LATOK_OUT_INT32; use the 64-bit form", (long long)s);
+    }
     StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
-    const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
     const uint8_t* d_u8 = nullptr;   // byte space: the tile kernel reads the UTF-8 bytes itself, results are byte offsets
@@ -675,16 +716,21 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     }
     if (n_str == 0) return LATOK_OK;
     if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
+    const size_t elt = o32 ? 4 : 8;                                   // width of counts and of every record field
+    const size_t item_bytes = (feats ? 4 : (spans ? 2 : 1)) * elt;
+    if (total == 0) {   // only empty strings: all counts are 0
+        if (dev) HIP_TRY(hipMemsetAsync(counts_out, 0, (size_t)n_str * elt, st));
+        else memset(counts_out, 0, (size_t)n_str * elt);
+        return LATOK_OK;
+    }
     // small host batch: inputs and every output live in pinned mapped memory; nothing is copied by the runtime and the
     // call synchronises once (a string of ~100 chars: ~110 us of blocking copies otherwise)
-    const bool small = !dev && !utf8 && total > 0 && total <= kSmallChars && n_str <= kSmallStrings;
-    const size_t item_bytes = feats ? 32 : (spans ? 16 : 8);
-    size_t po_row = 0, po_n = 0, po_counts = 0, po_items = 0, po_feat = 0;
+    const bool small = !dev && !utf8 && total <= kSmallChars && n_str <= kSmallStrings;
+    size_t po_row = 0, po_counts = 0, po_items = 0, po_feat = 0;
     if (small) {
         po_row = ((size_t)total * 4 + 15) & ~(size_t)15;
-        po_n = po_row + (size_t)(n_str + 1) * 8;
-        po_counts = po_n + 16;
-        po_items = po_counts + (size_t)n_str * 8;
+        po_counts = po_row + (((size_t)(n_str + 1) * 8 + 15) & ~(size_t)15);
+        po_items = po_counts + (((size_t)n_str * elt + 15) & ~(size_t)15);
         po_feat = po_items + (size_t)total * item_bytes;      // at most one item per char
         if ((rc = g.pin.ensure(po_feat + (feats ? (size_t)total * LATOK_FEATURE_COUNT : 0) + 64))) return rc;
         memcpy(g.pin.h, cps, (size_t)total * 4);
@@ -694,12 +740,12 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     } else if (!dev && !utf8) {
         if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
         if ((rc = g.h_row.ensure((size_t)(n_str + 1) * 8))) return rc;
-        if (total > 0) HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)total * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(g.h_row.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
         d_cps = (const uint32_t*)g.h_cps.p;
         d_row = (const int64_t*)g.h_row.p;
     }
-    // word-parallel compaction (compact_kernels.hip): items per 64-bit word -> device scan -> per-string counts and scatter
+    // word-parallel compaction (compact_kernels.hip)
     const int64_t words = (total + 63) / 64;
     if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
     if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
@@ -708,80 +754,79 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     if ((rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
     if ((rc = g.bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
     if ((rc = g.wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
-    if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
-    if ((rc = g.scan_tot.ensure((size_t)latok::scan_blocks(c_tiles) * 8))) return rc;
+    if (!dev && !small && (rc = g.counts.ensure((size_t)n_str * 8))) return rc;
+    if ((rc = g.pin_tot.ensure(64))) return rc;
+    unsigned epoch = 0;
+    if ((rc = next_scan_epoch(g, latok::count_blocks(words), st, &epoch))) return rc;
     uint64_t* d_bits = (uint64_t*)g.bits.p;
     uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
     uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
     const uint64_t* d_item_mask = spans ? d_kept : d_bits;
     int64_t* d_rank = (int64_t*)g.bases.p;
+    int64_t* d_tcnt = (int64_t*)g.wcnt.p;
+    uint16_t* d_pref = (uint16_t*)g.wpref.p;
     if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
     int64_t* d_tile_first = (int64_t*)g.tile_first.p;
     if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
                            nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind)))
         return rc;
-    const int64_t* d_tcnt = (const int64_t*)g.wcnt.p;
-    const uint16_t* d_pref = (const uint16_t*)g.wpref.p;
-    HIP_TRY(latok::launch_word_counts(spans, d_bits, d_space, words, total, d_kept, (int64_t*)g.wcnt.p, (uint16_t*)g.wpref.p, st));
-    int64_t* d_total = small ? (int64_t*)((char*)g.pin.d + po_n) : (int64_t*)g.scalar.p;
-    if ((rc = g.pin_tot.ensure(64))) return rc;
-    HIP_TRY(latok::launch_exclusive_scan((const int64_t*)g.wcnt.p, c_tiles, d_rank, d_total, (int64_t*)g.scan_tot.p, st,
-                                         small ? nullptr : (int64_t*)g.pin_tot.d));
-    int64_t* d_counts = dev ? counts_out : (small ? (int64_t*)((char*)g.pin.d + po_counts) : (int64_t*)g.counts.p);
-    HIP_TRY(latok::launch_string_counts(d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, st));
-    if (small) {
-        // the scatter cannot overrun: the pinned item area holds one item per char, the most there can be
-        int64_t* d_items = (int64_t*)((char*)g.pin.d + po_items);
-        int8_t* d_feat = (int8_t*)((char*)g.pin.d + po_feat);
+    // pinned, device-mapped words the kernels drop their results into: [0] item total, [1] int32-overflow flag
+    volatile int64_t* h_tot = (volatile int64_t*)g.pin_tot.h;
+    int64_t* p_tot = (int64_t*)g.pin_tot.d;
+    h_tot[1] = 0;
+    int64_t* d_total = (int64_t*)g.scalar.p;
+    int* d_err = (int*)(p_tot + 1);
+    HIP_TRY(latok::launch_word_counts_scan(spans, d_bits, d_space, words, total, d_kept, d_tcnt, d_pref, d_rank,
+                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, st));
+    auto enqueue_records = [&](void* d_counts, void* d_items, int8_t* d_feat, int64_t cap) -> int {
         if (feats) {   // spans and sums come from one kernel
-            if ((rc = enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
-                                       d_items, d_feat, st)))
-                return rc;
-        } else {
-            HIP_TRY(latok::launch_word_scatter(spans ? 1 : 0, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
-                                               d_row, n_str, d_tile_first, d_items, st));
+            HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
+            return enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
+                                    d_items, d_feat, o32, d_total, cap, st);
         }
+        HIP_TRY(latok::launch_counts_scatter(spans ? 1 : 0, o32, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
+                                             d_row, n_str, d_tile_first, d_items, d_total, cap, d_counts, d_err, st));
+        return LATOK_OK;
+    };
+    if (dev || small) {
+        // one synchronisation: records are written only if they fit (the kernel checks the total against the capacity)
+        void* d_counts = dev ? counts_out : (void*)((char*)g.pin.d + po_counts);
+        void* d_items = dev ? items_out : (void*)((char*)g.pin.d + po_items);
+        int8_t* d_feat = dev ? features_out : (int8_t*)((char*)g.pin.d + po_feat);
+        const int64_t cap = dev ? (items_out ? items_cap : 0) : total;   // the pinned item area holds one item per char
+        if ((rc = enqueue_records(d_counts, d_items, d_feat, cap))) return rc;
         HIP_TRY(hipStreamSynchronize(st));
-        const int64_t n_small = *(const int64_t*)((char*)g.pin.h + po_n);
-        *n_items_out = n_small;
-        memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * 8);
-        if (n_small > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_small);
-        if (n_small == 0) return LATOK_OK;
+        const int64_t n_items = h_tot[0];
+        *n_items_out = n_items;
+        if (h_tot[1]) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
+        if (small) memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * elt);
+        if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
+        if (n_items == 0) return LATOK_OK;
         if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
-        memcpy(items_out, (char*)g.pin.h + po_items, (size_t)n_small * item_bytes);
-        if (feats) memcpy(features_out, (char*)g.pin.h + po_feat, (size_t)n_small * LATOK_FEATURE_COUNT);
+        if (small) {
+            memcpy(items_out, (char*)g.pin.h + po_items, (size_t)n_items * item_bytes);
+            if (feats) memcpy(features_out, (char*)g.pin.h + po_feat, (size_t)n_items * LATOK_FEATURE_COUNT);
+        }
         return LATOK_OK;
     }
+    // host pointers, large batch: the total sizes the device staging buffers
     HIP_TRY(hipStreamSynchronize(st));
-    const int64_t n_items = *(volatile const int64_t*)g.pin_tot.h;
+    const int64_t n_items = h_tot[0];
     *n_items_out = n_items;
-    if (!dev) HIP_TRY(hipMemcpy(counts_out, g.counts.p, (size_t)n_str * 8, hipMemcpyDeviceToHost));
-    if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
-    if (n_items == 0) return LATOK_OK;
-    if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
-    int64_t* d_items = items_out;
-    int8_t* d_feat = features_out;
-    if (!dev) {
+    const bool fits = n_items <= items_cap && (n_items == 0 || items_out);
+    if (fits && n_items > 0) {
         if ((rc = g.h_out.ensure((size_t)n_items * item_bytes))) return rc;
-        d_items = (int64_t*)g.h_out.p;
-        if (feats) {
-            if ((rc = g.h_aux.ensure((size_t)n_items * LATOK_FEATURE_COUNT))) return rc;
-            d_feat = (int8_t*)g.h_aux.p;
-        }
+        if (feats && (rc = g.h_aux.ensure((size_t)n_items * LATOK_FEATURE_COUNT))) return rc;
     }
-    if (feats) {   // spans and sums come from one kernel
-        if ((rc = enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
-                                   d_feat, st)))
-            return rc;
-    } else {
-        HIP_TRY(latok::launch_word_scatter(spans ? 1 : 0, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total, d_row,
-                                           n_str, d_tile_first, d_items, st));
-    }
-    if (!dev) {
-        HIP_TRY(hipMemcpyAsync(items_out, d_items, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
-        if (feats) HIP_TRY(hipMemcpyAsync(features_out, d_feat, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
+    if ((rc = enqueue_records(g.counts.p, fits && n_items > 0 ? g.h_out.p : nullptr, (int8_t*)g.h_aux.p, fits ? n_items : 0))) return rc;
+    HIP_TRY(hipMemcpyAsync(counts_out, g.counts.p, (size_t)n_str * elt, hipMemcpyDeviceToHost, st));
+    if (fits && n_items > 0) {
+        HIP_TRY(hipMemcpyAsync(items_out, g.h_out.p, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
+        if (feats) HIP_TRY(hipMemcpyAsync(features_out, g.h_aux.p, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
+    if (n_items > 0 && !items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
     return LATOK_OK;
 }
 
@@ -1243,6 +1288,14 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
     HIP_TRY(hipMemcpyAsync(&t, g.scalar.p, 8, hipMemcpyDeviceToHost, g.stream));
     HIP_TRY(hipStreamSynchronize(g.stream));
     *bytes_out = (int64_t)t;
+    return LATOK_OK;
+}
+
+/* test hook (not part of the ABI in include/latok_hip.h): set the scan epoch of the current context, so that the wrap of
+ * the 18-bit epoch of k_word_counts_scan's state can be exercised without 262 144 calls */
+int latok_debug_set_scan_epoch(unsigned epoch) {
+    LATOK_ENTER();
+    g.scan_epoch = epoch & 0x3FFFFu;
     return LATOK_OK;
 }
 

@@ -7,12 +7,15 @@
 //
 // Inputs are the two bitmasks the tile kernel writes (boundary bits, SPACE bits; bit i = packed char i) and row_off.
 // Because strings are contiguous and ordered in the packed buffer, "all offsets of string 0, then string 1, ..." is
-// simply position order, so the output index of an item is the global rank of its bit:
-//   pass 1  one thread per 64-bit word: how many items start in the word (-> device-wide exclusive scan = word ranks)
-//   pass 2  one thread per string: count = rank(end) - rank(start), O(1)
-//   pass 3  one thread per word: scatter its items at word rank + position inside the word
+// simply position order, so the output index of an item is the global rank of its bit.  Three launches:
+//   k_word_counts        one wave per 4096-char tile: items per word (uint16 prefix inside the tile), items per tile
+//   k_scan_chained       exclusive scan of the tile counts over the whole batch in one launch (single-pass chained scan
+//                        with look-back over workgroup totals): every tile's rank and, for the host, the item total
+//   k_counts_scatter     workgroups split into two roles: one thread per string: count = rank(end) - rank(start), O(1);
+//                        one wave per tile: scatter its items at tile rank + position inside the tile
 // A token is kept iff it contains a non-SPACE char; its extent needs the next boundary bit, which normally sits in the
-// same or the next word (a thread follows the mask forward only for its own items).
+// same or the next word (a lane follows the mask forward only for its own items).  Counts and records are written as
+// int64 or, on request (LATOK_OUT_INT32), as int32: the records are most of the traffic of these paths.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,8 +44,8 @@ __device__ __forceinline__ bool tail_has_nonspace(const uint64_t* __restrict__ b
     return false;
 }
 
-// One wave per 4096-char tile, lane = word: the tile's item count (-> a scan over TILES, 64x fewer elements than
-// words) and every word's exclusive prefix inside its tile (uint16).  rank(word) = tile_rank[tile] + word_pref[word].
+// One wave per 4096-char tile, lane = word: the tile's item count and every word's exclusive prefix inside its tile
+// (uint16); rank(word) = tile_rank[tile] + word_pref[word], tile_rank = exclusive scan of the tile counts (k_scan_chained).
 template <bool SPANS>
 __global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
                                                      int64_t n_words, int64_t total, uint64_t* __restrict__ kept_out,
@@ -89,6 +92,98 @@ __global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict_
     if (lane == 63) tile_cnt[t] = inc;
 }
 
+// Exclusive scan of the tile counts over the whole batch in ONE launch (it used to be three: local scans, scan of the
+// block totals, fix-up): single-pass chained scan.  A workgroup takes a ticket -- its position in the scan order is the
+// order in which workgroups START, so a workgroup only ever waits for workgroups that are already running --, scans its
+// chunk of 4096 counts, publishes the chunk total, and looks back over its predecessors' published words, 64 at a time
+// (one per lane), summing totals until it meets a predecessor that already knows its inclusive prefix.  The words carry
+// the launch's epoch, so nothing has to be cleared between launches (api.cpp: next_scan_epoch).
+constexpr int kChainBlock = 1024, kChainItems = 4, kChainChunk = kChainBlock * kChainItems;
+constexpr int kChainValueBits = 44, kChainFlagShift = 44, kChainEpochShift = 46;
+constexpr unsigned long long kChainValueMask = (1ull << kChainValueBits) - 1ull;
+constexpr unsigned kChainAggregate = 1u, kChainPrefix = 2u;
+
+__device__ __forceinline__ void chain_publish(unsigned long long* slot, unsigned epoch, unsigned flag, long long value) {
+    const unsigned long long w = ((unsigned long long)epoch << kChainEpochShift) | ((unsigned long long)flag << kChainFlagShift) |
+                                 ((unsigned long long)value & kChainValueMask);
+    // relaxed, agent scope: the word IS the message (value + flag + epoch in one 64-bit store), nothing else has to be
+    // visible with it -- a release here writes back the whole L2 of the XCD for every workgroup (measured: 10x slower)
+    __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kChainBlock) void k_scan_chained(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
+                                                              unsigned long long* __restrict__ chain, unsigned* __restrict__ ticket,
+                                                              unsigned epoch, unsigned n_blocks, int64_t* __restrict__ total_out,
+                                                              int64_t* __restrict__ total_host) {
+    __shared__ unsigned s_ticket;
+    __shared__ long long s_wave_tot[kChainBlock / 64];
+    __shared__ long long s_prefix;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const unsigned b = s_ticket;
+    const int64_t base = (int64_t)b * kChainChunk + (int64_t)threadIdx.x * kChainItems;
+    long long v[kChainItems], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kChainItems; ++j) {
+        v[j] = base + j < n ? in[base + j] : 0;
+        sum += v[j];
+    }
+    long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave_tot[wave] = inc;
+    __syncthreads();
+    long long wave_excl = 0, agg = 0;
+#pragma unroll
+    for (int k = 0; k < kChainBlock / 64; ++k) {
+        const long long x = s_wave_tot[k];
+        if (k < wave) wave_excl += x;
+        agg += x;
+    }
+    if (wave == 0) {
+        if (lane == 0) chain_publish(&chain[b], epoch, b == 0 ? kChainPrefix : kChainAggregate, agg);
+        long long prefix = 0;
+        for (long long j0 = (long long)b - 1; j0 >= 0; j0 -= 64) {   // wave-uniform
+            const long long j = j0 - lane;
+            unsigned long long sv = 0;
+            if (j >= 0) {
+                do {
+                    sv = __hip_atomic_load(&chain[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((unsigned)(sv >> kChainEpochShift) != epoch || ((sv >> kChainFlagShift) & 3ull) == 0ull);
+            }
+            const bool is_prefix = j < 0 || ((sv >> kChainFlagShift) & 3ull) == kChainPrefix;   // before workgroup 0: prefix 0
+            const long long val = j >= 0 ? (long long)(sv & kChainValueMask) : 0;
+            const unsigned long long pm = __ballot(is_prefix);
+            const int first = pm ? __builtin_ctzll(pm) : 64;      // the nearest predecessor that knows its inclusive prefix
+            long long part = lane <= first ? val : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            prefix += part;
+            if (pm) break;
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            if (b > 0) chain_publish(&chain[b], epoch, kChainPrefix, prefix + agg);
+            if (b == n_blocks - 1) {          // the last ticket: every workgroup has taken its own by now
+                *total_out = prefix + agg;
+                if (total_host) *total_host = prefix + agg;   // pinned, device-mapped: read by the host after the stream drains
+                *ticket = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    long long run = s_prefix + wave_excl + inc - sum;
+#pragma unroll
+    for (int j = 0; j < kChainItems; ++j) {
+        if (base + j < n) out[base + j] = run;
+        run += v[j];
+    }
+}
+
 // ---- pass 2: items per string = rank(row_off[s+1]) - rank(row_off[s]) ------------------------------------------------
 __device__ __forceinline__ int64_t rank_at(const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
                                            const uint16_t* __restrict__ word_pref, int64_t x, int64_t total, int64_t n_items) {
@@ -96,14 +191,25 @@ __device__ __forceinline__ int64_t rank_at(const uint64_t* __restrict__ mask, co
     const int64_t w = x >> 6;
     return tile_rank[w >> 6] + word_pref[w] + __popcll(mask[w] & low_mask((int)(x & 63)));
 }
-__global__ void k_string_counts(const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
-                                const uint16_t* __restrict__ word_pref, const int64_t* __restrict__ row_off, int64_t n_str,
-                                int64_t total, const int64_t* __restrict__ n_items, int64_t* __restrict__ counts) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// OUT = int64_t or int32_t.  A string of 2^31 chars or more cannot be reported in int32: *err is raised (the host turns
+// it into LATOK_ERR_INVALID).
+template <typename OUT>
+__device__ __forceinline__ void string_counts_role(int64_t s, const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
+                                                   const uint16_t* __restrict__ word_pref, const int64_t* __restrict__ row_off,
+                                                   int64_t n_str, int64_t total, int64_t n, OUT* __restrict__ counts,
+                                                   int* __restrict__ err) {
     if (s >= n_str) return;
-    const int64_t n = *n_items;
-    counts[s] = rank_at(mask, tile_rank, word_pref, row_off[s + 1], total, n) -
-                rank_at(mask, tile_rank, word_pref, row_off[s], total, n);
+    const int64_t r0 = row_off[s], r1 = row_off[s + 1];
+    if (sizeof(OUT) == 4 && r1 - r0 > 0x7FFFFFFFll) *err = 1;   // (plain store: the flag may live in pinned host memory)
+    counts[s] = (OUT)(rank_at(mask, tile_rank, word_pref, r1, total, n) - rank_at(mask, tile_rank, word_pref, r0, total, n));
+}
+template <typename OUT>
+__global__ __launch_bounds__(256) void k_string_counts(const uint64_t* __restrict__ mask, const int64_t* __restrict__ tile_rank,
+                                                       const uint16_t* __restrict__ word_pref, const int64_t* __restrict__ row_off,
+                                                       int64_t n_str, int64_t total, const int64_t* __restrict__ n_items,
+                                                       OUT* __restrict__ counts, int* __restrict__ err) {
+    string_counts_role<OUT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, mask, tile_rank, word_pref, row_off, n_str, total, *n_items,
+                            counts, err);
 }
 
 // ---- pass 3 --------------------------------------------------------------------------------------------------------
@@ -139,15 +245,26 @@ __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict
     return lo;
 }
 
-template <int KIND>
-__global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
+template <int KIND, typename OUT>
+__global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
     const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
-    const int64_t* __restrict__ tile_first, int64_t* __restrict__ out) {
+    const int64_t* __restrict__ tile_first, OUT* __restrict__ out, const int64_t* __restrict__ n_items_dev, int64_t cap,
+    OUT* __restrict__ counts, unsigned n_scatter_blocks, int* __restrict__ err) {
+    static_assert(scatter_waves(KIND) * 64 == 256, "both roles use 256-thread workgroups");
+    if (blockIdx.x >= n_scatter_blocks) {   // role 2: one thread per string
+        if (counts)
+            string_counts_role<OUT>((int64_t)(blockIdx.x - n_scatter_blocks) * 256 + threadIdx.x, item_mask, tile_rank, word_pref,
+                                    row_off, n_str, total, *n_items_dev, counts, err);
+        return;
+    }
+    // role 1: one wave per tile.  The caller's buffer holds `cap` items; when the batch has more, nothing is written
+    // (the host reports the needed size) -- the launch does not have to wait for the host to learn the total.
+    if (*n_items_dev > cap) return;
     constexpr int kScatterWaves = scatter_waves(KIND);
     constexpr int kCodes = 1024;                                    // items per round
-    __shared__ int64_t buf_s[kScatterWaves][kCodes];                // KIND 0: window of values; KIND 1: the item codes
+    __shared__ int64_t buf_s[kScatterWaves][kCodes];                // KIND 0: window of values (OUT); KIND 1: the item codes
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
@@ -159,7 +276,7 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
     const int off = w < n_words ? (int)word_pref[w] : 0;            // rank of my first item inside the wave
     const int64_t base_out = tile_rank[w0 >> 6];
     uint16_t* codes = reinterpret_cast<uint16_t*>(buf_s[wave]);
-    int64_t* win = buf_s[wave];
+    OUT* win = reinterpret_cast<OUT*>(buf_s[wave]);
     long long* smax = smax_s[wave];
 
     // (a) where the string that owns a position begins: string-start bits of the tile in LDS (one atomicOr per string
@@ -224,25 +341,27 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
                 const int b = __builtin_ctzll(rest);
                 rest &= rest - 1;
                 const uint64_t bl = Bw & ((2ull << b) - 1ull);
-                win[k - win0] = base + b - (bl ? base + 63 - __builtin_clzll(bl) : lo_in);
+                win[k - win0] = (OUT)(base + b - (bl ? base + 63 - __builtin_clzll(bl) : lo_in));
                 ++k;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // stream the window out: single elements up to the first 16-byte boundary of the output, then 16-byte stores
             const int n_val = min(kCodes, n_wave - win0);
-            int64_t* dst = out + base_out + win0;
-            typedef long long ll2 __attribute__((ext_vector_type(2)));
-            const int head = (((uintptr_t)dst >> 3) & 1) ? 1 : 0;   // odd 8-byte slot: one scalar first
-            if (head && lane == 0) __builtin_nontemporal_store((long long)win[0], (long long*)dst);
-            const int n_pair = (n_val - head) >> 1;
-            for (int i = lane; i < n_pair; i += 64) {
-                ll2 v;
-                v.x = win[head + 2 * i];
-                v.y = win[head + 2 * i + 1];
-                __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(dst + head) + i);
+            OUT* dst = out + base_out + win0;
+            constexpr int kPer = 16 / (int)sizeof(OUT);                   // elements per 16-byte store
+            const int head = min(n_val, (int)(((16u - ((uintptr_t)dst & 15u)) & 15u) / sizeof(OUT)));
+            if (lane < head) __builtin_nontemporal_store(win[lane], dst + lane);
+            const int n_vec = (n_val - head) / kPer;
+            typedef OUT vec_t __attribute__((ext_vector_type(16 / sizeof(OUT))));
+            for (int i = lane; i < n_vec; i += 64) {
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < kPer; ++e) v[e] = win[head + kPer * i + e];
+                __builtin_nontemporal_store(v, reinterpret_cast<vec_t*>(dst + head) + i);
             }
-            if (((n_val - head) & 1) && lane == 0)
-                __builtin_nontemporal_store((long long)win[n_val - 1], (long long*)dst + n_val - 1);
+            const int tail0 = head + kPer * n_vec;
+            if (lane < n_val - tail0) __builtin_nontemporal_store(win[tail0 + lane], dst + tail0 + lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -297,11 +416,11 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
                         a2 = seg ? obase + __builtin_ctzll(seg) : next_zero_bit(space, obase + 64, e);
                         e2 = prev_zero_end(space, a2, e);
                     }
-                    typedef long long ll2 __attribute__((ext_vector_type(2)));
-                    ll2 v;
-                    v.x = a2 - lo;
-                    v.y = e2 - lo;
-                    __builtin_nontemporal_store(v, reinterpret_cast<ll2*>(out) + base_out + win0 + j);
+                    typedef OUT out2 __attribute__((ext_vector_type(2)));
+                    out2 v;
+                    v.x = (OUT)(a2 - lo);
+                    v.y = (OUT)(e2 - lo);
+                    __builtin_nontemporal_store(v, reinterpret_cast<out2*>(out) + base_out + win0 + j);
                 }
             }
         }
@@ -311,38 +430,64 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_word_scatter(
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
-hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
-                              uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, hipStream_t st) {
+int64_t count_blocks(int64_t n_words) { return n_words > 0 ? ((n_words + 63) / 64 + kChainChunk - 1) / kChainChunk : 0; }
+
+hipError_t launch_word_counts_scan(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
+                                   uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, int64_t* tile_rank,
+                                   unsigned long long* chain, unsigned* ticket, unsigned epoch, int64_t* total_dev,
+                                   int64_t* total_host, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
     const int64_t n_tiles = (n_words + 63) / 64;
     const dim3 grid((unsigned)((n_tiles + 3) / 4)), block(256);
     if (spans) hipLaunchKernelGGL((k_word_counts<true>), grid, block, 0, st, bits, space, n_words, total, kept, tile_cnt, word_pref);
     else hipLaunchKernelGGL((k_word_counts<false>), grid, block, 0, st, bits, space, n_words, total, kept, tile_cnt, word_pref);
+    const unsigned n_blocks = (unsigned)count_blocks(n_words);
+    hipLaunchKernelGGL(k_scan_chained, dim3(n_blocks), dim3(kChainBlock), 0, st, tile_cnt, n_tiles, tile_rank, chain, ticket, epoch,
+                       n_blocks, total_dev, total_host);
     return hipGetLastError();
 }
 
-hipError_t launch_string_counts(const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref, const int64_t* row_off,
-                                int64_t n_str, int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st) {
+hipError_t launch_string_counts(bool out32, const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref,
+                                const int64_t* row_off, int64_t n_str, int64_t total, const int64_t* n_items, void* counts, int* err,
+                                hipStream_t st) {
     if (n_str <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_string_counts, dim3((unsigned)((n_str + 255) / 256)), dim3(256), 0, st, mask, tile_rank, word_pref,
-                       row_off, n_str, total, n_items, counts);
+    const dim3 grid((unsigned)((n_str + 255) / 256)), block(256);
+    if (out32)
+        hipLaunchKernelGGL((k_string_counts<int32_t>), grid, block, 0, st, mask, tile_rank, word_pref, row_off, n_str, total, n_items,
+                           (int32_t*)counts, err);
+    else
+        hipLaunchKernelGGL((k_string_counts<int64_t>), grid, block, 0, st, mask, tile_rank, word_pref, row_off, n_str, total, n_items,
+                           (int64_t*)counts, err);
     return hipGetLastError();
 }
 
-hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
-                               const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
-                               int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, int64_t* out,
-                               hipStream_t st) {
-    if (n_words <= 0) return hipSuccess;
-    const int64_t per_block = (int64_t)scatter_waves(kind) * 64;
-    const dim3 grid((unsigned)((n_words + per_block - 1) / per_block)), block(scatter_waves(kind) * 64);
-    if (kind == 0)
-        hipLaunchKernelGGL((k_word_scatter<0>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
-                           total, row_off, n_str, tile_first, out);
-    else
-        hipLaunchKernelGGL((k_word_scatter<1>), grid, block, 0, st, bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words,
-                           total, row_off, n_str, tile_first, out);
+template <int KIND, typename OUT>
+static hipError_t launch_counts_scatter_t(const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
+                                          const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref,
+                                          int64_t n_words, int64_t total, const int64_t* row_off, int64_t n_str,
+                                          const int64_t* tile_first, void* out, const int64_t* n_items_dev, int64_t cap,
+                                          void* counts, int* err, hipStream_t st) {
+    const int64_t per_block = (int64_t)scatter_waves(KIND) * 64;
+    const unsigned nb_scatter = out ? (unsigned)((n_words + per_block - 1) / per_block) : 0u;
+    const unsigned nb_counts = counts ? (unsigned)((n_str + 255) / 256) : 0u;
+    if (nb_scatter + nb_counts == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_counts_scatter<KIND, OUT>), dim3(nb_scatter + nb_counts), dim3(scatter_waves(KIND) * 64), 0, st, bits, space,
+                       item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, n_str, tile_first, (OUT*)out, n_items_dev,
+                       cap, (OUT*)counts, nb_scatter, err);
     return hipGetLastError();
+}
+
+// counts (may be NULL: already written) and / or items (out may be NULL: counts only) in one launch
+hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
+                                 const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
+                                 int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
+                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st) {
+    if (n_words <= 0) return hipSuccess;
+#define LATOK_CS(K, T) launch_counts_scatter_t<K, T>(bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, \
+                                                     n_str, tile_first, out, n_items_dev, cap, counts, err, st)
+    if (kind == 0) return out32 ? LATOK_CS(0, int32_t) : LATOK_CS(0, int64_t);
+    return out32 ? LATOK_CS(1, int32_t) : LATOK_CS(1, int64_t);
+#undef LATOK_CS
 }
 
 }  // namespace latok

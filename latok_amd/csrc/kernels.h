@@ -83,7 +83,10 @@ struct FeatParams {
     const int64_t* tile_first;    // per tile: first string that starts at or after its first char
     const uint64_t* space;        // SPACE bitmask (only walked for tokens that span more than two words)
     int8_t* features;             // [n_tokens][25]
-    int64_t* spans4;              // [n_tokens][4] = {raw start, raw end, stripped start, stripped end}, string relative
+    void* spans4;                 // [n_tokens][4] = {raw start, raw end, stripped start, stripped end}, string relative; int64 or int32
+    bool out32;                   // spans4 holds int32
+    const int64_t* n_tokens_dev;  // device: total tokens of the batch (k_word_counts_scan) ...
+    int64_t cap;                  // ... nothing is written when it exceeds the caller's capacity
 };
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
 
@@ -102,14 +105,18 @@ int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_t
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
                                  hipStream_t st, int64_t* total_host = nullptr);
 // compact_kernels.hip: word-parallel compaction (offsets / token spans / featurize spans)
-hipError_t launch_word_counts(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
-                              uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, hipStream_t st);
-hipError_t launch_string_counts(const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref, const int64_t* row_off,
-                                int64_t n_str, int64_t total, const int64_t* n_items, int64_t* counts, hipStream_t st);
-hipError_t launch_word_scatter(int kind, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
-                               const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
-                               int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, int64_t* out,
-                               hipStream_t st);
+int64_t count_blocks(int64_t n_words);   // workgroups of launch_word_counts_scan = entries of its `chain` state
+hipError_t launch_word_counts_scan(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
+                                   uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, int64_t* tile_rank,
+                                   unsigned long long* chain, unsigned* ticket, unsigned epoch, int64_t* total_dev,
+                                   int64_t* total_host, hipStream_t st);
+hipError_t launch_string_counts(bool out32, const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref,
+                                const int64_t* row_off, int64_t n_str, int64_t total, const int64_t* n_items, void* counts, int* err,
+                                hipStream_t st);
+hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
+                                 const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
+                                 int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
+                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

@@ -1296,7 +1296,9 @@ static_assert(kFeatWinBytes >= kStageBytes, "the window doubles as the staging b
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
 static_assert(kFeatWinBytes % 16 == 0 && kFeatWaveLds % 16 == 0, "alignment");
 
+template <typename OUT>
 __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds& L, int64_t t, int lane) {
+    OUT* const spans4 = reinterpret_cast<OUT*>(P.spans4);   // int64 or int32 records (LATOK_OUT_INT32)
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
     const int64_t n_words = (total + 63) >> 6;
@@ -1570,13 +1572,13 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                         a2 = sg ? obase + lk_ctz(sg) : next_zero_bit(P.space, obase + 64, e);
                         e2 = prev_zero_end(P.space, a2, e);
                     }
-                    typedef long long ll2 __attribute__((ext_vector_type(2)));
-                    ll2* sp = reinterpret_cast<ll2*>(P.spans4 + (base_out + win0 + j) * 4);
-                    ll2 v0, v1;
-                    v0.x = p - lo;
-                    v0.y = e - lo;
-                    v1.x = a2 - lo;
-                    v1.y = e2 - lo;
+                    typedef OUT out2 __attribute__((ext_vector_type(2)));
+                    out2* sp = reinterpret_cast<out2*>(spans4 + (base_out + win0 + j) * 4);
+                    out2 v0, v1;
+                    v0.x = (OUT)(p - lo);
+                    v0.y = (OUT)(e - lo);
+                    v1.x = (OUT)(a2 - lo);
+                    v1.y = (OUT)(e2 - lo);
                     __builtin_nontemporal_store(v0, sp);
                     __builtin_nontemporal_store(v1, sp + 1);
                 }
@@ -1641,7 +1643,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 
     // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
-    int64_t* swin = reinterpret_cast<int64_t*>(L.stage);
+    OUT* swin = reinterpret_cast<OUT*>(L.stage);
     rest = x;
     k = off;
     for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
@@ -1672,22 +1674,24 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                 a2 = seg ? base + lk_ctz(seg) : next_zero_bit(P.space, base + 64, e);
                 e2 = prev_zero_end(P.space, a2, e);
             }
-            int64_t* rec = swin + (k - win0) * 4;
-            rec[0] = p - lo;
-            rec[1] = e - lo;
-            rec[2] = a2 - lo;
-            rec[3] = e2 - lo;
+            OUT* rec = swin + (k - win0) * 4;
+            rec[0] = (OUT)(p - lo);
+            rec[1] = (OUT)(e - lo);
+            rec[2] = (OUT)(a2 - lo);
+            rec[3] = (OUT)(e2 - lo);
             ++k;
         }
         wave_lds_sync();
         {
-            typedef long long ll2 __attribute__((ext_vector_type(2)));
-            const int n_pair = min(kFeatRound, n_wave - win0) * 2;
-            ll2* dst = reinterpret_cast<ll2*>(P.spans4 + (base_out + win0) * 4);
-            for (int i = lane; i < n_pair; i += 64) {
-                ll2 v;
-                v.x = swin[2 * i];
-                v.y = swin[2 * i + 1];
+            // 16-byte stores: two (int64) or four (int32) values each; a record is 32 or 16 bytes, so the stream is aligned
+            constexpr int kPer = 16 / (int)sizeof(OUT);
+            typedef OUT vec_t __attribute__((ext_vector_type(16 / sizeof(OUT))));
+            const int n_vec = min(kFeatRound, n_wave - win0) * 4 / kPer;
+            vec_t* dst = reinterpret_cast<vec_t*>(spans4 + (base_out + win0) * 4);
+            for (int i = lane; i < n_vec; i += 64) {
+                vec_t v;
+#pragma unroll
+                for (int e = 0; e < kPer; ++e) v[e] = swin[kPer * i + e];
                 __builtin_nontemporal_store(v, dst + i);
             }
         }
@@ -1695,7 +1699,9 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     }
 }
 
+template <typename OUT>
 __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P) {
+    if (P.n_tokens_dev && *P.n_tokens_dev > P.cap) return;   // the caller's buffers are too small: nothing is written
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFeatLdsTotal];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1715,14 +1721,15 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     L.halo = mine + kFeatWinBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kFeatWinBytes + 16);
     for (int64_t t = (int64_t)blockIdx.x * kFeatWaves + wave; t < P.n_tiles; t += (int64_t)gridDim.x * kFeatWaves)
-        feature_tile(P, L, t, lane);
+        feature_tile<OUT>(P, L, t, lane);
 }
 
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st) {
     if (P.n_tiles <= 0) return hipSuccess;
     int64_t blocks = (P.n_tiles + kFeatWaves - 1) / kFeatWaves;
     if (blocks > n_cu) blocks = n_cu;
-    hipLaunchKernelGGL(k_features_tiles, dim3((unsigned)blocks), dim3(kFeatWaves * 64), 0, st, P);
+    if (P.out32) hipLaunchKernelGGL((k_features_tiles<int32_t>), dim3((unsigned)blocks), dim3(kFeatWaves * 64), 0, st, P);
+    else hipLaunchKernelGGL((k_features_tiles<int64_t>), dim3((unsigned)blocks), dim3(kFeatWaves * 64), 0, st, P);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
   utf8_spans      latok_token_spans_utf8_batch
   bytes_mask / bytes_offsets / bytes_spans   latok_*_utf8_bytes_batch (8f-3 fused: the tile kernel reads the bytes)
   rules_mask      latok_split_mask_batch after latok_set_rules(built-in tables)   (8f-4)
+  offsets32 / spans32 / features32 / kind_offsets32 / kind_spans32   the same entry points with LATOK_OUT_INT32 records
   kind_mask / kind_offsets / kind_spans      latok_*_kind_batch on PEP 393 code units: kind 1 (uint8) when every char
                   of the corpus is <= U+00FF (C2), else kind 2 (uint16) with the corpus' astral chars folded into the BMP
                   (cp & 0xFFFF; timing only -- C3 as CPython would store it without its emoji)
@@ -60,8 +61,9 @@ def main():
     ap.add_argument("--strings", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
-    ap.add_argument("--paths", default="mask,offsets,spans,features,utf8_mask,utf8_offsets,utf8_spans,"
-                                       "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_spans")
+    ap.add_argument("--paths", default="mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
+                                       "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,"
+                                       "kind_spans,kind_spans32")
     args = ap.parse_args()
     lib = _lib.ensure_init()
     model, seed, lo, hi = WORKLOADS[args.workload]
@@ -119,6 +121,17 @@ def main():
     if "spans" in paths:
         run("spans", lambda: lib.latok_token_spans_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
             lambda: 4 * total + csr + 8 * n + 16 * nout.value, "4 B/char + 8 B/string read; 8 B/string counts + 16 B/token written")
+    D32 = D | _lib.OUT_INT32
+    if "offsets32" in paths:
+        run("offsets32", lambda: lib.latok_split_offsets_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D32, None),
+            lambda: 4 * total + csr + 4 * n + 4 * nout.value, "4 B/char + 8 B/string read; 4 B/string counts + 4 B/boundary written (LATOK_OUT_INT32)")
+    if "spans32" in paths:
+        run("spans32", lambda: lib.latok_token_spans_batch(d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D32, None),
+            lambda: 4 * total + csr + 4 * n + 8 * nout.value, "4 B/char + 8 B/string read; 4 B/string counts + 8 B/token written (LATOK_OUT_INT32)")
+    if "features32" in paths:
+        run("features32", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D32, None),
+            lambda: 2 * 4 * total + csr + 4 * n + (16 + 25) * nout.value,
+            "4 B/char read twice + 8 B/string; 4 B/string + 41 B/token written (LATOK_OUT_INT32)")
     if "features" in paths:
         run("features", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D, None),
             lambda: 2 * 4 * total + csr + 8 * n + (32 + 25) * nout.value,
@@ -170,6 +183,12 @@ def main():
         if "kind_offsets" in paths:
             run("kind_offsets", lambda: lib.latok_split_offsets_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
                 lambda: kind * total + csr + 8 * n + 8 * nout.value, note + "; 8 B/string counts + 8 B/boundary written")
+        if "kind_offsets32" in paths:
+            run("kind_offsets32", lambda: lib.latok_split_offsets_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D32, None),
+                lambda: kind * total + csr + 4 * n + 4 * nout.value, note + "; 4 B/string counts + 4 B/boundary written (LATOK_OUT_INT32)")
+        if "kind_spans32" in paths:
+            run("kind_spans32", lambda: lib.latok_token_spans_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D32, None),
+                lambda: kind * total + csr + 4 * n + 8 * nout.value, note + "; 4 B/string counts + 8 B/token written (LATOK_OUT_INT32)")
         if "kind_spans" in paths:
             run("kind_spans", lambda: lib.latok_token_spans_kind_batch(d_units, kind, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D, None),
                 lambda: kind * total + csr + 8 * n + 16 * nout.value, note + "; 8 B/string counts + 16 B/token written")

@@ -118,6 +118,7 @@ struct Ctx {
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, wpref, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
+    DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
     DevBuf chain, chain_ctl;   // k_word_counts_scan: look-back state per workgroup, {ticket counter}
     unsigned scan_epoch = 0;
     bool chain_ready = false;
@@ -188,7 +189,8 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
-                 const uint8_t* d_u8 = nullptr, int unit_kind = 0, int stages = 7) {   // stages: 1 = tile index, 2 = tiles, 4 = resolve
+                 const uint8_t* d_u8 = nullptr, int unit_kind = 0, int stages = 7,   // stages: 1 = tile index, 2 = tiles, 4 = resolve
+                 uint8_t* d_codes = nullptr) {   // d_codes: also leave the rule code of every char (featurize)
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
@@ -215,7 +217,10 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
     if ((size_t)P.n_segs * (sizeof(latok::Fn64) + sizeof(latok::Hd64)) > g.seg_agg.cap || (size_t)n_tiles * 16 > g.summ.cap)
         return fail(LATOK_ERR_INVALID, "internal: workspace too small for %lld segments / %lld tiles", (long long)P.n_segs, (long long)n_tiles);
-    const uint8_t* tables = (const uint8_t*)(mode == latok::kModeRules ? g.t1rule.p : g.t1.p);
+    if (d_codes && mode != latok::kModeBits && mode != latok::kModeRules)
+        return fail(LATOK_ERR_INVALID, "internal: code bytes are written by the UTF-32 bitmask modes only");
+    // rule codes (split code + NUM) when the rules are interpreted at run time or the code bytes are kept for featurize
+    const uint8_t* tables = (const uint8_t*)((mode == latok::kModeRules || d_codes) ? g.t1rule.p : g.t1.p);
     P.t1 = tables;
     P.t2 = tables + latok::kStage1Pad;
     if (mode == latok::kModeRules) P.rules = g.rules;
@@ -223,6 +228,7 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
+    P.codes_out = d_codes;
     if (!d_tile_first) d_tile_first = (int64_t*)g.tile_first.p;   // the per-tile string index lives in the workspace
     P.tile_first = d_tile_first;
     P.summ = (int4*)g.summ.p;
@@ -331,7 +337,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
                       &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
-                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl})
+                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl, &g.codes})
         b->release();
     for (auto& e : g.ev) {
         if (e) (void)hipEventDestroy(e);
@@ -594,17 +600,16 @@ static int decode_utf8_to_workspace(Ctx& g, const uint8_t* u8, const int64_t* by
 }
 
 // featurize: per-token column sums on the tile grid (split_kernels.hip: k_features_tiles)
-static int enqueue_features(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
+static int enqueue_features(Ctx& g, const uint8_t* d_codes, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
                             const uint64_t* d_space, const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt,
                             const uint16_t* d_pref, const int64_t* d_tile_first, void* d_spans4, int8_t* d_feat, bool out32,
                             const int64_t* d_n_tokens, int64_t cap, hipStream_t st) {
     latok::FeatParams F;
-    F.cps = d_cps;
+    F.codes = d_codes;
     F.row_off = d_row;
     F.n_str = n_str;
     F.total = total;
     F.n_tiles = (total + latok::kTile - 1) / latok::kTile;
-    F.t1 = (const uint8_t*)g.t1rule.p;
     F.bits = d_bits;
     F.kept = d_kept;
     F.tile_rank = d_rank;
@@ -767,8 +772,15 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     uint16_t* d_pref = (uint16_t*)g.wpref.p;
     if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
     int64_t* d_tile_first = (int64_t*)g.tile_first.p;
+    uint8_t* d_codes = nullptr;
+    if (feats) {   // the tile kernel leaves the rule code of every char: 1 B/char for k_features_tiles instead of 4 B/char + tables
+        const size_t code_bytes = (size_t)total + latok::kTile + 256;   // read (never used) up to a tile behind the last char
+        if ((rc = g.codes.ensure(code_bytes))) return rc;
+        d_codes = (uint8_t*)g.codes.p;
+        HIP_TRY(hipMemsetAsync(d_codes + ((size_t)total & ~(size_t)(latok::kTile - 1)), 0, code_bytes - ((size_t)total & ~(size_t)(latok::kTile - 1)), st));
+    }
     if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind)))
+                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes)))
         return rc;
     // pinned, device-mapped words the kernels drop their results into: [0] item total, [1] int32-overflow flag
     volatile int64_t* h_tot = (volatile int64_t*)g.pin_tot.h;
@@ -781,7 +793,7 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     auto enqueue_records = [&](void* d_counts, void* d_items, int8_t* d_feat, int64_t cap) -> int {
         if (feats) {   // spans and sums come from one kernel
             HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
-            return enqueue_features(g, d_cps, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
+            return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
                                     d_items, d_feat, o32, d_total, cap, st);
         }
         HIP_TRY(latok::launch_counts_scatter(spans ? 1 : 0, o32, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,

@@ -55,6 +55,8 @@ struct SplitParams {
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
     uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
+    uint8_t* codes_out;         // optional (kModeBits / kModeRules on UTF-32 input, t2 = rule codes): the code byte of every char
+                                // (featurize: k_features_tiles reads 1 B/char instead of classifying 4 B/char again)
     int64_t* tile_first;        // [n_tiles]: first string that starts at or after each tile's first char (k_tile_index; also read by the compaction passes)
     int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
     Fn64* seg_fn;               // [n_segs] segment aggregates
@@ -71,10 +73,9 @@ struct SplitParams {
 
 // featurize on the tile grid (split_kernels.hip: k_features_tiles)
 struct FeatParams {
-    const uint32_t* cps;
+    const uint8_t* codes;         // rule code of every char (SplitParams::codes_out of the tile kernel), padded by one tile + 256 B
     const int64_t* row_off;
     int64_t n_str, total, n_tiles;
-    const uint8_t* t1;            // [stage-1 | stage-2 rule codes], contiguous (global memory)
     const uint64_t* bits;         // final boundary bitmask
     const uint64_t* kept;         // boundaries whose token is kept (k_word_counts<true>)
     const int64_t* tile_rank;     // index of a tile's first token (exclusive scan of the per-tile token counts)

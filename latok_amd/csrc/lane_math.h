@@ -132,7 +132,7 @@ LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
     f.AN = p[LK_BIT_ALNUM];
     f.A = p[5] & ~f.Y;              // bit5 = ALPHA when SYMBOL=0
     f.T = p[5] & f.Y & ~p[7];       // sub 1 (# $ ^) or 3 ('@')
-    f.AT = p[5] & p[6];             // sub 3
+    f.AT = p[5] & p[6] & f.Y;       // sub 3 (the & SYMBOL makes the decode valid for rule codes too: NUM sits in bit 6 of non-symbols)
     f.CO = p[7] & ~p[6] & ~p[5];    // sub 4
     f.SL = p[7] & p[5];             // sub 5
     f.PE = p[7] & p[6];             // sub 6
@@ -167,7 +167,7 @@ LATOK_HD lk_feat1 lk_decode1(uint32_t c) {
     f.L = (c >> 2) & 1u;
     f.AN = (c >> 4) & 1u;
     f.A = (c >> 5) & ~(c >> 1) & 1u;
-    f.AT = (c >> 5) & (c >> 6) & 1u;
+    f.AT = (c >> 5) & (c >> 6) & (c >> 1) & 1u;
     f.SL = (c >> 7) & (c >> 5) & 1u;
     return f;
 }

@@ -772,12 +772,16 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
         LATOK_STAMP(1);
+        uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
             *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+            if (codes) codes[64 * i] = c;                                     // 256 contiguous bytes per wave instruction
         }
     } else {
+        // the batch's last, partial tile (its code bytes are written up to the end of the tile: 0 behind the last char)
+        uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;
 #pragma unroll 1
         for (int i = 0; i < 16; ++i) {
             const int64_t p = t0 + 256 * i + 4 * lane;
@@ -788,6 +792,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
             v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
             const uint32_t c = classify4(L.t1, L.t2, v);
             *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+            if (codes) codes[64 * i] = c;
         }
     }
     // halo chars t0-1, t0+4096, t0+4097 (lanes 0..2) and the string-start words
@@ -1287,14 +1292,54 @@ __device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint3
 // to global memory costs +0.4 ms in scattered stores.  So this kernel trades waves for LDS: kFeatWaves waves per CU,
 // each with a window for kFeatRound tokens (a 4096-char tile of word-soup text has ~830), which doubles as the
 // code-byte staging buffer before the planes are built.
-constexpr int kFeatWaves = 4;
+constexpr int kFeatWaves = 6;
 constexpr int kFeatRound = 896;                                       // tokens per round
-constexpr int kFeatWinBytes = kFeatRound * 32;                        // holds 25-byte feature records, then 32-byte span records
-constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | halo | string-start words
-constexpr int kFeatLdsTotal = kTablesLdsBytes + kFeatWaves * kFeatWaveLds;
-static_assert(kFeatWinBytes >= kStageBytes, "the window doubles as the staging buffer");
+constexpr int kFeatRec = 25;                                          // packed records in the window, as in the output
+constexpr int kFeatWinBytes = kFeatRound * kFeatRec + kFeatRound * 2; // feature records + the (lane, bit) codes of the token-major form
+constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | (unused) | string-start words
+constexpr int kFeatLdsTotal = kFeatWaves * kFeatWaveLds;
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
 static_assert(kFeatWinBytes % 16 == 0 && kFeatWaveLds % 16 == 0, "alignment");
+
+// A token's 25 sums enter the window packed (25-byte stride: the dword stores become byte stores).  Padding the records
+// to 28 or 32 bytes for aligned LDS stores was measured: the LDS pipe's busy time drops 2.5x (PMC), but the un-padding
+// on the way out costs more instructions than it saves and only 832 tokens fit a round at six waves: 796 vs 691 us on
+// C2 (32-byte records: every slot lands in one of four bank groups, 913 us).  The kernel is bound by the dependent
+// chain of ~7 K instructions per tile at 1.5 waves per SIMD, not by a pipe.
+__device__ __forceinline__ void put_record(uint8_t* win, int slot, const FeatSums& s) {
+    uint8_t* rec = win + slot * kFeatRec;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) __builtin_memcpy(rec + 4 * q, &s.v[q], 4);
+    rec[24] = (uint8_t)s.v[6];
+}
+// stream n_rec records out as n_rec * 25 contiguous bytes at dst (any alignment): bytes up to the first dword boundary of
+// the output, then dwords
+__device__ __forceinline__ void flush_records(const uint8_t* win, int n_rec, uint8_t* dst, int lane) {
+    const int n_bytes = n_rec * 25;
+    const int hb = min((int)((4u - ((uintptr_t)dst & 3u)) & 3u), n_bytes);
+    if (lane < hb) dst[lane] = win[lane];
+    const int n_dw = (n_bytes - hb) >> 2;
+    for (int i = lane; i < n_dw; i += 64) {
+        uint32_t v;
+        __builtin_memcpy(&v, win + hb + 4 * i, 4);
+        *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
+    }
+    const int tail0 = hb + 4 * n_dw;
+    if (lane < n_bytes - tail0) dst[tail0 + lane] = win[tail0 + lane];
+}
+// span records (4 x OUT per token) go through the same window in rounds of what fits
+template <typename OUT>
+constexpr int span_round() { return kFeatWinBytes / (4 * (int)sizeof(OUT)) < kFeatRound ? kFeatWinBytes / (4 * (int)sizeof(OUT)) : kFeatRound; }
+
+// 64 rule codes of one word (16-byte aligned) -> d[16]
+__device__ __forceinline__ void load_codes64(const uint8_t* __restrict__ p, uint32_t (&d)[16]) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x4 v = q[k];
+        d[4 * k + 0] = v.x; d[4 * k + 1] = v.y; d[4 * k + 2] = v.z; d[4 * k + 3] = v.w;
+    }
+}
 
 template <typename OUT>
 __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds& L, int64_t t, int lane) {
@@ -1310,39 +1355,25 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     const int64_t base_out = P.tile_rank[t];
     const lk_u64 xb = w < n_words ? P.bits[w] : 0ull;         // all boundaries of my word
 
-    // ---- classify the tile into rule codes (mirror of process_tile phase 1) ---------------------------------------
-    const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);
+    // ---- string starts of the tile (+ the two words behind it) as bits in LDS, from the per-tile string index --------
     int64_t idx0 = P.tile_first[t];
     idx0 = idx0 < 0 ? 0 : (idx0 > P.n_str ? P.n_str : idx0);
     // start of the string that is open when the tile begins (spans are string relative)
     const int64_t start_before = idx0 > 0 ? P.row_off[idx0 - 1] : 0;
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
-    uint32_t halo_cp = 0xFFFFFFFFu;
-    if (lane < 3) {
-        const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
-        if (hp >= 0 && hp < total) halo_cp = P.cps[hp];
+    // ---- my word: 64 rule codes (1 B/char, left by the tile kernel: P.codes; padded behind `total`), the three
+    //      neighbour codes from the neighbour lanes, and the 25 planes ------------------------------------------------
+    const int64_t base = t0 + 64 * (int64_t)lane;
+    const int64_t remain = total - base;
+    const lk_u64 valid = remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
+    uint32_t d[16];
+    load_codes64(P.codes + base, d);
+    uint32_t edge = 0;                                    // lane 0: code of char t0-1; lane 63: codes of t0+4096, t0+4097
+    if (lane == 0 && t0 > 0) edge = P.codes[t0 - 1];
+    if (lane == 63) {
+        if (t0 + kTile < total) edge = P.codes[t0 + kTile];
+        if (t0 + kTile + 1 < total) edge |= (uint32_t)P.codes[t0 + kTile + 1] << 8;
     }
-    if (t0 + kTile <= total) {
-        u32x4 v[16];
-        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = classify4(L.t1, L.t2, v[i]);
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < 16; ++i) {
-            const int64_t p = t0 + 256 * i + 4 * lane;
-            u32x4 v;
-            v.x = p + 0 < total ? P.cps[p + 0] : 0xFFFFFFFFu;
-            v.y = p + 1 < total ? P.cps[p + 1] : 0xFFFFFFFFu;
-            v.z = p + 2 < total ? P.cps[p + 2] : 0xFFFFFFFFu;
-            v.w = p + 3 < total ? P.cps[p + 3] : 0xFFFFFFFFu;
-            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = classify4(L.t1, L.t2, v);
-        }
-    }
-    if (lane < 3) L.halo[lane] = (uint8_t)classify1(L.t1, L.t2, halo_cp);
     L.bw[lane] = 0;
     if (lane < 2) L.bw[64 + lane] = 0;   // one word more than the split kernel: the first word of the next tile is needed
     wave_lds_sync();
@@ -1355,31 +1386,21 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     }
     wave_lds_sync();
-
-    // ---- my word: the 25 planes ---------------------------------------------------------------------------------
     const lk_u64 B = L.bw[lane];
     const lk_u64 Bn = L.bw[lane + 1] & 3ull;
-    const int64_t base = t0 + 64 * (int64_t)lane;
-    const int64_t remain = total - base;
-    const lk_u64 valid = remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
     lk_planes F;
     {
-        uint32_t d[16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint4 q = *reinterpret_cast<const uint4*>(L.stage + 80u * lane + 16u * k);
-            d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
-        }
         lk_halo h;
-        h.prev = lane > 0 ? L.stage[80u * lane - 17u] : L.halo[0];
-        h.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[1];
-        h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
+        const uint32_t up = (uint32_t)__shfl_up((int)(d[15] >> 24), 1);
+        const uint32_t dn = (uint32_t)__shfl_down((int)(d[0] & 0xFFFFu), 1);
+        h.prev = lane > 0 ? up : edge;
+        h.next0 = lane < 63 ? (dn & 0xFFu) : (edge & 0xFFu);
+        h.next1 = lane < 63 ? (dn >> 8) : (edge >> 8);
         lk_u64 plane[8];
         lk_bitslice64(d, plane);
         lk_feature_planes(plane, h, B, Bn, F);
     }
-    const uint32_t prev65 = L.stage[80u * 63u + 63u];   // code of the tile's last char (stage_addr(4095))
-    wave_lds_sync();   // the staging buffer becomes the output window from here on
+    const uint32_t prev65 = (uint32_t)lane_read((int)(d[15] >> 24), 63);   // code of the tile's last char
 
     // ---- what a token that leaves my word collects from the following words -----------------------------------------
     const lk_u64 head_mask = (xb ? ((xb & (~xb + 1ull)) - 1ull) : ~0ull) & valid;
@@ -1405,21 +1426,15 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         }
     }
     if (__ballot(open)) {
-        // A token runs past the tile (the usual case for its last token): the whole wave builds the planes of the next
-        // tile's first word -- lane i classifies char t0 + 4096 + i, lanes 0..1 also the two chars after the word -- and
-        // the open lanes take its head sums.
+        // A token runs past the tile (the usual case for its last token): every lane builds the planes of the next tile's
+        // first word (the same 64 codes, a broadcast load) and the open lanes take its head sums.
         const int64_t q0 = t0 + kTile;
-        const uint32_t c_me = q0 + lane < total ? classify1(L.t1, L.t2, P.cps[q0 + lane]) : 0u;
-        const uint32_t c_nx = (lane < 2 && q0 + 64 + lane < total) ? classify1(L.t1, L.t2, P.cps[q0 + 64 + lane]) : 0u;
         uint32_t d65[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            d65[j] = (uint32_t)__shfl(c_me, 4 * j) | ((uint32_t)__shfl(c_me, 4 * j + 1) << 8) |
-                     ((uint32_t)__shfl(c_me, 4 * j + 2) << 16) | ((uint32_t)__shfl(c_me, 4 * j + 3) << 24);
+        load_codes64(P.codes + q0, d65);
         lk_halo h65;
         h65.prev = prev65;                         // code of the tile's last char
-        h65.next0 = (uint32_t)__shfl(c_nx, 0);
-        h65.next1 = (uint32_t)__shfl(c_nx, 1);
+        h65.next0 = q0 + 64 < total ? (uint32_t)P.codes[q0 + 64] : 0u;
+        h65.next1 = q0 + 65 < total ? (uint32_t)P.codes[q0 + 65] : 0u;
         lk_u64 plane65[8];
         lk_bitslice64(d65, plane65);
         lk_planes F65;
@@ -1438,40 +1453,70 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
             open = xb65 == 0 && q0 + 64 < total;
         }
     }
-    if (open) {
-        // still open after the next tile's first word (a token of > 64 chars): finish it char by char from there
+    const lk_u64 open_m = __ballot(open);
+    if (open_m) {
+        // Still open after the next tile's first word: a token of more than 64 chars that leaves the tile (at most one
+        // lane: the owner of the tile's last kept token -- a masked URL, a long run of letters; a 1 M-char document
+        // without whitespace is ONE such token).  The whole wave continues it, 64 words per step, lane = word: the same
+        // planes + popcount as above, until the word that holds the next boundary; the partial sums meet in a
+        // butterfly and go to the owner.  (The token lies inside one string: the only string start that matters is
+        // the string's end.)
+        const int owner = lk_ctz(open_m);
         const int64_t from = t0 + kTile + 64;
-        if (from < total) {
-            int64_t e = from;   // next boundary at or after `from`
-            for (int64_t v = from >> 6; v < n_words; ++v) {
-                const lk_u64 b2 = P.bits[v];
-                if (b2) { e = (v << 6) + lk_ctz(b2); break; }
-                e = min((v + 1) << 6, total);
-            }
-            // the string that holds the token ends at the first row offset > from - 1 (tokens never cross strings)
-            int64_t lo_s = 0, hi_s = P.n_str;
-            while (hi_s - lo_s > 1) {
-                const int64_t mid = (lo_s + hi_s) >> 1;
-                if (P.row_off[mid] <= from - 1) lo_s = mid; else hi_s = mid;
-            }
-            const int64_t s_end = P.row_off[lo_s + 1];
-            uint32_t acc[25];
+        // the string that holds the token ends at the first row offset > from - 1 (tokens never cross strings)
+        int64_t lo_s = 0, hi_s = P.n_str;
+        while (hi_s - lo_s > 1) {
+            const int64_t mid = (lo_s + hi_s) >> 1;
+            if (P.row_off[mid] <= from - 1) lo_s = mid; else hi_s = mid;
+        }
+        const int64_t s_end = P.row_off[lo_s + 1];
+        FeatSums acc;
 #pragma unroll
-            for (int c = 0; c < 25; ++c) acc[c] = 0;
-            auto bw1 = [&](int64_t i) -> uint32_t { return i < s_end ? lk_base_word1(classify1(L.t1, L.t2, P.cps[i])) : 0u; };
-            uint32_t pw = lk_base_word1(classify1(L.t1, L.t2, P.cps[from - 1])), cw = bw1(from), nw = bw1(from + 1);
-            for (int64_t i = from; i < e; ++i) {
-                const uint32_t aw = bw1(i + 2);
-                const uint32_t r = feat_row_bits1(cw, pw, nw, aw, false, i + 1 == s_end);
-#pragma unroll
-                for (int c = 0; c < 25; ++c) acc[c] += (r >> c) & 1u;
-                pw = cw; cw = nw; nw = aw;
+        for (int j = 0; j < 7; ++j) acc.v[j] = 0;
+        for (int64_t c0 = from; c0 < total; c0 += kTile) {
+            const int64_t wb = c0 + 64 * (int64_t)lane;
+            const lk_u64 xbw = (wb >> 6) < n_words ? P.bits[wb >> 6] : 0ull;
+            const lk_u64 hasb = __ballot(xbw != 0ull);
+            const int fl = hasb ? lk_ctz(hasb) : 64;                  // lane of the word that holds the next boundary
+            uint32_t dw[16];
+            load_codes64(P.codes + wb, dw);                            // (in bounds: the code array is padded by a tile)
+            uint32_t e2 = 0;
+            if (lane == 0) e2 = P.codes[c0 - 1];
+            if (lane == 63) {
+                if (c0 + kTile < total) e2 = P.codes[c0 + kTile];
+                if (c0 + kTile + 1 < total) e2 |= (uint32_t)P.codes[c0 + kTile + 1] << 8;
             }
+            const uint32_t up = (uint32_t)__shfl_up((int)(dw[15] >> 24), 1);
+            const uint32_t dn = (uint32_t)__shfl_down((int)(dw[0] & 0xFFFFu), 1);
+            lk_halo hw;
+            hw.prev = lane > 0 ? up : e2;
+            hw.next0 = lane < 63 ? (dn & 0xFFu) : (e2 & 0xFFu);
+            hw.next1 = lane < 63 ? (dn >> 8) : (e2 >> 8);
+            const int64_t rel = s_end - wb;                            // the string's end as a "string start" bit
+            const lk_u64 Bw = (rel >= 0 && rel < 64) ? (1ull << rel) : 0ull;
+            const lk_u64 Bnw = (rel == 64) ? 1ull : (rel == 65 ? 2ull : 0ull);
+            lk_u64 pw[8];
+            lk_bitslice64(dw, pw);
+            lk_planes Fw;
+            lk_feature_planes(pw, hw, Bw, Bnw, Fw);
+            const int64_t remw = total - wb;
+            const lk_u64 validw = remw >= 64 ? ~0ull : (remw <= 0 ? 0ull : ((1ull << remw) - 1ull));
+            lk_u64 m = 0ull;
+            if (lane < fl) m = validw;
+            else if (lane == fl) m = ((xbw & (~xbw + 1ull)) - 1ull) & validw;
+            const FeatSums part = feat_popc(Fw, m);
 #pragma unroll
-            for (int c = 0; c < 25; ++c) {
-                const uint32_t add = (acc[c] & 0xFFu) << (8 * (c & 3));
-                C.v[c >> 2] = swar_add_u8(C.v[c >> 2], add);
-            }
+            for (int j = 0; j < 7; ++j) acc.v[j] = swar_add_u8(acc.v[j], part.v[j]);
+            if (hasb) break;
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc.v[j] = swar_add_u8(acc.v[j], (uint32_t)__shfl_xor((int)acc.v[j], sh));
+        }
+        if (lane == owner) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) C.v[j] = swar_add_u8(C.v[j], acc.v[j]);
         }
     }
 
@@ -1502,7 +1547,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
     if (maxc * 2 > ((n_wave + 63) >> 6) * 3) {
         uint8_t* fwin = L.stage;
-        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRound * 25);   // behind the feature records
+        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRound * kFeatRec);   // behind the feature records
         lk_u64 trest = x;
         int tk = off;
         for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
@@ -1544,10 +1589,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                     if (!above) sum.v[q] = swar_add_u8(sum.v[q], cq);
                 }
                 if (active) {
-                    uint8_t* rec = fwin + j * 25;
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) __builtin_memcpy(rec + 4 * q, &sum.v[q], 4);
-                    rec[24] = (uint8_t)sum.v[6];
+                    put_record(fwin, j, sum);
                     const lk_u64 o_nn = ~o_S & ovalid;
                     const int64_t p = obase + b;
                     const lk_u64 bl = o_B & ((2ull << b) - 1ull);
@@ -1584,19 +1626,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                 }
             }
             wave_lds_sync();
-            const int n_bytes = n_here * 25;
-            uint8_t* dst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
-            const int head = (int)((4u - ((uintptr_t)dst & 3u)) & 3u);
-            const int hb = min(head, n_bytes);
-            if (lane < hb) dst[lane] = fwin[lane];
-            const int n_dw = (n_bytes - hb) >> 2;
-            for (int i = lane; i < n_dw; i += 64) {
-                uint32_t v;
-                __builtin_memcpy(&v, fwin + hb + 4 * i, 4);
-                *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
-            }
-            const int tail0 = hb + 4 * n_dw;
-            if (lane < n_bytes - tail0) dst[tail0 + lane] = fwin[tail0 + lane];
+            flush_records(fwin, n_here, reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25, lane);
             wave_lds_sync();
         }
         return;
@@ -1618,36 +1648,22 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #pragma unroll
                 for (int j = 0; j < 7; ++j) sum.v[j] = swar_add_u8(sum.v[j], C.v[j]);
             }
-            uint8_t* rec = win + (k - win0) * 25;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) __builtin_memcpy(rec + 4 * j, &sum.v[j], 4);
-            rec[24] = (uint8_t)sum.v[6];
+            put_record(win, k - win0, sum);
             ++k;
         }
         wave_lds_sync();
-        const int n_bytes = min(kFeatRound, n_wave - win0) * 25;
-        uint8_t* dst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
-        const int head = (int)((4u - ((uintptr_t)dst & 3u)) & 3u);      // bytes up to the first aligned dword
-        const int hb = min(head, n_bytes);
-        if (lane < hb) dst[lane] = win[lane];
-        const int n_dw = (n_bytes - hb) >> 2;
-        for (int i = lane; i < n_dw; i += 64) {
-            uint32_t v;
-            __builtin_memcpy(&v, win + hb + 4 * i, 4);
-            *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
-        }
-        const int tail0 = hb + 4 * n_dw;
-        if (lane < n_bytes - tail0) dst[tail0 + lane] = win[tail0 + lane];
+        flush_records(win, min(kFeatRound, n_wave - win0), reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25, lane);
         wave_lds_sync();
     }
 
     // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
     OUT* swin = reinterpret_cast<OUT*>(L.stage);
+    constexpr int kSpanRound = span_round<OUT>();
     rest = x;
     k = off;
-    for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
-        while (rest && k < win0 + kFeatRound) {
+    for (int win0 = 0; win0 < n_wave; win0 += kSpanRound) {
+        while (rest && k < win0 + kSpanRound) {
             const int b = lk_ctz(rest);
             rest &= rest - 1;
             const int64_t p = base + b;
@@ -1686,7 +1702,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
             // 16-byte stores: two (int64) or four (int32) values each; a record is 32 or 16 bytes, so the stream is aligned
             constexpr int kPer = 16 / (int)sizeof(OUT);
             typedef OUT vec_t __attribute__((ext_vector_type(16 / sizeof(OUT))));
-            const int n_vec = min(kFeatRound, n_wave - win0) * 4 / kPer;
+            const int n_vec = min(kSpanRound, n_wave - win0) * 4 / kPer;
             vec_t* dst = reinterpret_cast<vec_t*>(spans4 + (base_out + win0) * 4);
             for (int i = lane; i < n_vec; i += 64) {
                 vec_t v;
@@ -1706,17 +1722,9 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {   // [stage-1 | stage-2 rule codes] -> LDS, same layout as the split kernel
-        constexpr int kVec = kTablesLdsBytes / 16;
-        const uint4* src = reinterpret_cast<const uint4*>(P.t1);
-        uint4* dst = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < kVec; i += kFeatWaves * 64) dst[i] = src[i];
-    }
-    __syncthreads();
     TileLds L;
-    L.t1 = lds;
-    L.t2 = lds + kStage1Pad;
-    uint8_t* mine = lds + kTablesLdsBytes + wave * kFeatWaveLds;
+    L.t1 = L.t2 = L.lut = L.ctab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
+    uint8_t* mine = lds + wave * kFeatWaveLds;
     L.stage = mine;
     L.halo = mine + kFeatWinBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kFeatWinBytes + 16);

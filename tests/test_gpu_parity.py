@@ -818,6 +818,38 @@ def test_featurize_long_tokens_across_words_and_tiles(gpu, oracle):
             assert np.array_equal(tok.features, f), (t[:40], a, b, tok.features, f)
 
 
+def test_featurize_million_char_tokens(gpu, oracle):
+    """BASELINE configs[4] stress documents (SURVEY 8d C5 i, ii): 1 M chars without whitespace, and the same with a URL
+    start at char 4 (the whole document is one masked token).  The token that leaves its tile is continued by the whole
+    wave, 4096 chars per step (it used to be finished char by char on one lane: 10^6 dependent steps)."""
+    from latok_amd import batch
+    rng = random.Random(4242)
+    n = 1_000_000
+    body = "".join(rng.choice("abcdefghXYZ019_") for _ in range(n))
+    docs = [body,                                         # (i) no whitespace at all: camelCase humps split it
+            "see http://" + body[:n - 11],                # (ii)-like: a masked block of ~1 M chars behind a short word
+            "http://" + body[:n - 7],                     # (ii) the whole document is one token
+            "x " * 10 + "a@" + body[:300000] + "/.:" + body[:200000] + " tail",   # long masked e-mail between short tokens
+            "é" * 5000 + "@" + "日" * 200000 + " end"]
+    got = batch.featurize_batch(docs)
+    for t, toks in zip(docs, got):
+        m = oracle.gen_parse_matrix(t).astype(np.uint8)
+        nz = oracle.split_offsets(t).tolist() + [len(t)]
+        want = [(a, b) for a, b in zip(nz[:-1], nz[1:]) if t[a:b].strip()]
+        assert [(x.start_idx, x.end_idx) for x in toks] == want, t[:40]
+        csum = np.zeros((len(t) + 1, 25), np.uint64)
+        np.cumsum(m, axis=0, dtype=np.uint64, out=csum[1:])
+        for tok, (a, b) in zip(toks, want):
+            f = (csum[b] - csum[a]).astype(np.uint8).astype(np.int8)
+            assert np.array_equal(tok.features, f), (t[:30], a, b, tok.features, f)
+    # the same documents in one batch with short strings around them, 32-bit records
+    texts = ["short one", docs[2], "", docs[0][:5000] + " x", docs[1], "tail #tag"]
+    cps, row = pack(texts)
+    a = batch.token_features_csr(cps, row)
+    b = batch.token_features_csr(cps, row, dtype=np.int32)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def _byte_expect(oracle, texts):
     """oracle boundaries / SPACE flags mapped from code-point to byte positions of the UTF-8 encoding"""
     blobs = [t.encode("utf-8", "surrogatepass") for t in texts]

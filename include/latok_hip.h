@@ -203,6 +203,10 @@ int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out,
 /* ---- device memory / stream helpers (so hosts need no other GPU runtime binding) ------------------------------ */
 void* latok_dev_alloc(size_t bytes);   /* NULL on failure */
 int latok_dev_free(void* p);
+/* Pinned (page-locked) host memory: host-pointer batches handed over in such buffers move over the bus at full speed and
+ * asynchronously -- the chunked pipeline of the large-batch compaction calls then keeps both copy directions busy at once. */
+void* latok_host_alloc(size_t bytes);  /* NULL on failure */
+int latok_host_free(void* p);
 int latok_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int latok_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int latok_memset_dev(void* dst_dev, int value, size_t bytes);

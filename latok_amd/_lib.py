@@ -57,6 +57,8 @@ SIGNATURES = {
     "latok_block_mask": (ci, [vp, vp, i64, vp, ci, vp]),
     "latok_dev_alloc": (vp, [C.c_size_t]),
     "latok_dev_free": (ci, [vp]),
+    "latok_host_alloc": (vp, [C.c_size_t]),
+    "latok_host_free": (ci, [vp]),
     "latok_memcpy_h2d": (ci, [vp, vp, C.c_size_t]),
     "latok_memcpy_d2h": (ci, [vp, vp, C.c_size_t]),
     "latok_memset_dev": (ci, [vp, ci, C.c_size_t]),

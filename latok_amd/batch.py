@@ -34,6 +34,34 @@ def _csr(cps, row_off):
 
 
 
+class _Pinned:
+    """keeps a pinned allocation alive for as long as the numpy array over it"""
+
+    def __init__(self, lib, nbytes):
+        self.lib, self.ptr = lib, lib.latok_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise MemoryError(_lib.last_error())
+
+    def __del__(self):
+        try:
+            self.lib.latok_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """np.empty in pinned (page-locked) host memory (latok_host_alloc): host-pointer batches held in such arrays cross the
+    bus at full speed and asynchronously, which is what lets the chunked pipeline of the large-batch calls overlap the
+    upload of one chunk with the download of another.  The memory is freed when the array (and its views) are gone."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    owner = _Pinned(_lib.ensure_init(), n * dt.itemsize)
+    buf = (C.c_char * max(n * dt.itemsize, 1)).from_address(owner.ptr)
+    buf._latok_owner = owner
+    a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    return a
+
+
 def _out_dtype(dtype):
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.int64), np.dtype(np.int32)):
@@ -41,21 +69,24 @@ def _out_dtype(dtype):
     return dt, (_lib.OUT_INT32 if dt == np.dtype(np.int32) else 0)
 
 
-def _compact(fn, lead, n_str, total, width, dtype, feats=False):
+def _compact(fn, lead, n_str, total, width, dtype, feats=False, pinned=False):
     """Shared body of the compaction wrappers: fn(*lead, n_str, total, counts, items[, features], cap, &n, flags, stream).
     Returns (counts[n_str], items[n] or items[n, width][, features int8[n, 25]]); counts / items in `dtype` (int64, or
-    int32 = LATOK_OUT_INT32: half the bytes written on the device and moved over the bus)."""
+    int32 = LATOK_OUT_INT32: half the bytes written on the device and moved over the bus).  pinned: the result arrays
+    live in pinned host memory and are returned as views (no copy)."""
     dt, flags = _out_dtype(dtype)
-    counts = np.zeros(n_str, dt)
+    alloc = pinned_empty if pinned else np.empty
+    counts = alloc(n_str, dt)
     cap = max(total, 1)                                  # a string has at most len items
-    items = np.empty((cap, width) if width > 1 else cap, dt)
-    feat = np.empty((cap, _lib.FEATURE_COUNT), np.int8) if feats else None
+    items = alloc((cap, width) if width > 1 else cap, dt)
+    feat = alloc((cap, _lib.FEATURE_COUNT), np.int8) if feats else None
     n = C.c_int64(0)
     args = list(lead) + [n_str, total, _ptr(counts), _ptr(items)] + ([_ptr(feat)] if feats else []) + [cap, C.byref(n), flags, None]
     _lib.check(fn(*args))
+    keep = (lambda a: a) if pinned else (lambda a: a.copy())
     if feats:
-        return counts, items[:n.value].copy(), feat[:n.value].copy()
-    return counts, items[:n.value].copy()
+        return counts, keep(items[:n.value]), keep(feat[:n.value])
+    return counts, keep(items[:n.value])
 
 
 def split_mask_batch(cps, row_off) -> np.ndarray:

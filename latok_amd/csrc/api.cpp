@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -119,6 +120,11 @@ struct Ctx {
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
+    // chunked host pipeline (compact_host_pipelined): copy streams, events and double buffers
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_in_ready[2] = {nullptr, nullptr}, ev_k_done[2] = {nullptr, nullptr}, ev_d2h_done[2] = {nullptr, nullptr};
+    DevBuf pipe_in[2], pipe_row[2], pipe_counts[2], pipe_items[2], pipe_feat[2];
+    PinBuf pipe_tot;
     DevBuf chain, chain_ctl;   // k_word_counts_scan: look-back state per workgroup, {ticket counter}
     unsigned scan_epoch = 0;
     bool chain_ready = false;
@@ -348,6 +354,17 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.turn_stream_valid = false;
     g.chain_ready = false;
     g.scan_epoch = 0;
+    for (int i = 0; i < 2; ++i) {
+        for (DevBuf* b : {&g.pipe_in[i], &g.pipe_row[i], &g.pipe_counts[i], &g.pipe_items[i], &g.pipe_feat[i]}) b->release();
+        for (hipEvent_t* e : {&g.ev_in_ready[i], &g.ev_k_done[i], &g.ev_d2h_done[i]}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    }
+    g.pipe_tot.release();
+    if (g.s_h2d) (void)hipStreamDestroy(g.s_h2d);
+    if (g.s_d2h) (void)hipStreamDestroy(g.s_d2h);
+    g.s_h2d = g.s_d2h = nullptr;
     if (g.stream) (void)hipStreamDestroy(g.stream);
     g.stream = nullptr;
     g.inited = false;
@@ -644,15 +661,207 @@ static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* e
     return LATOK_OK;
 }
 
-// Shared body of the compaction entry points: per-string boundary offsets (spans = false), token spans, or token spans +
-// feature sums (features_out).  Launch sequence on device-resident data:
+// Device-side core of the compaction entry points, on one device-resident (chunk of a) batch: per-string boundary
+// offsets (spans = false), token spans, or token spans + feature sums (feats).  Launch sequence:
 //   tile index -> tiles -> resolve            the two bitmasks (boundaries, SPACE)
-//   k_word_counts_scan                        items per word / tile, tile ranks (scan) and the total, one launch
-//   k_counts_scatter (or k_string_counts + k_features_tiles)     per-string counts + the records, one launch, written
-//                                             only if the total fits the caller's capacity
-//   one synchronisation: the total (and the error flag) are read from pinned memory
-// With host pointers the records are staged on the device, so the total has to be known before the staging buffer can be
-// sized: one more synchronisation in the middle (that path is bound by the bus anyway).
+//   k_word_counts, k_scan_chained             items per word / tile, tile ranks and the total
+//   k_counts_scatter (or k_string_counts + k_features_tiles)     per-string counts + the records, written only if the
+//                                             total fits `cap`
+// Nothing is synchronised here: the total and the int32-overflow flag land in the pinned pair p_tot[0..1] (h_tot = the
+// host's view of the same two words) when the stream gets there.
+static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, const uint32_t* d_cps, const uint8_t* d_u8, int unit_kind,
+                                  const int64_t* d_row, int64_t n_str, int64_t total, void* d_counts, void* d_items, int8_t* d_feat,
+                                  int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st) {
+    int rc;
+    if (d_u8 && unit_kind && (feats || g.rules_on)) {
+        // featurize re-reads the code points and the rule interpreter has no narrow-unit form: widen once, on the device
+        if (((uintptr_t)d_u8 & (size_t)(unit_kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
+        if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
+        HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)g.h_cps.p, st));
+        d_cps = (const uint32_t*)g.h_cps.p;
+        d_u8 = nullptr;
+    }
+    const int64_t words = (total + 63) / 64;
+    if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = g.kept.ensure((size_t)words * 8 + 8))) return rc;
+    const int64_t c_tiles = (words + 63) / 64;
+    if ((rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
+    if ((rc = g.bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
+    if ((rc = g.wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
+    unsigned epoch = 0;
+    if ((rc = next_scan_epoch(g, latok::count_blocks(words), st, &epoch))) return rc;
+    uint64_t* d_bits = (uint64_t*)g.bits.p;
+    uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
+    uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
+    const uint64_t* d_item_mask = spans ? d_kept : d_bits;
+    int64_t* d_rank = (int64_t*)g.bases.p;
+    int64_t* d_tcnt = (int64_t*)g.wcnt.p;
+    uint16_t* d_pref = (uint16_t*)g.wpref.p;
+    if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
+    int64_t* d_tile_first = (int64_t*)g.tile_first.p;
+    uint8_t* d_codes = nullptr;
+    if (feats) {   // the tile kernel leaves the rule code of every char: 1 B/char for k_features_tiles instead of 4 B/char + tables
+        const size_t code_bytes = (size_t)total + latok::kTile + 256;   // read (never used) up to a tile behind the last char
+        if ((rc = g.codes.ensure(code_bytes))) return rc;
+        d_codes = (uint8_t*)g.codes.p;
+        const size_t tail0 = (size_t)total & ~(size_t)(latok::kTile - 1);
+        HIP_TRY(hipMemsetAsync(d_codes + tail0, 0, code_bytes - tail0, st));
+    }
+    if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes)))
+        return rc;
+    h_tot[0] = 0;
+    h_tot[1] = 0;
+    int64_t* d_total = (int64_t*)g.scalar.p;
+    int* d_err = (int*)(p_tot + 1);
+    HIP_TRY(latok::launch_word_counts_scan(spans, d_bits, d_space, words, total, d_kept, d_tcnt, d_pref, d_rank,
+                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, st));
+    if (feats) {   // spans and sums come from one kernel
+        HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
+        return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
+                                d_feat, o32, d_total, cap, st);
+    }
+    HIP_TRY(latok::launch_counts_scatter(spans ? 1 : 0, o32, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total, d_row,
+                                         n_str, d_tile_first, d_items, d_total, cap, d_counts, d_err, st));
+    return LATOK_OK;
+}
+
+// Large host-pointer batches: a chunked pipeline over three streams.  The batch is cut into chunks of whole strings
+// (~8 M chars); chunk c + 1 is on its way up the bus (copy stream) while chunk c runs its kernels (the context's stream)
+// and the records of chunk c - 1 go down (second copy stream); inputs and outputs are double-buffered on the device, a
+// chunk's records land in a buffer sized for the worst case (one item per char), so nothing waits for a total before it
+// is enqueued.  Per chunk the host waits once (for its total) before it can place the chunk's records behind the
+// previous ones in the caller's arrays.  With pinned host arrays (latok_host_alloc) both copy directions run at bus
+// speed concurrently; pageable arrays work too (the runtime stages them).
+constexpr int64_t kPipeChunkChars = 8 << 20;
+constexpr int64_t kPipeMinChars = 2 * kPipeChunkChars;
+
+static int ensure_pipe(Ctx& g) {
+    if (g.s_h2d) return LATOK_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&g.s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&g.s_d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_in_ready[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_k_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g.ev_d2h_done[i], hipEventDisableTiming));
+    }
+    return LATOK_OK;
+}
+
+static int compact_host_pipelined(Ctx& g, bool spans, bool feats, bool o32, const void* data, size_t unit_bytes, int unit_kind,
+                                  bool as_u8, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
+                                  void* items_out, int64_t items_cap, int64_t* n_items_out, int8_t* features_out, hipStream_t st) {
+    int rc;
+    if ((rc = ensure_pipe(g))) return rc;
+    const size_t elt = o32 ? 4 : 8;
+    const size_t item_bytes = (feats ? 4 : (spans ? 2 : 1)) * elt;
+    // chunk boundaries (string ids): cut where the cumulative char count passes multiples of the chunk size
+    std::vector<int64_t> cut(1, 0);
+    int64_t max_chars = 0, max_strs = 0;
+    while (cut.back() < n_str) {
+        const int64_t s0 = cut.back();
+        const int64_t* e = std::upper_bound(row_off + s0 + 1, row_off + n_str + 1, row_off[s0] + kPipeChunkChars);
+        int64_t s1 = (e - row_off) - 1;            // last string that still ends within the chunk size
+        if (s1 <= s0) s1 = s0 + 1;                 // a single string longer than a chunk is a chunk of its own
+        cut.push_back(s1);
+        max_chars = std::max(max_chars, row_off[s1] - row_off[s0]);
+        max_strs = std::max(max_strs, s1 - s0);
+    }
+    const int n_chunks = (int)cut.size() - 1;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = g.pipe_in[i].ensure((size_t)max_chars * unit_bytes + 64))) return rc;
+        if ((rc = g.pipe_row[i].ensure((size_t)(max_strs + 1) * 8))) return rc;
+        if ((rc = g.pipe_counts[i].ensure((size_t)max_strs * elt + 16))) return rc;
+        if ((rc = g.pipe_items[i].ensure((size_t)max_chars * item_bytes + 64))) return rc;      // at most one item per char
+        if (feats && (rc = g.pipe_feat[i].ensure((size_t)max_chars * LATOK_FEATURE_COUNT + 64))) return rc;
+    }
+    if ((rc = g.pipe_tot.ensure(8 * 16))) return rc;
+    {   // size every workspace for the largest chunk now: growing one later would free it under a chunk that is still running
+        const size_t w = (size_t)((max_chars + 63) / 64), t = (size_t)((max_chars + latok::kTile - 1) / latok::kTile);
+        if ((rc = ensure_workspace(g, (int64_t)t))) return rc;
+        if ((rc = g.bits.ensure(w * 8 + 8))) return rc;
+        if (spans && ((rc = g.space.ensure(w * 8 + 8)) || (rc = g.kept.ensure(w * 8 + 8)))) return rc;
+        if ((rc = g.wcnt.ensure(((w + 63) / 64) * 8 + 8)) || (rc = g.bases.ensure(((w + 63) / 64) * 8 + 8))) return rc;
+        if ((rc = g.wpref.ensure(w * 2 + 8))) return rc;
+        if ((rc = g.tile_first.ensure(t * 8 + 8))) return rc;
+        if (feats && (rc = g.codes.ensure((size_t)max_chars + latok::kTile + 256))) return rc;
+        if (as_u8 && unit_kind && (feats || g.rules_on) && (rc = g.h_cps.ensure((size_t)max_chars * 4 + 16))) return rc;
+        if ((rc = g.chain.ensure((size_t)latok::count_blocks((int64_t)w) * 8 + 64))) return rc;
+    }
+    int64_t running = 0;
+    bool overflow = false, too_long = false;
+    std::vector<int64_t> n_of(n_chunks, 0);
+    auto finish = [&](int c) -> int {   // chunk c's kernels are enqueued: wait for its total, send its records down
+        const int slot = c & 1;
+        HIP_TRY(hipEventSynchronize(g.ev_k_done[slot]));
+        volatile int64_t* h = (volatile int64_t*)g.pipe_tot.h + 2 * (c & 7);
+        const int64_t n = h[0];
+        if (h[1]) too_long = true;
+        n_of[c] = n;
+        const int64_t s0 = cut[c], ns = cut[c + 1] - cut[c];
+        HIP_TRY(hipStreamWaitEvent(g.s_d2h, g.ev_k_done[slot], 0));
+        HIP_TRY(hipMemcpyAsync((char*)counts_out + (size_t)s0 * elt, g.pipe_counts[slot].p, (size_t)ns * elt, hipMemcpyDeviceToHost, g.s_d2h));
+        if (running + n > items_cap || (n > 0 && !items_out)) overflow = true;
+        if (!overflow && n > 0) {
+            HIP_TRY(hipMemcpyAsync((char*)items_out + (size_t)running * item_bytes, g.pipe_items[slot].p, (size_t)n * item_bytes,
+                                   hipMemcpyDeviceToHost, g.s_d2h));
+            if (feats)
+                HIP_TRY(hipMemcpyAsync(features_out + (size_t)running * LATOK_FEATURE_COUNT, g.pipe_feat[slot].p,
+                                       (size_t)n * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, g.s_d2h));
+        }
+        HIP_TRY(hipEventRecord(g.ev_d2h_done[slot], g.s_d2h));
+        running += n;
+        return LATOK_OK;
+    };
+    auto upload = [&](int c) -> int {   // chunk c's code units and row offsets (its device buffers are free once chunk c - 2 is computed)
+        const int slot = c & 1;
+        const int64_t s0 = cut[c], ns = cut[c + 1] - s0, c0 = row_off[s0], nc = row_off[cut[c + 1]] - c0;
+        if (c >= 2) HIP_TRY(hipStreamWaitEvent(g.s_h2d, g.ev_k_done[slot], 0));
+        if (nc > 0)
+            HIP_TRY(hipMemcpyAsync(g.pipe_in[slot].p, (const char*)data + (size_t)c0 * unit_bytes, (size_t)nc * unit_bytes,
+                                   hipMemcpyHostToDevice, g.s_h2d));
+        HIP_TRY(hipMemcpyAsync(g.pipe_row[slot].p, row_off + s0, (size_t)(ns + 1) * 8, hipMemcpyHostToDevice, g.s_h2d));
+        HIP_TRY(hipEventRecord(g.ev_in_ready[slot], g.s_h2d));
+        return LATOK_OK;
+    };
+    if ((rc = upload(0))) return rc;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int slot = c & 1;
+        const int64_t s0 = cut[c], ns = cut[c + 1] - s0, c0 = row_off[s0], nc = row_off[cut[c + 1]] - c0;
+        // compute: behind the upload, and behind the download of chunk c - 2 (it read the same output buffers)
+        HIP_TRY(hipStreamWaitEvent(st, g.ev_in_ready[slot], 0));
+        if (c >= 2) HIP_TRY(hipStreamWaitEvent(st, g.ev_d2h_done[slot], 0));
+        HIP_TRY(latok::launch_rebase_rows((int64_t*)g.pipe_row[slot].p, ns + 1, c0, st));
+        volatile int64_t* h = (volatile int64_t*)g.pipe_tot.h + 2 * (c & 7);
+        int64_t* p = (int64_t*)g.pipe_tot.d + 2 * (c & 7);
+        if (nc > 0) {
+            rc = enqueue_compaction_dev(g, spans, feats, o32, as_u8 ? nullptr : (const uint32_t*)g.pipe_in[slot].p,
+                                        as_u8 ? (const uint8_t*)g.pipe_in[slot].p : nullptr, unit_kind, (const int64_t*)g.pipe_row[slot].p,
+                                        ns, nc, g.pipe_counts[slot].p, g.pipe_items[slot].p, (int8_t*)g.pipe_feat[slot].p, nc, p, h, st);
+            if (rc) return rc;
+        } else {   // only empty strings in this chunk
+            h[0] = 0;
+            h[1] = 0;
+            HIP_TRY(hipMemsetAsync(g.pipe_counts[slot].p, 0, (size_t)ns * elt, st));
+        }
+        HIP_TRY(hipEventRecord(g.ev_k_done[slot], st));
+        // the next upload is queued before the host waits for anything: the copy stream never runs dry
+        // (chunk c + 1 shares its buffers with chunk c - 1, whose kernels were enqueued an iteration ago)
+        if (c + 1 < n_chunks && (rc = upload(c + 1))) return rc;
+        if (c >= 1 && (rc = finish(c - 1))) return rc;
+    }
+    if ((rc = finish(n_chunks - 1))) return rc;
+    HIP_TRY(hipStreamSynchronize(g.s_d2h));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_items_out = running;
+    if (too_long) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
+    if (running > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)running);
+    if (running > 0 && !items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
+    return LATOK_OK;
+}
+
+// Shared body of the compaction entry points: argument checks, staging of host-pointer batches, one synchronisation.
 static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           void* counts_out, void* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
@@ -672,35 +881,36 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     }
     StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
+    const size_t elt = o32 ? 4 : 8;                                   // width of counts and of every record field
+    const size_t item_bytes = (feats ? 4 : (spans ? 2 : 1)) * elt;
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
     const uint8_t* d_u8 = nullptr;   // byte space: the tile kernel reads the UTF-8 bytes itself, results are byte offsets
+    const size_t unit_bytes = (utf8 && byte_space) ? (unit_kind ? (size_t)unit_kind : 1) : 4;
+    if (!dev && !(utf8 && !byte_space)) {
+        // host pointers, fixed-width units or UTF-8 in byte space: checked here; large batches take the chunked pipeline
+        if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
+        if (n_str == 0) return LATOK_OK;
+        if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
+        if (total >= kPipeMinChars)
+            return compact_host_pipelined(g, spans, feats, o32, utf8 ? (const void*)utf8 : (const void*)cps, unit_bytes, unit_kind,
+                                          utf8 != nullptr, row_off, n_str, total, counts_out, items_out, items_cap, n_items_out,
+                                          features_out, st);
+    }
     if (utf8 && byte_space) {
         // UTF-8 in byte space, or (unit_kind 1 / 2) PEP 393 code units: `total` positions of unit_bytes each
-        const size_t unit_bytes = unit_kind ? (size_t)unit_kind : 1;
         if (dev) {
             if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
             d_u8 = utf8;
-        } else {
-            if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
-            if (n_str > 0) {
-                if ((rc = g.u_bytes.ensure((size_t)total * unit_bytes + 16))) return rc;
-                if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
-                if (total > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total * unit_bytes, hipMemcpyHostToDevice, st));
-                HIP_TRY(hipMemcpyAsync(g.u_boff.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
-                d_u8 = (const uint8_t*)g.u_bytes.p;
-                d_row = (const int64_t*)g.u_boff.p;
-            }
+        } else if (n_str > 0) {
+            if ((rc = g.u_bytes.ensure((size_t)total * unit_bytes + 16))) return rc;
+            if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+            if (total > 0) HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total * unit_bytes, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(g.u_boff.p, row_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+            d_u8 = (const uint8_t*)g.u_bytes.p;
+            d_row = (const int64_t*)g.u_boff.p;
         }
         d_cps = nullptr;
-        if (unit_kind && (feats || g.rules_on) && n_str > 0 && total > 0) {
-            // featurize re-reads the code points and the rule interpreter has no narrow-unit form: widen once, on the device
-            if (total > 0 && ((uintptr_t)d_u8 & (unit_bytes - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
-            if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
-            HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)g.h_cps.p, st));
-            d_cps = (const uint32_t*)g.h_cps.p;
-            d_u8 = nullptr;
-        }
     } else if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
         BytesRoute br;
         if ((rc = decode_utf8_to_workspace(g, utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
@@ -716,13 +926,9 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
         if (total > 0 && ((uintptr_t)cps & 15) != 0)
             return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
-    } else {
-        if ((rc = check_csr_host(row_off, n_str, &total))) return rc;
     }
     if (n_str == 0) return LATOK_OK;
     if (!counts_out) return fail(LATOK_ERR_INVALID, "counts_out is NULL");
-    const size_t elt = o32 ? 4 : 8;                                   // width of counts and of every record field
-    const size_t item_bytes = (feats ? 4 : (spans ? 2 : 1)) * elt;
     if (total == 0) {   // only empty strings: all counts are 0
         if (dev) HIP_TRY(hipMemsetAsync(counts_out, 0, (size_t)n_str * elt, st));
         else memset(counts_out, 0, (size_t)n_str * elt);
@@ -750,93 +956,51 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         d_cps = (const uint32_t*)g.h_cps.p;
         d_row = (const int64_t*)g.h_row.p;
     }
-    // word-parallel compaction (compact_kernels.hip)
-    const int64_t words = (total + 63) / 64;
-    if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
-    if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
-    if (spans && (rc = g.kept.ensure((size_t)words * 8 + 8))) return rc;
-    const int64_t c_tiles = (words + 63) / 64;
-    if ((rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
-    if ((rc = g.bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
-    if ((rc = g.wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
-    if (!dev && !small && (rc = g.counts.ensure((size_t)n_str * 8))) return rc;
     if ((rc = g.pin_tot.ensure(64))) return rc;
-    unsigned epoch = 0;
-    if ((rc = next_scan_epoch(g, latok::count_blocks(words), st, &epoch))) return rc;
-    uint64_t* d_bits = (uint64_t*)g.bits.p;
-    uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
-    uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
-    const uint64_t* d_item_mask = spans ? d_kept : d_bits;
-    int64_t* d_rank = (int64_t*)g.bases.p;
-    int64_t* d_tcnt = (int64_t*)g.wcnt.p;
-    uint16_t* d_pref = (uint16_t*)g.wpref.p;
-    if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
-    int64_t* d_tile_first = (int64_t*)g.tile_first.p;
-    uint8_t* d_codes = nullptr;
-    if (feats) {   // the tile kernel leaves the rule code of every char: 1 B/char for k_features_tiles instead of 4 B/char + tables
-        const size_t code_bytes = (size_t)total + latok::kTile + 256;   // read (never used) up to a tile behind the last char
-        if ((rc = g.codes.ensure(code_bytes))) return rc;
-        d_codes = (uint8_t*)g.codes.p;
-        HIP_TRY(hipMemsetAsync(d_codes + ((size_t)total & ~(size_t)(latok::kTile - 1)), 0, code_bytes - ((size_t)total & ~(size_t)(latok::kTile - 1)), st));
-    }
-    if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes)))
-        return rc;
-    // pinned, device-mapped words the kernels drop their results into: [0] item total, [1] int32-overflow flag
     volatile int64_t* h_tot = (volatile int64_t*)g.pin_tot.h;
     int64_t* p_tot = (int64_t*)g.pin_tot.d;
-    h_tot[1] = 0;
-    int64_t* d_total = (int64_t*)g.scalar.p;
-    int* d_err = (int*)(p_tot + 1);
-    HIP_TRY(latok::launch_word_counts_scan(spans, d_bits, d_space, words, total, d_kept, d_tcnt, d_pref, d_rank,
-                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, st));
-    auto enqueue_records = [&](void* d_counts, void* d_items, int8_t* d_feat, int64_t cap) -> int {
-        if (feats) {   // spans and sums come from one kernel
-            HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
-            return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first,
-                                    d_items, d_feat, o32, d_total, cap, st);
-        }
-        HIP_TRY(latok::launch_counts_scatter(spans ? 1 : 0, o32, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total,
-                                             d_row, n_str, d_tile_first, d_items, d_total, cap, d_counts, d_err, st));
-        return LATOK_OK;
-    };
-    if (dev || small) {
-        // one synchronisation: records are written only if they fit (the kernel checks the total against the capacity)
-        void* d_counts = dev ? counts_out : (void*)((char*)g.pin.d + po_counts);
-        void* d_items = dev ? items_out : (void*)((char*)g.pin.d + po_items);
-        int8_t* d_feat = dev ? features_out : (int8_t*)((char*)g.pin.d + po_feat);
-        const int64_t cap = dev ? (items_out ? items_cap : 0) : total;   // the pinned item area holds one item per char
-        if ((rc = enqueue_records(d_counts, d_items, d_feat, cap))) return rc;
-        HIP_TRY(hipStreamSynchronize(st));
-        const int64_t n_items = h_tot[0];
-        *n_items_out = n_items;
-        if (h_tot[1]) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
-        if (small) memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * elt);
-        if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
-        if (n_items == 0) return LATOK_OK;
-        if (!items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
-        if (small) {
+    // where the records go: the caller's device buffers, the pinned area, or (host pointers, mid-size batch) device staging
+    // sized for the worst case of one item per char
+    void* d_counts = counts_out;
+    void* d_items = items_out;
+    int8_t* d_feat = features_out;
+    int64_t cap = items_out ? items_cap : 0;
+    if (small) {
+        d_counts = (char*)g.pin.d + po_counts;
+        d_items = (char*)g.pin.d + po_items;
+        d_feat = (int8_t*)((char*)g.pin.d + po_feat);
+        cap = total;
+    } else if (!dev) {
+        if ((rc = g.counts.ensure((size_t)n_str * 8))) return rc;
+        if ((rc = g.h_out.ensure((size_t)total * item_bytes))) return rc;
+        if (feats && (rc = g.h_aux.ensure((size_t)total * LATOK_FEATURE_COUNT))) return rc;
+        d_counts = g.counts.p;
+        d_items = g.h_out.p;
+        d_feat = (int8_t*)g.h_aux.p;
+        cap = total;
+    }
+    if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat, cap,
+                                     p_tot, h_tot, st)))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(st));   // the one synchronisation: total and flag are in pinned memory now
+    const int64_t n_items = h_tot[0];
+    *n_items_out = n_items;
+    if (h_tot[1]) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
+    const bool fits = n_items <= items_cap && (n_items == 0 || items_out);
+    if (small) {
+        memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * elt);
+        if (fits && n_items > 0) {
             memcpy(items_out, (char*)g.pin.h + po_items, (size_t)n_items * item_bytes);
             if (feats) memcpy(features_out, (char*)g.pin.h + po_feat, (size_t)n_items * LATOK_FEATURE_COUNT);
         }
-        return LATOK_OK;
+    } else if (!dev) {
+        HIP_TRY(hipMemcpyAsync(counts_out, g.counts.p, (size_t)n_str * elt, hipMemcpyDeviceToHost, st));
+        if (fits && n_items > 0) {
+            HIP_TRY(hipMemcpyAsync(items_out, g.h_out.p, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
+            if (feats) HIP_TRY(hipMemcpyAsync(features_out, g.h_aux.p, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
     }
-    // host pointers, large batch: the total sizes the device staging buffers
-    HIP_TRY(hipStreamSynchronize(st));
-    const int64_t n_items = h_tot[0];
-    *n_items_out = n_items;
-    const bool fits = n_items <= items_cap && (n_items == 0 || items_out);
-    if (fits && n_items > 0) {
-        if ((rc = g.h_out.ensure((size_t)n_items * item_bytes))) return rc;
-        if (feats && (rc = g.h_aux.ensure((size_t)n_items * LATOK_FEATURE_COUNT))) return rc;
-    }
-    if ((rc = enqueue_records(g.counts.p, fits && n_items > 0 ? g.h_out.p : nullptr, (int8_t*)g.h_aux.p, fits ? n_items : 0))) return rc;
-    HIP_TRY(hipMemcpyAsync(counts_out, g.counts.p, (size_t)n_str * elt, hipMemcpyDeviceToHost, st));
-    if (fits && n_items > 0) {
-        HIP_TRY(hipMemcpyAsync(items_out, g.h_out.p, (size_t)n_items * item_bytes, hipMemcpyDeviceToHost, st));
-        if (feats) HIP_TRY(hipMemcpyAsync(features_out, g.h_aux.p, (size_t)n_items * LATOK_FEATURE_COUNT, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
     if (n_items > items_cap) return fail(LATOK_ERR_INVALID, "output capacity too small: need %lld", (long long)n_items);
     if (n_items > 0 && !items_out) return fail(LATOK_ERR_INVALID, "output buffer is NULL");
     return LATOK_OK;
@@ -1213,6 +1377,19 @@ void* latok_dev_alloc(size_t bytes) {
 int latok_dev_free(void* p) {
     LATOK_ENTER();
     if (p) HIP_TRY(hipFree(p));
+    return LATOK_OK;
+}
+void* latok_host_alloc(size_t bytes) {
+    LATOK_ENTER();
+    void* p = nullptr;
+    if (!g.inited) { fail(LATOK_ERR_NOT_INIT, "latok_init() has not been called"); return nullptr; }
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { fail(LATOK_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int latok_host_free(void* p) {
+    LATOK_ENTER();
+    if (p) HIP_TRY(hipHostFree(p));
     return LATOK_OK;
 }
 int latok_memcpy_h2d(void* d, const void* s, size_t n) {

@@ -218,6 +218,16 @@ hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)n_blocks), dim3(kScanBlock), 0, st, out, n, block_tot);
     return hipGetLastError();
 }
+// row offsets of a chunk of a batch, uploaded as they are: subtract the chunk's first offset (chunked host pipeline)
+__global__ void k_rebase_rows(int64_t* __restrict__ row, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) row[i] -= base;
+}
+hipError_t launch_rebase_rows(int64_t* row, int64_t n, int64_t base, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rebase_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, row, n, base);
+    return hipGetLastError();
+}
 int64_t scan_blocks(int64_t n) { return n > 0 ? (n + kScanChunk - 1) / kScanChunk : 1; }
 
 // ---- UTF-8 ingest: decode a CSR batch of UTF-8 strings to packed UTF-32 on the device --------------

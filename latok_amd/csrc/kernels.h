@@ -102,6 +102,7 @@ hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1
                                const uint16_t* cw, int8_t* out, hipStream_t st);
 hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
                                int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
+hipError_t launch_rebase_rows(int64_t* row, int64_t n, int64_t base, hipStream_t st);
 int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_tot`
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,
                                  hipStream_t st, int64_t* total_host = nullptr);

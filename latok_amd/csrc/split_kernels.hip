@@ -16,8 +16,10 @@
 //            scan over lanes (forward) and a carry chain over lane ballots (backward).
 // Tiles are not string-aligned, so a block (whitespace-delimited span) may straddle tiles.  Each tile is first
 // computed assuming no pending start enters it and with a provisional decision for its open tail block, and
-// publishes a 16-byte summary; k_scan_summaries resolves the two unknowns per tile exactly and lists the (few) tiles
-// whose assumption was wrong; those are recomputed by the same tile code with the exact inputs.
+// publishes a 16-byte summary (k_tiles_main); k_resolve_fix then resolves the two unknowns per tile exactly (block-wide
+// scans over the tile summaries of a segment + the aggregates of the other segments) and repairs the few tiles whose
+// assumption was wrong: a patch of the bitmask in place for the common cases, else a recomputation by the same tile
+// code with the exact inputs.  Stage 0 (k_tile_index) gives every tile the first string that starts in it.
 //
 // No MFMA: this is integer/bit work bounded by HBM reads (4 B/char), not a contraction.
 #include <hip/hip_runtime.h>

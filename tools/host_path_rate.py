@@ -1,40 +1,80 @@
 #!/usr/bin/env python3
-"""Dev tool: PCIe-inclusive rate of the host-pointer API (H2D of the batch + pipeline + D2H of the bitmask)."""
-import sys, time
+"""PCIe-inclusive rate of the host-pointer API on C2 (1 M ASCII strings, 128 M chars): the batch starts and ends in HOST
+memory -- upload, kernels, download of the per-string counts and the records -- through the C ABI's host-pointer calls
+(large batches: the chunked three-stream pipeline of api.cpp).  One line per input form x record width x host memory
+kind; GB/s = UTF-8 bytes of the corpus / wall time of the call.  Never the `value` of bench.py (that one starts with the
+data resident in HBM); reported in DESIGN.md."""
+import ctypes as C
+import json
+import sys
+import time
+
 import numpy as np
+
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
-from latok_amd import _lib, batch
+from latok_amd import _lib, batch  # noqa: E402
+
 lib = _lib.ensure_init()
 n = 1_000_000
 row = np.zeros(n + 1, np.int64)
 lib.latok_corpus_offsets(0x1A70C0DE, 0, n, 64, 192, row.ctypes.data)
 cps = np.zeros(int(row[-1]), np.uint32)
 lib.latok_corpus_fill_host(0x1A70C0DE, 0, 0, n, row.ctypes.data, cps.ctypes.data)
-batch.split_mask_batch(cps, row)
-t = time.perf_counter()
-for _ in range(5):
-    batch.split_mask_batch(cps, row)
-dt = (time.perf_counter() - t) / 5
-print(f"host-pointer split_mask_batch: {dt * 1e3:.2f} ms per 1M-string batch = {cps.size / dt / 1e9:.2f} GB/s UTF-8 (PCIe-inclusive, pageable host memory)")
-t = time.perf_counter()
-counts, offs = batch.split_offsets_csr(cps, row)
-dt = time.perf_counter() - t
-print(f"host-pointer split_offsets_csr: {dt * 1e3:.2f} ms ({offs.size} boundaries)")
-# same batch handed over as UTF-8 (ASCII corpus: 1 byte per char over PCIe instead of 4)
+total = int(row[-1])
 u8 = cps.astype(np.uint8)
-t = time.perf_counter()
-for _ in range(3):
-    c2, o2 = batch.split_offsets_utf8_csr(u8, row)
-dt8 = (time.perf_counter() - t) / 3
-t = time.perf_counter()
-for _ in range(3):
-    c1, o1 = batch.split_offsets_csr(cps, row)
-dt32 = (time.perf_counter() - t) / 3
-assert np.array_equal(o1, o2)
-print(f"host-pointer offsets: UTF-32 input {dt32 * 1e3:.1f} ms, UTF-8 input {dt8 * 1e3:.1f} ms per 1M-string batch "
-      f"({cps.size / dt32 / 1e9:.2f} vs {cps.size / dt8 / 1e9:.2f} GB/s UTF-8, output copy of {o1.size} int64 offsets included)")
-t = time.perf_counter()
-for _ in range(5):
-    mb, mrow = batch.split_mask_utf8_csr(u8, row)
-dtm = (time.perf_counter() - t) / 5
-print(f"host-pointer split_mask from UTF-8: {dtm * 1e3:.2f} ms per batch = {cps.size / dtm / 1e9:.2f} GB/s UTF-8 (PCIe-inclusive)")
+utf8_bytes = total  # ASCII corpus
+
+
+def pinned(a):
+    p = batch.pinned_empty(a.shape, a.dtype)
+    p[...] = a
+    return p
+
+
+def timed(label, fn, lead, width, dtype, pin, reps=5):
+    """the C call alone: output arrays (sized for the result, touched once) are allocated outside the timed region"""
+    isz = np.dtype(dtype).itemsize
+    alloc = batch.pinned_empty if pin else np.empty
+    cap = total // 4
+    counts, items = alloc(n, dtype), alloc((cap, width) if width > 1 else cap, dtype)
+    counts[...] = 0
+    items[...] = 0
+    flags = _lib.OUT_INT32 if np.dtype(dtype) == np.dtype(np.int32) else 0
+    n_out = C.c_int64(0)
+    best = None
+    for _ in range(reps + 1):
+        t = time.perf_counter()
+        _lib.check(fn(*lead, n, total, counts.ctypes.data, items.ctypes.data, cap, C.byref(n_out), flags, None))
+        dt = time.perf_counter() - t
+        best = dt if best is None or dt < best else best   # (first pass warms the library's buffers up)
+    n_items = n_out.value
+    print(json.dumps({"path": label, "records": np.dtype(dtype).name, "host_memory": "pinned" if pin else "pageable",
+                      "ms_per_batch": best * 1e3, "utf8_GBps": utf8_bytes / best / 1e9, "items": n_items,
+                      "bytes_up": int(sum(np.asarray(x).nbytes for x in lead_arrays[label])),
+                      "bytes_down": n * isz + n_items * width * isz}), flush=True)
+
+
+lead_arrays = {}
+for pin in (False, True):
+    a_cps, a_u8, a_row = (pinned(cps), pinned(u8), pinned(row)) if pin else (cps, u8, row)
+    for dtype in (np.int64, np.int32):
+        for label, fn, lead, width in (
+                ("offsets, UTF-32 in", lib.latok_split_offsets_batch, [a_cps, a_row], 1),
+                ("offsets, Latin-1 units in", lib.latok_split_offsets_kind_batch, [a_u8, 1, a_row], 1),
+                ("offsets, UTF-8 in (byte space)", lib.latok_split_offsets_utf8_bytes_batch, [a_u8, a_row], 1),
+                ("token spans, UTF-8 in (byte space)", lib.latok_token_spans_utf8_bytes_batch, [a_u8, a_row], 2)):
+            lead_arrays[label] = [x for x in lead if isinstance(x, np.ndarray)]
+            args = [x.ctypes.data if isinstance(x, np.ndarray) else x for x in lead]
+            timed(label, fn, args, width, dtype, pin)
+# the bitmask only (the north-star output): 1 bit per char down
+for pin in (False, True):
+    a_u8, a_row = (pinned(u8), pinned(row)) if pin else (u8, row)
+    bits = batch.pinned_empty((total + 63) // 64, np.uint64) if pin else np.empty((total + 63) // 64, np.uint64)
+    best = None
+    for _ in range(6):
+        t = time.perf_counter()
+        _lib.check(lib.latok_split_mask_utf8_bytes_batch(a_u8.ctypes.data, a_row.ctypes.data, n, total, bits.ctypes.data, 0, None))
+        dt = time.perf_counter() - t
+        best = dt if best is None or dt < best else best
+    print(json.dumps({"path": "mask, UTF-8 in (byte space)", "host_memory": "pinned" if pin else "pageable",
+                      "ms_per_batch": best * 1e3, "utf8_GBps": utf8_bytes / best / 1e9}), flush=True)

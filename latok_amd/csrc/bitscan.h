@@ -52,5 +52,22 @@ __device__ __forceinline__ int64_t prev_zero_end(const uint64_t* __restrict__ bi
     return from;
 }
 
+// bits of word w that lie inside the batch
+__device__ __forceinline__ uint64_t valid_mask(int64_t w, int64_t total) {
+    const int64_t remain = total - (w << 6);
+    return remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
+}
+
+__device__ __forceinline__ bool tail_has_nonspace(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                                                  int64_t w, int64_t n_words, int64_t total) {
+    for (int64_t v = w + 1; v < n_words; ++v) {
+        const uint64_t xb = bits[v];
+        const uint64_t nn = ~space[v] & valid_mask(v, total);
+        if (xb) return (nn & ((xb & (~xb + 1ull)) - 1ull)) != 0;
+        if (nn) return true;
+    }
+    return false;
+}
+
 }  // namespace latok
 #endif

@@ -28,22 +28,6 @@ namespace latok {
 // SPANS = false: items = boundary bits.  SPANS = true: items = boundaries whose token is kept; the kept-mask word is
 // stored for the later passes.  A token is kept iff it holds a non-SPACE char; for all but the last boundary of a
 // word that is a mask test inside the word, the last one looks ahead until the next boundary (normally the next word).
-__device__ __forceinline__ uint64_t valid_mask(int64_t w, int64_t total) {
-    const int64_t remain = total - (w << 6);
-    return remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
-}
-
-__device__ __forceinline__ bool tail_has_nonspace(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
-                                                  int64_t w, int64_t n_words, int64_t total) {
-    for (int64_t v = w + 1; v < n_words; ++v) {
-        const uint64_t xb = bits[v];
-        const uint64_t nn = ~space[v] & valid_mask(v, total);
-        if (xb) return (nn & ((xb & (~xb + 1ull)) - 1ull)) != 0;
-        if (nn) return true;
-    }
-    return false;
-}
-
 // One wave per 4096-char tile, lane = word: the tile's item count and every word's exclusive prefix inside its tile
 // (uint16); rank(word) = tile_rank[tile] + word_pref[word], tile_rank = exclusive scan of the tile counts (k_scan_chained).
 template <bool SPANS>

@@ -1062,7 +1062,11 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) {
             if (j < slot) {
                 const int64_t w = (T0 + k_first + j * kWPB) * 64 + lane;
+#ifdef LATOK_AB_SC1_STORES
+                if (w < n_words) __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.bits_out) + w, obuf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 if (w < n_words) P.bits_out[w] = obuf[j];
+#endif
             }
         }
         slot = 0;

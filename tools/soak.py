@@ -112,7 +112,9 @@ def main():
     ap.add_argument("--workers", type=int, default=12)
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
-    from latok_amd import batch
+    from latok_amd import _lib, batch
+    _lib.ensure_init()
+    second = _lib.Context(0)            # every other batch runs on a second context of the same device
     t_end = time.time() + args.seconds
     n_batches = n_chars = n_rules = n_spans = n_u8 = n_feat = n_kind = 0
     seed = args.seed * 1_000_003
@@ -125,18 +127,24 @@ def main():
             if time.time() < t_end:
                 pending.append(pool.apply_async(make_batch, (seed,)))
                 seed += 1
-            tag = f"seed {sd} kind {kind} n_str {len(row) - 1} chars {cps.size}"
+            dt = np.int32 if (sd >> 1) & 1 else np.int64      # record width of the compaction calls (LATOK_OUT_INT32)
+            tag = f"seed {sd} kind {kind} n_str {len(row) - 1} chars {cps.size} records {np.dtype(dt).name} ctx {sd & 1}"
+            if sd & 1:
+                second.make_current()
+            else:
+                _lib.load().latok_ctx_set_current(None)
             gv = batch.split_values_batch(cps, row)
             assert np.array_equal(gv, vals), "values differ: " + tag
             gb = batch.split_mask_batch(cps, row)
             assert np.array_equal(gb, bits), "bitmask differs: " + tag
-            counts, offs = batch.split_offsets_csr(cps, row)
+            counts, offs = batch.split_offsets_csr(cps, row, dtype=dt)
+            assert counts.dtype == offs.dtype == dt
             exp = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(row) - 1)]
             assert np.array_equal(counts, [len(e) for e in exp]), "offset counts differ: " + tag
             assert np.array_equal(offs, np.concatenate(exp) if exp else np.zeros(0, np.int64)), "offsets differ: " + tag
             if cps.size < 20000:
                 wc, ws = spans_from(vals, space, row)
-                gc, gs = batch.token_spans_csr(cps, row)
+                gc, gs = batch.token_spans_csr(cps, row, dtype=dt)
                 assert np.array_equal(gc, wc) and np.array_equal(gs, ws), "token spans differ: " + tag
                 n_spans += 1
             if rules is not None:
@@ -148,7 +156,7 @@ def main():
                 assert np.array_equal(rb, rule_bits), "rule-table bitmask differs: " + tag
                 n_rules += 1
             if feats is not None and cps.size > 0:
-                fc, fs, ff = batch.token_features_csr(cps, row)
+                fc, fs, ff = batch.token_features_csr(cps, row, dtype=dt)
                 assert ff.shape == feats[0].shape and np.array_equal(ff, feats[0]), "featurize sums differ: " + tag
                 assert np.array_equal(fs, feats[1]), "featurize span records differ: " + tag
                 n_feat += 1
@@ -156,10 +164,10 @@ def main():
                 # PEP 393 kinds: the same text as 1- or 2-byte code units
                 units = cps.astype(np.uint8 if int(cps.max()) < 256 else np.uint16)
                 assert np.array_equal(batch.split_mask_kind_csr(units, row), bits), "kind bitmask differs: " + tag
-                kc, ko = batch.split_offsets_kind_csr(units, row)
+                kc, ko = batch.split_offsets_kind_csr(units, row, dtype=dt)
                 assert np.array_equal(kc, counts) and np.array_equal(ko, offs), "kind offsets differ: " + tag
                 if cps.size < 20000:
-                    kc, ks = batch.token_spans_kind_csr(units, row)
+                    kc, ks = batch.token_spans_kind_csr(units, row, dtype=dt)
                     assert np.array_equal(kc, wc) and np.array_equal(ks, ws), "kind token spans differ: " + tag
                 if rules is not None:
                     batch.set_rules(*rules)
@@ -169,7 +177,7 @@ def main():
                         batch.reset_rules()
                     assert np.array_equal(rb, rule_bits), "kind rule-table bitmask differs: " + tag
                 if feats is not None:
-                    fc, fs, ff = batch.token_features_kind_csr(units, row)
+                    fc, fs, ff = batch.token_features_kind_csr(units, row, dtype=dt)
                     assert np.array_equal(ff, feats[0]) and np.array_equal(fs, feats[1]), "kind featurize differs: " + tag
                 n_kind += 1
             if u8 is not None and cps.size > 0:
@@ -179,7 +187,7 @@ def main():
                 bb = batch.split_mask_utf8_bytes_csr(u8, boff)
                 got = np.unpackbits(bb.view(np.uint8), bitorder="little")[:u8.size].astype(bool)
                 assert np.array_equal(got, flags), "byte-space bitmask differs: " + tag
-                bc, bo = batch.split_offsets_utf8_bytes_csr(u8, boff)
+                bc, bo = batch.split_offsets_utf8_bytes_csr(u8, boff, dtype=dt)
                 exp_b = [bpos[row[s]:row[s + 1]][vals[row[s]:row[s + 1]] != 0] - boff[s] for s in range(len(row) - 1)]
                 assert np.array_equal(bc, [len(e) for e in exp_b]), "byte offset counts differ: " + tag
                 assert np.array_equal(bo, np.concatenate(exp_b)), "byte offsets differ: " + tag
@@ -192,7 +200,9 @@ def main():
                 last = time.time()
                 print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8, {n_feat} featurize, {n_kind} PEP 393 kinds ... ok",
                       flush=True)
-    print(f"soak passed: {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
+    _lib.load().latok_ctx_set_current(None)
+    second.destroy()
+    print(f"soak passed (two contexts alternating, int32 / int64 records alternating): {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
           f"{n_u8} UTF-8 (byte space + code-point) checks, {n_feat} featurize checks, {n_kind} PEP 393 kind checks, {args.seconds:.0f} s")
 
 

@@ -3,6 +3,7 @@
 A batch is CSR: ``cps`` = packed UTF-32 code points of all strings, ``row_off[n+1]`` = start of each string.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -122,6 +123,33 @@ def split_offsets_csr(cps, row_off, dtype=np.int64):
 # host batches beyond the library's small-batch path (api.cpp: kSmallChars / kSmallStrings, served from pinned memory
 # in UTF-32) are shipped as the narrowest PEP 393 kind: 1 or 2 bytes per char over the bus instead of 4
 _SMALL_CHARS, _SMALL_STRINGS = 16384, 512
+
+
+_ROW1 = None
+
+
+def split_offsets_one(text: str) -> np.ndarray:
+    """np.nonzero(split mask)[0] of ONE non-empty string with as little Python around the C call as possible (the drop-in
+    tokenize(text) surface): a string of at most 4096 chars is one single-wave launch and one synchronisation in the
+    library; what is left here is the UTF-32 encode and two small arrays."""
+    global _ROW1
+    n = len(text)
+    if n > _SMALL_CHARS:
+        return split_offsets_batch([text])[0]
+    lib = _lib.ensure_init()
+    cps = np.frombuffer(text.encode("utf-32-le", "surrogatepass"), dtype="<u4")
+    if _ROW1 is None:
+        _ROW1 = threading.local()
+    row = getattr(_ROW1, "row", None)
+    if row is None:
+        row = _ROW1.row = np.zeros(2, np.int64)
+        _ROW1.count = np.zeros(1, np.int32)
+        _ROW1.n = C.c_int64(0)
+    row[1] = n
+    offs = np.empty(n, np.int32)
+    _lib.check(lib.latok_split_offsets_batch(cps.ctypes.data, row.ctypes.data, 1, n, _ROW1.count.ctypes.data, offs.ctypes.data, n,
+                                             C.byref(_ROW1.n), _lib.OUT_INT32, None))
+    return offs[:_ROW1.n.value]
 
 
 def _record_dtype(row_off):

@@ -91,7 +91,7 @@ def _boundaries(text: str) -> np.ndarray:
         # the reference fails at ``splits[0] = 1`` on an empty array (default_tokenizer.py:132)
         raise IndexError("index 0 is out of bounds for axis 0 with size 0")
     _sync_rules()
-    return _batch.split_offsets_batch([text])[0]
+    return _batch.split_offsets_one(text)
 
 
 def _spans(text: str, non_zero):

@@ -979,9 +979,26 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         d_feat = (int8_t*)g.h_aux.p;
         cap = total;
     }
-    if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat, cap,
-                                     p_tot, h_tot, st)))
+    if (small && !feats && total <= latok::kTile) {
+        // at most one tile (tokenize(text): one string per call): one single-wave launch does everything
+        latok::SplitParams P;
+        memset(&P, 0, sizeof(P));
+        P.cps = d_cps;
+        P.row_off = d_row;
+        P.n_str = n_str;
+        P.total = total;
+        P.n_tiles = 1;
+        const uint8_t* tables = (const uint8_t*)(g.rules_on ? g.t1rule.p : g.t1.p);
+        P.t1 = tables;
+        P.t2 = tables + latok::kStage1Pad;
+        if (g.rules_on) P.rules = g.rules;
+        h_tot[0] = 0;
+        h_tot[1] = 0;
+        HIP_TRY(latok::launch_small_batch(P, g.rules_on, spans ? 1 : 0, o32, d_counts, d_items, p_tot, st));
+    } else if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
+                                            cap, p_tot, h_tot, st))) {
         return rc;
+    }
     HIP_TRY(hipStreamSynchronize(st));   // the one synchronisation: total and flag are in pinned memory now
     const int64_t n_items = h_tot[0];
     *n_items_out = n_items;

@@ -1748,6 +1748,151 @@ hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Small batches in ONE launch (the drop-in tokenize(text) surface: one string per call).  A batch of at most one tile
+// (4096 chars) needs no tile index, no resolve stage and no device-wide scan: a single wave classifies it, runs the
+// tile function -- whose two provisional assumptions are exact here: nothing enters the batch's first tile, and the
+// batch ends inside it or at its end --, counts, ranks and scatters.  What was six dependent launches (~45 us of launch
+// latency for ~2 us of work) is one.  Inputs and outputs live in pinned host memory the kernel reads and writes over
+// the bus (api.cpp), the class tables are read from global memory (they sit in L2; the 41 KB LDS copy would cost more
+// than the few hundred lookups).
+// ---------------------------------------------------------------------------------------------------------------
+struct SmallParams {
+    SplitParams P;          // cps, row_off, n_str, total (<= kTile), t1 / t2 (global memory), rules
+    void* counts;           // OUT[n_str]
+    void* items;            // KIND 0: OUT[n_items] offsets; KIND 1: OUT[n_items][2] stripped token spans
+    int64_t* n_items;       // [1]
+};
+
+template <int MODE, int KIND, typename OUT>
+__global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWaveLdsBytes];
+    __shared__ uint64_t s_bits[66], s_space[66], s_items[66];
+    __shared__ int s_pref[66];
+    const int lane = threadIdx.x;
+    TileLds L;
+    L.t1 = S.P.t1;          // global memory
+    L.t2 = S.P.t2;
+    L.lut = L.ctab = nullptr;
+    L.stage = lds;
+    L.halo = lds + kStageBytes;
+    L.bw = reinterpret_cast<lk_u64*>(lds + kStageBytes + 16);
+    s_bits[lane] = 0ull;
+    s_space[lane] = ~0ull;   // positions behind the batch read as SPACE
+    if (lane < 2) { s_bits[64 + lane] = 0ull; s_space[64 + lane] = ~0ull; }
+    SplitParams P = S.P;
+    P.bits_out = s_bits;     // (generic pointers into LDS: the tile function stores its words there)
+    P.space_out = KIND == 1 ? s_space : nullptr;
+    wave_lds_sync();
+    const int64_t total = P.total, n_str = P.n_str;
+    const int64_t n_words = (total + 63) >> 6;
+    const lk_u64 xb = process_tile<MODE, false>(P, L, 0, 0, 0, -1, false, nullptr, lane);   // boundaries of my word
+    wave_lds_sync();
+    const int64_t base = 64 * (int64_t)lane;
+    // ---- which boundaries are items (spans: those whose token holds a non-SPACE char), like k_word_counts -------------
+    lk_u64 x = xb;
+    const lk_u64 nn = KIND == 1 ? (~s_space[lane] & valid_mask(lane, total)) : 0ull;
+    lk_u64 xb1 = 0, nn1 = 0;
+    if (KIND == 1) {
+        xb1 = __shfl_down(xb, 1);
+        nn1 = __shfl_down(nn, 1);
+        if (lane == 63) { xb1 = 0; nn1 = 0; }
+        bool cin;
+        if (xb1) cin = (nn1 & ((xb1 & (~xb1 + 1ull)) - 1ull)) != 0;
+        else cin = nn1 != 0 || (xb != 0 && lane + 1 < n_words && tail_has_nonspace(s_bits, s_space, lane + 1, n_words, total));
+        const lk_u64 xr = __builtin_bitreverse64(xb), nr = __builtin_bitreverse64(nn);
+        const lk_u64 g = nr & ~xr, pr = ~xr;
+        const lk_u64 a = pr | g;
+        const lk_u64 carries = (a + g + (cin ? 1ull : 0ull)) ^ a ^ g;
+        x = __builtin_bitreverse64(xr & (nr | carries));
+    }
+    const int cnt = lk_popc(x);
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const int n_items = __shfl(inc, 63);
+    s_items[lane] = x;
+    s_pref[lane] = inc - cnt;
+    if (lane == 0) { s_items[64] = 0ull; s_pref[64] = n_items; *S.n_items = n_items; }
+    wave_lds_sync();
+    // ---- per-string counts: rank(end) - rank(start) ----------------------------------------------------------------
+    OUT* counts = reinterpret_cast<OUT*>(S.counts);
+    auto rank_of = [&](int64_t p) -> int {
+        if (p >= total) return n_items;
+        return s_pref[p >> 6] + lk_popc(s_items[p >> 6] & low_mask((int)(p & 63)));
+    };
+    for (int64_t s = lane; s < n_str; s += 64) counts[s] = (OUT)(rank_of(P.row_off[s + 1]) - rank_of(P.row_off[s]));
+    // ---- where the string that owns a position begins: last string start at or before it (L.bw: the tile's string starts)
+    const lk_u64 Bw = L.bw[lane];
+    int carry = Bw ? 64 * lane + 63 - __builtin_clzll(Bw) : -1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(carry, d);
+        if (lane >= d && o > carry) carry = o;
+    }
+    carry = __shfl_up(carry, 1);
+    if (lane == 0) carry = -1;
+    const int64_t lo_in = carry >= 0 ? carry : 0;
+    // ---- the records, word-major: lane = word walks its items -------------------------------------------------------
+    OUT* out = reinterpret_cast<OUT*>(S.items);
+    lk_u64 rest = x;
+    int k = inc - cnt;
+    while (rest) {
+        const int b = lk_ctz(rest);
+        rest &= rest - 1;
+        const lk_u64 bl = Bw & ((2ull << b) - 1ull);      // string starts at or before the item (b = 63: all)
+        const int64_t lo = bl ? base + 63 - __builtin_clzll(bl) : lo_in;
+        if (KIND == 0) {
+            out[k] = (OUT)(base + b - lo);
+        } else {
+            const lk_u64 above = xb & (~1ull << b);
+            int64_t a2, e2;
+            if (above) {
+                const int eb = lk_ctz(above);
+                const lk_u64 seg = nn & (~0ull << b) & ((1ull << eb) - 1ull);
+                a2 = base + lk_ctz(seg);
+                e2 = base + 64 - __builtin_clzll(seg);
+            } else if (xb1) {
+                const int eb = lk_ctz(xb1);
+                const lk_u64 seg0 = nn & (~0ull << b);
+                const lk_u64 seg1 = nn1 & ((1ull << eb) - 1ull);
+                a2 = seg0 ? base + lk_ctz(seg0) : base + 64 + lk_ctz(seg1);
+                e2 = seg1 ? base + 128 - __builtin_clzll(seg1) : base + 64 - __builtin_clzll(seg0);
+            } else {
+                const int64_t e = next_set_bit(s_bits, base + 64, total);
+                const lk_u64 seg = nn & (~0ull << b);
+                a2 = seg ? base + lk_ctz(seg) : next_zero_bit(s_space, base + 64, e);
+                e2 = prev_zero_end(s_space, a2, e);
+            }
+            out[2 * k] = (OUT)(a2 - lo);
+            out[2 * k + 1] = (OUT)(e2 - lo);
+        }
+        ++k;
+    }
+}
+
+hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int64_t* n_items,
+                              hipStream_t st) {
+    SmallParams S;
+    S.P = P;
+    S.counts = counts;
+    S.items = items;
+    S.n_items = n_items;
+#define LATOK_SB(M, K, T) hipLaunchKernelGGL((k_small_batch<M, K, T>), dim3(1), dim3(64), 0, st, S)
+    if (rules) {
+        if (kind == 0) { if (out32) LATOK_SB(kModeRules, 0, int32_t); else LATOK_SB(kModeRules, 0, int64_t); }
+        else { if (out32) LATOK_SB(kModeRules, 1, int32_t); else LATOK_SB(kModeRules, 1, int64_t); }
+    } else {
+        if (kind == 0) { if (out32) LATOK_SB(kModeBits, 0, int32_t); else LATOK_SB(kModeBits, 0, int64_t); }
+        else { if (out32) LATOK_SB(kModeBits, 1, int32_t); else LATOK_SB(kModeBits, 1, int64_t); }
+    }
+#undef LATOK_SB
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import ALPHABETS, pack, random_strings
+from conftest import ALPHABETS, bits_to_bool, pack, random_strings
 
 pytestmark = pytest.mark.gpu
 
@@ -139,3 +139,58 @@ def test_string_too_long_for_int32(gpu):
     assert n_out.value == 2 and out.tolist() == [0, 0]      # "aaa...": one boundary per string, at its start
     for p in (d_units, d_row, d_counts, d_out):
         gpu.latok_dev_free(p)
+
+
+def test_one_tile_batches_single_launch(gpu, oracle):
+    """host batches of at most one tile (4096 chars) -- what tokenize(text) sends -- are served by ONE single-wave launch
+    (k_small_batch: tile function + counts + ranks + scatter); everything around the 4096-char and 512-string limits of
+    that path, offsets and spans, both record widths, built-in and run-time rule tables, against the oracle."""
+    from conftest import RULE_SETS, oracle_rule_bits
+    from latok_amd import batch
+    rng = random.Random(4096)
+
+    def check(texts, rules=None):
+        cps, row = pack(texts)
+        if rules is None:
+            vals, _ = oracle.split_batch(cps, row, want_bits=False)
+            flags = vals != 0
+        else:
+            flags = bits_to_bool(oracle_rule_bits(oracle, texts, rules), int(row[-1]))
+        want = [np.nonzero(flags[row[s]:row[s + 1]])[0] for s in range(len(texts))]
+        for dt in (np.int64, np.int32):
+            c, o = batch.split_offsets_csr(cps, row, dtype=dt)
+            assert np.array_equal(c, [len(w) for w in want]) and np.array_equal(o, np.concatenate(want) if want else np.zeros(0))
+        if rules is None:
+            toks = batch.tokenize_batch(texts)
+            assert toks == [oracle.tokenize(t) if t else [] for t in texts]
+            c64, s64 = batch.token_spans_csr(cps, row)
+            c32, s32 = batch.token_spans_csr(cps, row, dtype=np.int32)
+            assert np.array_equal(c64, c32) and np.array_equal(s64, s32)
+            assert [[t[a:b] for a, b in s64[i0:i0 + n].tolist()] for t, i0, n in
+                    zip(texts, np.concatenate([[0], np.cumsum(c64)[:-1]]).tolist(), c64.tolist())] == toks
+
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 4094, 4095, 4096):
+        check(["".join(rng.choice(ALPHABETS["mixed"]) for _ in range(n))])
+        check(["x" * (n - 1) + " "])
+    check(["http://" + "a" * 4089])                                  # one masked token that fills the tile exactly
+    check(["a" * 4090 + " #tag"])
+    check([" " * 4096])
+    for _ in range(30):
+        n_str = rng.choice([1, 2, 5, 64, 65, 200, 511, 512])
+        budget = rng.choice([50, 700, 4096])
+        texts, used = [], 0
+        for _ in range(n_str):
+            ln = rng.randint(0, max(0, min(60, budget - used)))
+            texts.append("".join(rng.choice(ALPHABETS[rng.choice(["mixed", "starts", "words"])]) for _ in range(ln)))
+            used += len(texts[-1])
+        texts = [t[:max(0, 4096)] for t in texts]
+        while sum(len(t) for t in texts) > 4096:
+            texts.pop()
+        check(texts)
+    for name in ("sym_everywhere", "all_starts", "no_mask"):
+        batch.set_rules(*RULE_SETS[name])
+        try:
+            for _ in range(5):
+                check(random_strings(rng, rng.randint(1, 40), 0, 90, ALPHABETS["mixed"]), RULE_SETS[name])
+        finally:
+            batch.reset_rules()

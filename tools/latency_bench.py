@@ -20,3 +20,17 @@ m = dt._gen_parse_matrix(text)
 timeit("gen_split_mask(m) [compat kernels]", lambda: dt.gen_split_mask(m), 100)
 texts = [text] * 1000
 timeit("tokenize_batch(1000 strings)", lambda: batch.tokenize_batch(texts), 20)
+# the C call alone (arrays prebuilt): what a C / Cython caller of the ABI pays per string
+import ctypes as C
+from latok_amd import _lib
+lib = _lib.ensure_init()
+cps, row = batch.pack([text])
+counts = np.zeros(1, np.int64); offs = np.empty(len(text), np.int64); n_out = C.c_int64(0)
+args = (cps.ctypes.data, row.ctypes.data, 1, len(text), counts.ctypes.data, offs.ctypes.data, offs.size, C.byref(n_out), 0, None)
+timeit("latok_split_offsets_batch, 1 string (C ABI)", lambda: lib.latok_split_offsets_batch(*args), 2000)
+timeit("latok_token_spans_batch, 1 string (C ABI)", lambda: lib.latok_token_spans_batch(*args), 2000)
+c32 = np.zeros(1, np.int32); o32 = np.empty(2 * len(text), np.int32)
+a32 = (cps.ctypes.data, row.ctypes.data, 1, len(text), c32.ctypes.data, o32.ctypes.data, len(text), C.byref(n_out), _lib.OUT_INT32, None)
+timeit("latok_token_spans_batch, int32 (C ABI)", lambda: lib.latok_token_spans_batch(*a32), 2000)
+timeit("batch.pack([text])", lambda: batch.pack([text]), 2000)
+timeit("dt._sync_rules()", lambda: dt._sync_rules(), 2000)

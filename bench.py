@@ -198,7 +198,8 @@ def pmc_traffic(workload: str, total_chars: int):
         with open(PMC_SUMMARY) as f:
             pmc = json.load(f)
         for rec in pmc.get("runs", []):
-            if rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main" and rec.get("total_chars") == total_chars:
+            if (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
+                    and rec.get("total_chars") == total_chars):
                 return rec.get("hbm_bytes_per_launch")
     except Exception:
         pass

@@ -245,11 +245,13 @@ int latok_reset_rules(void);   /* back to the built-in default_tokenizer.py tabl
 int latok_rules_active(void);  /* 1 while custom tables are installed */
 
 /* ---- measurement ----------------------------------------------------------------------------------------------- */
-/* Run latok_split_mask_batch `iters` times on device-resident data after `warmup` untimed runs, bracketed by HIP
- * events on the stream the kernels run on.  ms_total_out = elapsed ms of the `iters` timed passes (all kernels of
- * the pipeline); ms_tiles_out = summed elapsed ms of the dominant kernel only (k_tiles_main), measured with its own
- * event pair per launch in `iters` further passes that are enqueued back to back and synchronised once; n_fix_tiles_out = tiles re-done by the fix-up stage in the last
- * pass.  Any may be NULL (a NULL output skips its passes), so warm-up-only and kernel-only calls are possible. */
+/* Run latok_split_mask_batch on device-resident data: `warmup` untimed passes, then
+ *   ms_total_out  = elapsed ms of `iters` whole-pipeline passes (tile index, tiles, resolve) between ONE pair of HIP events
+ *                   on the stream the kernels run on;
+ *   ms_tiles_out  = elapsed ms of `iters` further launches of the dominant kernel alone (k_tiles_main, back to back,
+ *                   again one event pair: an event pair per launch charges each interval with ~6 us of marker dispatch);
+ *   n_fix_tiles_out = tiles recomputed by the resolve stage in the last pass.
+ * Any may be NULL (a NULL output skips its passes), so warm-up-only and kernel-only calls are possible. */
 int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                            uint64_t* mask_dev, int warmup, int iters, float* ms_total_out, float* ms_tiles_out,
                            int64_t* n_fix_tiles_out);

@@ -734,8 +734,18 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
 // is enqueued.  Per chunk the host waits once (for its total) before it can place the chunk's records behind the
 // previous ones in the caller's arrays.  With pinned host arrays (latok_host_alloc) both copy directions run at bus
 // speed concurrently; pageable arrays work too (the runtime stages them).
-constexpr int64_t kPipeChunkChars = 8 << 20;
-constexpr int64_t kPipeMinChars = 2 * kPipeChunkChars;
+// (test hook: LATOK_PIPE_CHUNK_CHARS in the environment shrinks the chunks, so that a test can push hundreds of chunks
+// through the double buffers with batches the oracle checks in seconds)
+static int64_t pipe_chunk_chars() {
+    static const int64_t v = [] {
+        const char* e = getenv("LATOK_PIPE_CHUNK_CHARS");
+        const long long x = e ? atoll(e) : 0;
+        return (int64_t)(x >= 64 ? x : (8ll << 20));
+    }();
+    return v;
+}
+#define kPipeChunkChars (pipe_chunk_chars())
+#define kPipeMinChars (2 * pipe_chunk_chars())
 
 static int ensure_pipe(Ctx& g) {
     if (g.s_h2d) return LATOK_OK;
@@ -749,9 +759,32 @@ static int ensure_pipe(Ctx& g) {
     return LATOK_OK;
 }
 
+static int compact_host_pipelined_body(Ctx& g, bool spans, bool feats, bool o32, const void* data, size_t unit_bytes, int unit_kind,
+                                       bool as_u8, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
+                                       void* items_out, int64_t items_cap, int64_t* n_items_out, int8_t* features_out,
+                                       hipStream_t st);
+
 static int compact_host_pipelined(Ctx& g, bool spans, bool feats, bool o32, const void* data, size_t unit_bytes, int unit_kind,
                                   bool as_u8, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
                                   void* items_out, int64_t items_cap, int64_t* n_items_out, int8_t* features_out, hipStream_t st) {
+    const int rc = compact_host_pipelined_body(g, spans, feats, o32, data, unit_bytes, unit_kind, as_u8, row_off, n_str, total,
+                                               counts_out, items_out, items_cap, n_items_out, features_out, st);
+    if (rc != LATOK_OK && g.s_h2d) {
+        // a failure in the middle leaves copies in flight that read and write the CALLER's arrays: drain them before the
+        // error is returned (the message of the failure is kept)
+        const std::string msg = g_err;
+        (void)hipStreamSynchronize(g.s_h2d);
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(g.s_d2h);
+        g_err = msg;
+    }
+    return rc;
+}
+
+static int compact_host_pipelined_body(Ctx& g, bool spans, bool feats, bool o32, const void* data, size_t unit_bytes, int unit_kind,
+                                       bool as_u8, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
+                                       void* items_out, int64_t items_cap, int64_t* n_items_out, int8_t* features_out,
+                                       hipStream_t st) {
     int rc;
     if ((rc = ensure_pipe(g))) return rc;
     const size_t elt = o32 ? 4 : 8;

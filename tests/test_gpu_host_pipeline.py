@@ -104,3 +104,50 @@ def test_pipelined_with_pinned_arrays_and_small_capacity(gpu):
     assert rc == _lib.ERR_INVALID and n_out.value == n and np.array_equal(counts, want[0])
     assert (items[n // 2:] == -5).all()
     del got, p_cps, p_row
+
+
+def test_hundreds_of_tiny_chunks_against_the_oracle():
+    """the same pipeline with 4 K-char chunks (test hook LATOK_PIPE_CHUNK_CHARS): every double-buffer hand-over, the
+    rebasing of the row offsets, chunks that are one long string, chunks of empty strings -- a few hundred chunks per
+    batch, every record kind, checked against the oracle.  Runs in a process of its own (the hook is read once)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import random, sys, numpy as np
+sys.path[:0] = [%r, %r + "/oracle", %r + "/tests"]
+from conftest import ALPHABETS, pack, random_strings
+from latok_amd import batch
+import latok_oracle as orc
+rng = random.Random(2024)
+for rep in range(6):
+    texts = random_strings(rng, rng.randint(2000, 6000), 0, 300, ALPHABETS[rng.choice(["mixed", "words", "starts"])])
+    texts[rng.randrange(len(texts))] = "".join(rng.choice(ALPHABETS["rare_space_at"]) for _ in range(30000))   # >> one chunk
+    for k in range(0, len(texts), 700):
+        texts[k:k + 40] = [""] * 40                                                                           # runs of empties
+    cps, row = pack(texts)
+    assert int(row[-1]) > 40 * 4096
+    vals, _ = orc.split_batch(cps, row, want_bits=False)
+    want = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(texts))]
+    for dt in (np.int64, np.int32):
+        c, o = batch.split_offsets_csr(cps, row, dtype=dt)
+        assert np.array_equal(c, [len(w) for w in want]) and np.array_equal(o, np.concatenate(want)), (rep, dt)
+    toks = batch.tokenize_batch(texts)
+    assert toks == [orc.tokenize(t) if t else [] for t in texts], rep
+    u8 = cps.astype(np.uint8) if int(cps.max()) < 256 else None
+    fc, fs, ff = batch.token_features_csr(cps, row, dtype=np.int32)
+    k = 0
+    for t, n in zip(texts, fc.tolist()):
+        if n and len(t) < 400:
+            m = orc.gen_parse_matrix(t).astype(np.uint8)
+            for a, b, _, _ in fs[k:k + n].tolist():
+                assert np.array_equal(ff[k], m[a:b].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8)), (rep, t[:30])
+                k += 1
+        else:
+            k += n
+print("ok")
+''' % (ROOT, ROOT, ROOT)
+    env = dict(os.environ, LATOK_PIPE_CHUNK_CHARS="4096")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=800, env=env)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-3000:])

@@ -47,8 +47,10 @@ int fail(int code, const char* fmt, ...) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    unsigned gen = 0;   // counts (re)allocations: fresh memory holds anything
     int ensure(size_t bytes) {
         if (bytes <= cap) return LATOK_OK;
+        ++gen;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -128,6 +130,7 @@ struct Ctx {
     DevBuf chain, chain_ctl;   // k_word_counts_scan: look-back state per workgroup, {ticket counter}
     unsigned scan_epoch = 0;
     bool chain_ready = false;
+    unsigned chain_seen = 0, chain_ctl_seen = 0;   // DevBuf::gen of the allocations the state was last cleared in
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
@@ -353,6 +356,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.turn_event = nullptr;
     g.turn_stream_valid = false;
     g.chain_ready = false;
+    g.chain_seen = g.chain_ctl_seen = 0;
     g.scan_epoch = 0;
     for (int i = 0; i < 2; ++i) {
         for (DevBuf* b : {&g.pipe_in[i], &g.pipe_row[i], &g.pipe_counts[i], &g.pipe_items[i], &g.pipe_feat[i]}) b->release();
@@ -647,11 +651,13 @@ static int enqueue_features(Ctx& g, const uint8_t* d_codes, const int64_t* d_row
 // cleared only when it is (re)allocated or when the 18-bit epoch wraps
 static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* epoch_out) {
     int rc;
-    const size_t old_cap = g.chain.cap;
     if ((rc = g.chain.ensure((size_t)n_blocks * 8 + 64))) return rc;
     if ((rc = g.chain_ctl.ensure(64))) return rc;
     g.scan_epoch = (g.scan_epoch + 1) & 0x3FFFFu;
-    if (g.chain.cap != old_cap || g.scan_epoch == 0 || !g.chain_ready) {
+    // (the state array may have been re-allocated by this call or by an earlier reserve: fresh memory holds anything)
+    if (g.chain.gen != g.chain_seen || g.chain_ctl.gen != g.chain_ctl_seen || g.scan_epoch == 0 || !g.chain_ready) {
+        g.chain_seen = g.chain.gen;
+        g.chain_ctl_seen = g.chain_ctl.gen;
         HIP_TRY(hipMemsetAsync(g.chain.p, 0, g.chain.cap, st));
         HIP_TRY(hipMemsetAsync(g.chain_ctl.p, 0, 64, st));
         g.scan_epoch = 1;

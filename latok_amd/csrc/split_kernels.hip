@@ -771,8 +771,13 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+#ifdef LATOK_AB_PLAIN_LOADS
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = src[64 * i];
+#else
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+#endif
         LATOK_STAMP(1);
         uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;   // wave-uniform
 #pragma unroll

@@ -75,13 +75,16 @@ def _sync_rules():
     cur = (np.asarray(C_SPLIT), np.asarray(C_MASK), np.asarray(C_SYM))
     custom = not all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cur, _BUILTIN))
     have = _installed.get(key)
+    if have is not None and not _batch.rules_active():
+        have = None                     # (a new context at the address of a destroyed one, or an explicit reset_rules)
+        _installed.pop(key, None)
     if custom:
         if have is None or not all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cur, have)):
             _batch.set_rules(*cur)
             _installed[key] = tuple(np.array(x, copy=True) for x in cur)
     elif have is not None:
         _batch.reset_rules()
-        del _installed[key]
+        _installed.pop(key, None)
 
 
 def _boundaries(text: str) -> np.ndarray:

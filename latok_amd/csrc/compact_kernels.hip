@@ -319,13 +319,28 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
     int k = off;                                                    // wave rank of my next item
     if (KIND == 0) {
         // offsets are one subtraction per item: here the word-major loop through an LDS window is the faster form
+        // Every string start is itself a boundary (splits[0] = 1), so the walk over a word's items meets the string starts
+        // in passing: `cur` = offset of the word's bit 0 relative to the string the walk is in -- base - lo_in on entry,
+        // -b once the item at bit b is a string start.  32-bit halves: no 64-bit shifts, masks or clz in the loop (the
+        // former form -- mask the string starts below the item, clz -- was 3x the instructions).
         const int64_t base = w << 6;
+        uint32_t r0 = (uint32_t)rest, r1 = (uint32_t)(rest >> 32);
+        const uint32_t B0 = (uint32_t)Bw, B1 = (uint32_t)(Bw >> 32);
+        OUT cur = (OUT)(base - lo_in);
         for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
-            while (rest && k < win0 + kCodes) {
-                const int b = __builtin_ctzll(rest);
-                rest &= rest - 1;
-                const uint64_t bl = Bw & ((2ull << b) - 1ull);
-                win[k - win0] = (OUT)(base + b - (bl ? base + 63 - __builtin_clzll(bl) : lo_in));
+            const int lim = win0 + kCodes;
+            while (r0 && k < lim) {
+                const int b = __builtin_ctz(r0);
+                r0 &= r0 - 1u;
+                if ((B0 >> b) & 1u) cur = (OUT)(-b);
+                win[k - win0] = (OUT)(cur + b);
+                ++k;
+            }
+            while (!r0 && r1 && k < lim) {
+                const int b = __builtin_ctz(r1);
+                r1 &= r1 - 1u;
+                if ((B1 >> b) & 1u) cur = (OUT)(-(32 + b));
+                win[k - win0] = (OUT)(cur + 32 + b);
                 ++k;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -166,3 +166,23 @@ def test_rebinding_the_module_level_tables_changes_tokenize(gpu, oracle):
     finally:
         dt.C_SPLIT, dt.C_MASK, dt.C_SYM = saved
     assert list(dt.tokenize(text)) == base and not batch.rules_active()
+
+
+def test_contexts_come_and_go(gpu, oracle):
+    """contexts (and pools) are created and destroyed many times: every one gets working tables / workspaces of its own,
+    nothing is left behind that breaks the next one or the default context"""
+    from latok_amd import _lib, batch, multi
+    texts = ["a http://b.c/d e@f.gh #i camelCase 1 2", "", "日本語 テキスト"] * 50
+    cps, row = pack(texts)
+    _, want = oracle.split_batch(cps, row, want_values=False)
+    free0 = None
+    for i in range(40):
+        with _lib.Context(0) as ctx:
+            assert np.array_equal(batch.split_mask_batch(cps, row), want)
+            c, o = batch.split_offsets_csr(cps, row, dtype=np.int32)
+            assert int(c.sum()) == len(o)
+        ctx.destroy()
+        if i % 10 == 9:
+            with multi.DevicePool([0, 0]) as pool:
+                assert np.array_equal(multi.split_mask_batch(cps, row, pool), want)
+    assert np.array_equal(batch.split_mask_batch(cps, row), want)

@@ -366,6 +366,13 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
         }
         return;
     }
+    // the lanes' masks as 48-byte rows in LDS (behind the codes): in the token-major loop lane j reads the row of the
+    // word that owns its item with three 16-byte reads (six 64-bit shuffles = twelve ds_bpermute before)
+    uint64_t* rows = reinterpret_cast<uint64_t*>(buf_s[wave]) + (kCodes * 2) / 8;     // codes take kCodes * 2 bytes
+    {
+        uint64_t* r = rows + 6 * lane;
+        r[0] = xb; r[1] = nn; r[2] = xb1; r[3] = nn1; r[4] = Bw; r[5] = (uint64_t)lo_in;
+    }
     for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
         while (rest && k < win0 + kCodes) {
             const int b = __builtin_ctzll(rest);
@@ -381,15 +388,9 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
             const bool active = j < n_here;
             const int code = active ? (int)codes[j] : 0;
             const int owner = code >> 6, b = code & 63;
-            const uint64_t o_Bw = __shfl(Bw, owner);
-            const int64_t o_lo_in = __shfl(lo_in, owner);
-            uint64_t o_xb = 0, o_nn = 0, o_xb1 = 0, o_nn1 = 0;
-            if (KIND != 0) {
-                o_xb = __shfl(xb, owner);
-                o_nn = __shfl(nn, owner);
-                o_xb1 = __shfl(xb1, owner);
-                o_nn1 = __shfl(nn1, owner);
-            }
+            const uint64_t* orow = rows + 6 * owner;
+            const uint64_t o_xb = orow[0], o_nn = orow[1], o_xb1 = orow[2], o_nn1 = orow[3], o_Bw = orow[4];
+            const int64_t o_lo_in = (int64_t)orow[5];
             if (active) {
                 const int64_t obase = (w0 + owner) << 6;
                 const uint64_t bl = o_Bw & ((2ull << b) - 1ull);      // string starts at or before the item (b = 63: all)

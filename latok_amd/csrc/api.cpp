@@ -722,7 +722,7 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
     int64_t* d_total = (int64_t*)g.scalar.p;
     int* d_err = (int*)(p_tot + 1);
     HIP_TRY(latok::launch_word_counts_scan(spans, d_bits, d_space, words, total, d_kept, d_tcnt, d_pref, d_rank,
-                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, st));
+                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, d_err + 1, st));   // (the scan's own flag: the upper half of the pinned word)
     if (feats) {   // spans and sums come from one kernel
         HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
         return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
@@ -836,7 +836,8 @@ static int compact_host_pipelined_body(Ctx& g, bool spans, bool feats, bool o32,
         HIP_TRY(hipEventSynchronize(g.ev_k_done[slot]));
         volatile int64_t* h = (volatile int64_t*)g.pipe_tot.h + 2 * (c & 7);
         const int64_t n = h[0];
-        if (h[1]) too_long = true;
+        if (h[1] >> 32) { g.chain_ready = false; return fail(LATOK_ERR_HIP, "internal: the scan's look-back state was corrupt (the call is safe to repeat)"); }
+        if (h[1] & 0xFFFFFFFFll) too_long = true;
         n_of[c] = n;
         const int64_t s0 = cut[c], ns = cut[c + 1] - cut[c];
         HIP_TRY(hipStreamWaitEvent(g.s_d2h, g.ev_k_done[slot], 0));
@@ -1041,7 +1042,8 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     HIP_TRY(hipStreamSynchronize(st));   // the one synchronisation: total and flag are in pinned memory now
     const int64_t n_items = h_tot[0];
     *n_items_out = n_items;
-    if (h_tot[1]) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
+    if (h_tot[1] >> 32) { g.chain_ready = false; return fail(LATOK_ERR_HIP, "internal: the scan's look-back state was corrupt (the call is safe to repeat)"); }
+    if (h_tot[1] & 0xFFFFFFFFll) return fail(LATOK_ERR_INVALID, "a string is too long for LATOK_OUT_INT32; use the 64-bit form");
     const bool fits = n_items <= items_cap && (n_items == 0 || items_out);
     if (small) {
         memcpy(counts_out, (char*)g.pin.h + po_counts, (size_t)n_str * elt);

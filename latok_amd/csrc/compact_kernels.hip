@@ -98,7 +98,7 @@ __device__ __forceinline__ void chain_publish(unsigned long long* slot, unsigned
 __global__ __launch_bounds__(kChainBlock) void k_scan_chained(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out,
                                                               unsigned long long* __restrict__ chain, unsigned* __restrict__ ticket,
                                                               unsigned epoch, unsigned n_blocks, int64_t* __restrict__ total_out,
-                                                              int64_t* __restrict__ total_host) {
+                                                              int64_t* __restrict__ total_host, int* __restrict__ err) {
     __shared__ unsigned s_ticket;
     __shared__ long long s_wave_tot[kChainBlock / 64];
     __shared__ long long s_prefix;
@@ -135,9 +135,17 @@ __global__ __launch_bounds__(kChainBlock) void k_scan_chained(const int64_t* __r
             const long long j = j0 - lane;
             unsigned long long sv = 0;
             if (j >= 0) {
+                // (bounded: every predecessor holds a ticket, i.e. is running, and publishes before it waits for anything,
+                // so this never spins for long; should the state ever be corrupt, the launch ends with an error flag
+                // instead of hanging the device)
+                int spins = 0;
                 do {
                     sv = __hip_atomic_load(&chain[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((unsigned)(sv >> kChainEpochShift) != epoch || ((sv >> kChainFlagShift) & 3ull) == 0ull);
+                } while (((unsigned)(sv >> kChainEpochShift) != epoch || ((sv >> kChainFlagShift) & 3ull) == 0ull) && ++spins < (1 << 22));
+                if (spins >= (1 << 22)) {
+                    *err = 2;
+                    sv = ((unsigned long long)epoch << kChainEpochShift) | ((unsigned long long)kChainPrefix << kChainFlagShift);
+                }
             }
             const bool is_prefix = j < 0 || ((sv >> kChainFlagShift) & 3ull) == kChainPrefix;   // before workgroup 0: prefix 0
             const long long val = j >= 0 ? (long long)(sv & kChainValueMask) : 0;
@@ -435,7 +443,7 @@ int64_t count_blocks(int64_t n_words) { return n_words > 0 ? ((n_words + 63) / 6
 hipError_t launch_word_counts_scan(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
                                    uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, int64_t* tile_rank,
                                    unsigned long long* chain, unsigned* ticket, unsigned epoch, int64_t* total_dev,
-                                   int64_t* total_host, hipStream_t st) {
+                                   int64_t* total_host, int* err, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
     const int64_t n_tiles = (n_words + 63) / 64;
     const dim3 grid((unsigned)((n_tiles + 3) / 4)), block(256);
@@ -443,7 +451,7 @@ hipError_t launch_word_counts_scan(bool spans, const uint64_t* bits, const uint6
     else hipLaunchKernelGGL((k_word_counts<false>), grid, block, 0, st, bits, space, n_words, total, kept, tile_cnt, word_pref);
     const unsigned n_blocks = (unsigned)count_blocks(n_words);
     hipLaunchKernelGGL(k_scan_chained, dim3(n_blocks), dim3(kChainBlock), 0, st, tile_cnt, n_tiles, tile_rank, chain, ticket, epoch,
-                       n_blocks, total_dev, total_host);
+                       n_blocks, total_dev, total_host, err);
     return hipGetLastError();
 }
 

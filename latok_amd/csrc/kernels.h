@@ -115,7 +115,7 @@ int64_t count_blocks(int64_t n_words);   // workgroups of launch_word_counts_sca
 hipError_t launch_word_counts_scan(bool spans, const uint64_t* bits, const uint64_t* space, int64_t n_words, int64_t total,
                                    uint64_t* kept, int64_t* tile_cnt, uint16_t* word_pref, int64_t* tile_rank,
                                    unsigned long long* chain, unsigned* ticket, unsigned epoch, int64_t* total_dev,
-                                   int64_t* total_host, hipStream_t st);
+                                   int64_t* total_host, int* err, hipStream_t st);
 hipError_t launch_string_counts(bool out32, const uint64_t* mask, const int64_t* tile_rank, const uint16_t* word_pref,
                                 const int64_t* row_off, int64_t n_str, int64_t total, const int64_t* n_items, void* counts, int* err,
                                 hipStream_t st);

@@ -911,6 +911,23 @@ def test_c_example_program(gpu, oracle, tmp_path):
     assert out == [f"{i}:" + "".join(f" [{t}]" for t in oracle.tokenize(s)) for i, s in enumerate(texts)]
 
 
+def test_c_example_sharding_over_contexts(gpu, oracle, tmp_path):
+    """examples/shard_contexts.c: a C caller cuts one batch over several contexts (one pthread each, two and three contexts
+    on the one device of this box) and prints every string's boundary offsets: np.nonzero of the oracle's split values."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "shard_contexts")
+    subprocess.check_call(["gcc", "-std=c99", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "shard_contexts.c"), "-L" + os.path.join(ROOT, "latok_amd"), "-llatok_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"), "-o", exe])
+    texts = [G1, "see http://a.b/c or mail me@x.org", "camelCaseXMLParser", "foo@bar.com, .@user hi", "x\t\ny", "$#@^:a./"]
+    want = [f"{i}:" + "".join(f" {o}" for o in oracle.split_offsets(t).tolist()) for i, t in enumerate(texts)]
+    for args in ([], ["0", "0", "0"]):
+        out = subprocess.run([exe] + args, capture_output=True, timeout=120, check=True).stdout.decode().splitlines()
+        assert out == want, (args, out)
+
+
 def test_device_pointer_forms_match_host_pointer_forms(gpu, oracle):
     """Every batch entry point with LATOK_DEVICE_PTRS (inputs and outputs in HBM, caller-owned) against the same call with
     host pointers, on a mixed batch that is larger than the small-batch path and contains multi-byte chars."""

@@ -307,12 +307,14 @@ struct lk_planes {
 };
 #define LK_PLANE_SET(P, k, v) do { const lk_u64 v_ = (v); (P).lo[k] = (uint32_t)v_; (P).hi[k] = (uint32_t)(v_ >> 32); } while (0)
 #define LK_PLANE_GET(P, k) ((lk_u64)(P).lo[k] | ((lk_u64)(P).hi[k] << 32))
+#define LK_PLANE_HALF(P, k, upper) ((upper) ? (P).hi[k] : (P).lo[k])
 #else
 struct lk_planes {
     lk_u64 v[32];
 };
 #define LK_PLANE_SET(P, k, val) ((P).v[k] = (val))
 #define LK_PLANE_GET(P, k) ((P).v[k])
+#define LK_PLANE_HALF(P, k, upper) ((uint32_t)((P).v[k] >> ((upper) ? 32 : 0)))
 #endif
 
 // 12-bit base feature word (bit i = reference column i, offsets.py:24-35) of ONE rule code (gen_unicode_tables.py:

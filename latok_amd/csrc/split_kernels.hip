@@ -1286,6 +1286,18 @@ __device__ __forceinline__ FeatSums feat_popc(const lk_planes& F, lk_u64 m) {
         r.v[c >> 2] |= (uint32_t)__popcll(LK_PLANE_GET(F, c) & m) << (8 * (c & 3));   // <= 64: no byte overflow
     return r;
 }
+// the same over one 32-bit half of the word (HI = 0: chars 0..31, 1: chars 32..63): a token of a few chars lies in one half,
+// so its 25 sums cost one and + one popcount per column instead of two
+template <int HI>
+__device__ __forceinline__ FeatSums feat_popc_half(const lk_planes& F, uint32_t m) {
+    FeatSums r;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) r.v[j] = 0;
+#pragma unroll
+    for (int c = 0; c < LK_N_FEATURES; ++c)
+        r.v[c >> 2] |= (uint32_t)__popc(LK_PLANE_HALF(F, c, HI) & m) << (8 * (c & 3));   // <= 32: no byte overflow
+    return r;
+}
 __device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint32_t x, uint32_t y, bool first, bool last) {
     // 25 columns of one char from base words (aux_kernels.hip:feature_row_bits, same bit layout)
     uint32_t r = w & 0xFFFu;
@@ -1644,17 +1656,57 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     }
 
     // ---- tokens of my word, round by round through the staging buffer -------------------------------------------------
+    // The walk is split by 32-bit halves: first the tokens that start in chars 0..31 (popcounts on the low halves of the
+    // planes only), then the part of the one token that may reach from the low half into the high half, then the tokens that
+    // start in chars 32..63 (high halves only).  Ranks grow in that order, so the records land at consecutive slots.
     uint8_t* win = L.stage;
-    lk_u64 rest = x;
+    uint32_t rest_lo = (uint32_t)x, rest_hi = (uint32_t)(x >> 32);
+    const uint32_t xb_lo = (uint32_t)xb, xb_hi = (uint32_t)(xb >> 32);
+    const uint32_t valid_lo = (uint32_t)valid, valid_hi = (uint32_t)(valid >> 32);
+    FeatSums S_str;                       // low-half sums of the straddling token
+#pragma unroll
+    for (int j = 0; j < 7; ++j) S_str.v[j] = 0;
+    int str_slot = -1;                    // its slot (>= 0: the upper part is still to be added)
     int k = off;
     for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
-        while (rest && k < win0 + kFeatRound) {
-            const int b = lk_ctz(rest);
-            rest &= rest - 1;
-            const lk_u64 above = xb & (~1ull << b);
-            lk_u64 seg = (~0ull << b) & valid;
-            if (above) seg &= (above & (~above + 1ull)) - 1ull;
-            FeatSums sum = feat_popc(F, seg);
+        const int lim = win0 + kFeatRound;
+        while (rest_lo && k < lim) {
+            const int b = __builtin_ctz(rest_lo);
+            rest_lo &= rest_lo - 1u;
+            const uint32_t above = xb_lo & (~1u << b);
+            uint32_t seg = (~0u << b) & valid_lo;
+            if (above) seg &= (above & (0u - above)) - 1u;
+            const FeatSums sum = feat_popc_half<0>(F, seg);
+            if (above) {
+                put_record(win, k - win0, sum);
+            } else {                      // no boundary up to char 31: the token goes on in the high half (the last low token)
+                S_str = sum;
+                str_slot = k;
+            }
+            ++k;
+        }
+        if (__ballot(str_slot >= 0 && rest_lo == 0u)) {
+            if (str_slot >= 0 && rest_lo == 0u) {
+                uint32_t seg = valid_hi;
+                if (xb_hi) seg &= (xb_hi & (0u - xb_hi)) - 1u;          // chars 32.. up to the first boundary there
+                const FeatSums s2 = feat_popc_half<1>(F, seg);
+#pragma unroll
+                for (int j = 0; j < 7; ++j) S_str.v[j] = swar_add_u8(S_str.v[j], s2.v[j]);
+                if (!xb_hi) {                                             // ... and on into the following words
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) S_str.v[j] = swar_add_u8(S_str.v[j], C.v[j]);
+                }
+                put_record(win, str_slot - win0, S_str);
+                str_slot = -1;
+            }
+        }
+        while (rest_lo == 0u && rest_hi && k < lim) {
+            const int b = __builtin_ctz(rest_hi);
+            rest_hi &= rest_hi - 1u;
+            const uint32_t above = xb_hi & (~1u << b);
+            uint32_t seg = (~0u << b) & valid_hi;
+            if (above) seg &= (above & (0u - above)) - 1u;
+            FeatSums sum = feat_popc_half<1>(F, seg);
             if (!above) {
 #pragma unroll
                 for (int j = 0; j < 7; ++j) sum.v[j] = swar_add_u8(sum.v[j], C.v[j]);
@@ -1671,7 +1723,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
     OUT* swin = reinterpret_cast<OUT*>(L.stage);
     constexpr int kSpanRound = span_round<OUT>();
-    rest = x;
+    lk_u64 rest = x;
     k = off;
     for (int win0 = 0; win0 < n_wave; win0 += kSpanRound) {
         while (rest && k < win0 + kSpanRound) {

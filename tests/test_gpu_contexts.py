@@ -186,3 +186,44 @@ def test_contexts_come_and_go(gpu, oracle):
             with multi.DevicePool([0, 0]) as pool:
                 assert np.array_equal(multi.split_mask_batch(cps, row, pool), want)
     assert np.array_equal(batch.split_mask_batch(cps, row), want)
+
+
+def test_one_context_shared_by_threads_is_serialised(gpu, oracle):
+    """two threads on the SAME (default) context: the calls are serialised by its lock, every result is exact"""
+    from latok_amd import batch
+    rng = random.Random(12)
+    work = []
+    for _ in range(2):
+        cps, row = pack(random_strings(rng, 2000, 0, 150, ALPHABETS["mixed"]) + random_strings(rng, 2, 9000, 30000, ALPHABETS["words"]))
+        work.append((cps, row, _oracle_offsets(oracle, cps, row)))
+    errors = []
+
+    def run(k):
+        try:
+            cps, row, (wc, wo, wb) = work[k]
+            for _ in range(25):
+                assert np.array_equal(batch.split_mask_batch(cps, row), wb)
+                c, o = batch.split_offsets_csr(cps, row, dtype=np.int32)
+                assert np.array_equal(c, wc) and np.array_equal(o, wo)
+        except BaseException as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errors, errors[0]
+
+
+def test_default_context_can_be_shut_down_and_come_back(gpu, oracle):
+    from latok_amd import _lib, batch
+    cps, row = pack(["shut down, then back: a@b.c http://x.y/z"] * 300)
+    _, want = oracle.split_batch(cps, row, want_values=False)
+    assert np.array_equal(batch.split_mask_batch(cps, row), want)
+    _lib.shutdown()
+    out = np.zeros(1, np.uint64)
+    assert gpu.latok_split_mask_batch(cps.ctypes.data, row.ctypes.data, 1, -1, out.ctypes.data, 0, None) == _lib.ERR_NOT_INIT
+    assert np.array_equal(batch.split_mask_batch(cps, row), want)          # ensure_init brings it back
+    c, o = batch.split_offsets_csr(cps, row, dtype=np.int32)
+    assert int(c.sum()) == len(o) > 0

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -86,6 +87,7 @@ struct PinBuf {
             release();
             return fail(LATOK_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
         }
+        memset(h, 0, want);
         cap = want;
         return LATOK_OK;
     }
@@ -95,6 +97,26 @@ struct PinBuf {
         cap = 0;
     }
 };
+
+// Small-batch completion: the kernel stores a sequence number into pinned memory after its last output and the host
+// polls that word -- the end-of-kernel signal takes ~10 us longer to come back through the runtime than the data does.
+// Bounded: after kPollNs without the word (first launch of a code object, a busy stream, a faulted kernel) the caller
+// falls back to hipStreamSynchronize, which also surfaces errors.  LATOK_SMALL_POLL=0 turns polling off.
+constexpr long long kPollNs = 200000;
+static bool poll_completion() {
+    static const bool on = [] { const char* e = getenv("LATOK_SMALL_POLL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static bool wait_completion_word(const unsigned long long* word, unsigned long long seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 256; ++i) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return true;
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kPollNs) return false;
+    }
+}
 
 // host-pointer calls up to this size take the pinned zero-copy path (inputs are then read over the bus, including the
 // binary searches over row_off, so it only pays for small batches; larger ones amortise their copies)
@@ -120,6 +142,7 @@ struct Ctx {
     // staging for host-pointer calls and for the offsets API
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, wpref, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
+    unsigned long long small_seq = 0;   // completion word of the single-launch small-batch path (pin_tot word 2)
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
     // chunked host pipeline (compact_host_pipelined): copy streams, events and double buffers
@@ -1019,6 +1042,7 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         d_feat = (int8_t*)g.h_aux.p;
         cap = total;
     }
+    bool polled = false;
     if (small && !feats && total <= latok::kTile) {
         // at most one tile (tokenize(text): one string per call): one single-wave launch does everything
         latok::SplitParams P;
@@ -1034,12 +1058,17 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         if (g.rules_on) P.rules = g.rules;
         h_tot[0] = 0;
         h_tot[1] = 0;
-        HIP_TRY(latok::launch_small_batch(P, g.rules_on, spans ? 1 : 0, o32, d_counts, d_items, p_tot, st));
+        const unsigned long long seq = ++g.small_seq;
+        HIP_TRY(latok::launch_small_batch(P, g.rules_on, spans ? 1 : 0, o32, d_counts, d_items, p_tot,
+                                          poll_completion() ? (unsigned long long*)(p_tot + 2) : nullptr, seq, st));
+        polled = poll_completion() && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
     } else if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
                                             cap, p_tot, h_tot, st))) {
         return rc;
     }
-    HIP_TRY(hipStreamSynchronize(st));   // the one synchronisation: total and flag are in pinned memory now
+    // the one synchronisation: total and flag are in pinned memory now (a polled small batch has seen its completion
+    // word, which the kernel stores after everything else; the launch itself retires on the stream a moment later)
+    if (!polled) HIP_TRY(hipStreamSynchronize(st));
     const int64_t n_items = h_tot[0];
     *n_items_out = n_items;
     if (h_tot[1] >> 32) { g.chain_ready = false; return fail(LATOK_ERR_HIP, "internal: the scan's look-back state was corrupt (the call is safe to repeat)"); }

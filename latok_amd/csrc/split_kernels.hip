@@ -729,7 +729,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     return out_word;
 }
 
-template <int MODE, bool DEFER = false>
+template <int MODE, bool DEFER = false, bool SMALL = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
                                              int tail_zero, bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
@@ -785,6 +785,41 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
             const uint32_t c = classify4(L.t1, L.t2, v[i]);
             *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
             if (codes) codes[64 * i] = c;                                     // 256 contiguous bytes per wave instruction
+        }
+    } else if (SMALL) {
+        // a batch of at most one tile, latency matters (k_small_batch: the chars sit in host memory, the tables in global
+        // memory).  Only the rows of 256 chars that exist are loaded and classified, all loads before the first lookup
+        // (the 16 serial load -> lookup rounds of the general path below were most of that kernel's time).
+        uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;
+        const int n_rows = (int)((total - t0 + 255) >> 8);            // wave-uniform, 1..16
+        const int64_t remain0 = total - t0 - 4 * (int64_t)lane;       // chars that exist from my first char on (row 0)
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+        u32x4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = u32x4{0u, 0u, 0u, 0u};
+            if (i < n_rows) {
+                const int64_t remain = remain0 - 256 * i;
+                if (remain >= 4) {
+                    v[i] = __builtin_nontemporal_load(src + 64 * i);
+                } else {
+                    const uint32_t* q = P.cps + t0 + 256 * i + 4 * lane;
+                    if (remain > 0) v[i].x = q[0];
+                    if (remain > 1) v[i].y = q[1];
+                    if (remain > 2) v[i].z = q[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t c = 0;
+            if (i < n_rows) {
+                const int64_t remain = remain0 - 256 * i;
+                const uint32_t exist = remain >= 4 ? 0xFFFFFFFFu : (remain <= 0 ? 0u : ((1u << (8 * (int)remain)) - 1u));
+                c = classify4(L.t1, L.t2, v[i]) & exist;              // a char that does not exist has code 0 ("nothing")
+            }
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+            if (codes) codes[64 * i] = c;
         }
     } else {
         // the batch's last, partial tile (its code bytes are written up to the end of the tile: 0 behind the last char)
@@ -1818,6 +1853,8 @@ struct SmallParams {
     void* counts;           // OUT[n_str]
     void* items;            // KIND 0: OUT[n_items] offsets; KIND 1: OUT[n_items][2] stripped token spans
     int64_t* n_items;       // [1]
+    unsigned long long* done;   // pinned host word that receives `seq` after every output has been stored (or NULL)
+    unsigned long long seq;
 };
 
 template <int MODE, int KIND, typename OUT>
@@ -1842,7 +1879,10 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     wave_lds_sync();
     const int64_t total = P.total, n_str = P.n_str;
     const int64_t n_words = (total + 63) >> 6;
-    const lk_u64 xb = process_tile<MODE, false>(P, L, 0, 0, 0, -1, false, nullptr, lane);   // boundaries of my word
+    // the bounds of the first 64 strings, requested now: they travel over the bus together with the tile's chars
+    int64_t ro_a = 0, ro_b = 0;
+    if (lane < n_str) { ro_a = P.row_off[lane]; ro_b = P.row_off[lane + 1]; }
+    const lk_u64 xb = process_tile<MODE, false, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);   // boundaries of my word
     wave_lds_sync();
     const int64_t base = 64 * (int64_t)lane;
     // ---- which boundaries are items (spans: those whose token holds a non-SPACE char), like k_word_counts -------------
@@ -1880,7 +1920,8 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
         if (p >= total) return n_items;
         return s_pref[p >> 6] + lk_popc(s_items[p >> 6] & low_mask((int)(p & 63)));
     };
-    for (int64_t s = lane; s < n_str; s += 64) counts[s] = (OUT)(rank_of(P.row_off[s + 1]) - rank_of(P.row_off[s]));
+    if (lane < n_str) counts[lane] = (OUT)(rank_of(ro_b) - rank_of(ro_a));
+    for (int64_t s = 64 + lane; s < n_str; s += 64) counts[s] = (OUT)(rank_of(P.row_off[s + 1]) - rank_of(P.row_off[s]));
     // ---- where the string that owns a position begins: last string start at or before it (L.bw: the tile's string starts)
     const lk_u64 Bw = L.bw[lane];
     int carry = Bw ? 64 * lane + 63 - __builtin_clzll(Bw) : -1;
@@ -1928,15 +1969,23 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
         }
         ++k;
     }
+    // completion word: the host polls it instead of waiting for the end-of-kernel signal to travel through the runtime.
+    // One wave wrote everything, its stores leave in order, the fence drains them to system scope before the word follows.
+    if (S.done) {
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(S.done, S.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int64_t* n_items,
-                              hipStream_t st) {
+                              unsigned long long* done, unsigned long long seq, hipStream_t st) {
     SmallParams S;
     S.P = P;
     S.counts = counts;
     S.items = items;
     S.n_items = n_items;
+    S.done = done;
+    S.seq = seq;
 #define LATOK_SB(M, K, T) hipLaunchKernelGGL((k_small_batch<M, K, T>), dim3(1), dim3(64), 0, st, S)
     if (rules) {
         if (kind == 0) { if (out32) LATOK_SB(kModeRules, 0, int32_t); else LATOK_SB(kModeRules, 0, int64_t); }

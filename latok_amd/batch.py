@@ -130,26 +130,27 @@ _ROW1 = None
 
 def split_offsets_one(text: str) -> np.ndarray:
     """np.nonzero(split mask)[0] of ONE non-empty string with as little Python around the C call as possible (the drop-in
-    tokenize(text) surface): a string of at most 4096 chars is one single-wave launch and one synchronisation in the
-    library; what is left here is the UTF-32 encode and two small arrays."""
+    tokenize(text) surface): a string of at most 4096 chars is one single-wave launch in the library, which polls the
+    kernel's completion word; what is left here is the UTF-32 encode (the bytes object goes to the C call as it is) and
+    a copy of the offsets out of a per-thread output array."""
     global _ROW1
     n = len(text)
     if n > _SMALL_CHARS:
         return split_offsets_batch([text])[0]
     lib = _lib.ensure_init()
-    cps = np.frombuffer(text.encode("utf-32-le", "surrogatepass"), dtype="<u4")
     if _ROW1 is None:
         _ROW1 = threading.local()
-    row = getattr(_ROW1, "row", None)
-    if row is None:
-        row = _ROW1.row = np.zeros(2, np.int64)
-        _ROW1.count = np.zeros(1, np.int32)
-        _ROW1.n = C.c_int64(0)
+    st = getattr(_ROW1, "st", None)
+    if st is None:
+        row, count, offs, n_out = np.zeros(2, np.int64), np.zeros(1, np.int32), np.empty(_SMALL_CHARS, np.int32), C.c_int64(0)
+        st = _ROW1.st = (row, count, offs, n_out, row.ctypes.data, count.ctypes.data, offs.ctypes.data, C.byref(n_out))
+    row, _, offs, n_out, p_row, p_count, p_offs, p_n = st
     row[1] = n
-    offs = np.empty(n, np.int32)
-    _lib.check(lib.latok_split_offsets_batch(cps.ctypes.data, row.ctypes.data, 1, n, _ROW1.count.ctypes.data, offs.ctypes.data, n,
-                                             C.byref(_ROW1.n), _lib.OUT_INT32, None))
-    return offs[:_ROW1.n.value]
+    rc = lib.latok_split_offsets_batch(text.encode("utf-32-le", "surrogatepass"), p_row, 1, n, p_count, p_offs, n, p_n,
+                                       _lib.OUT_INT32, None)
+    if rc:
+        _lib.check(rc)
+    return offs[:n_out.value].copy()
 
 
 def _record_dtype(row_off):

@@ -144,6 +144,8 @@ struct TileLds {
     lk_u64* bw;            // 65 words of string-start bits, wave private
     const uint8_t* lut;    // kModeLatin1: slice LUT (kSliceLutBytes) in place of the Unicode tables
     const uint8_t* ctab;   // kModeLatin1: split code of each of the 256 Latin-1 chars
+    uint64_t* small_bits;  // k_small_batch: where the tile's boundary / SPACE words go (LDS) in place of P.bits_out /
+    uint64_t* small_space; // P.space_out -- the kernel arguments stay where they are (no private copy of the rule tables)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -486,7 +488,7 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
 // Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
 // words are in the wave's LDS buffer L.  (A separate function because a producer / consumer variant of the kernel ran
 // the two phases in different waves; see DESIGN.md, negative results.)
-template <int MODE, bool DEFER = false>
+template <int MODE, bool DEFER = false, bool SMALL = false>
 __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
                                             bool write_summary, int4* summ_l, int lane, bool raw_stage
 #ifdef LATOK_STAMPS
@@ -686,8 +688,10 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         const lk_u64 keep = ~cleared;
         if (mode_writes_bits(MODE)) {
             out_word = ((loc.raw & keep) | loc.sym | B) & valid;
-            if (!DEFER) P.bits_out[base >> 6] = out_word;
-            if (P.space_out) P.space_out[base >> 6] = (mode_is_bytes(MODE) ? space_plane : loc.S) & valid;   // token-span mode only
+            uint64_t* const bits_out = SMALL ? L.small_bits : P.bits_out;
+            uint64_t* const space_out = SMALL ? L.small_space : P.space_out;
+            if (!DEFER) bits_out[base >> 6] = out_word;
+            if (space_out) space_out[base >> 6] = (mode_is_bytes(MODE) ? space_plane : loc.S) & valid;   // token-span mode only
         } else {
             // kModeValues: split VALUES 0..5 = (sum of the five C_SPLIT terms) * mask + C_SYM term; string start = 1
             // kModeBlockMask: the 1/0 block mask itself; element 0 follows the reference's quirk (never zeroed on the
@@ -856,7 +860,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #endif
     LATOK_STAMP(3);
 
-    return tile_phase2<MODE, DEFER>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage
+    return tile_phase2<MODE, DEFER, SMALL>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage
 #ifdef LATOK_STAMPS
                                     , stamp_acc, stamp_prev
 #endif
@@ -1055,6 +1059,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
     L.lut = lds + (MODE == kModeBytes ? kLdsSlice : 0);   // build_latin1_tables: kModeLatin1 at 0, kModeBytes behind the rest
     L.ctab = L.lut + kSliceLutBytes;
+    L.small_bits = L.small_space = nullptr;
     return L;
 }
 
@@ -1821,6 +1826,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     TileLds L;
+    L.small_bits = L.small_space = nullptr;
     L.t1 = L.t2 = L.lut = L.ctab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
     uint8_t* mine = lds + wave * kFeatWaveLds;
     L.stage = mine;
@@ -1873,9 +1879,9 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     s_bits[lane] = 0ull;
     s_space[lane] = ~0ull;   // positions behind the batch read as SPACE
     if (lane < 2) { s_bits[64 + lane] = 0ull; s_space[64 + lane] = ~0ull; }
-    SplitParams P = S.P;
-    P.bits_out = s_bits;     // (generic pointers into LDS: the tile function stores its words there)
-    P.space_out = KIND == 1 ? s_space : nullptr;
+    const SplitParams& P = S.P;
+    L.small_bits = s_bits;
+    L.small_space = KIND == 1 ? s_space : nullptr;
     wave_lds_sync();
     const int64_t total = P.total, n_str = P.n_str;
     const int64_t n_words = (total + 63) >> 6;

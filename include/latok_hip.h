@@ -27,6 +27,11 @@
  *     over the GPUs of a node (SURVEY 8b "Threading", 8e).  The compaction entry points (offsets / spans / features)
  *     return the item total to the host and therefore block even in device mode: everything is enqueued first (the
  *     kernels write the records only if the total fits the caller's capacity) and the call synchronises once.
+ *   - small host batches (host pointers, at most LATOK_TILE_CHARS chars and 512 strings -- one string per call is the
+ *     reference's own calling pattern, default_tokenizer.py:137-191) are one single-wavefront launch for offsets, spans
+ *     and features alike: inputs and outputs pass through pinned memory the kernel reads / writes directly, and the
+ *     call returns when it has seen the completion word the kernel stores after its last output (LATOK_SMALL_POLL=0 in
+ *     the environment: wait for the stream instead).
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H

@@ -153,6 +153,37 @@ def split_offsets_one(text: str) -> np.ndarray:
     return offs[:n_out.value].copy()
 
 
+def featurize_one(text: str):
+    """list(featurize(text)) of the reference for ONE non-empty string of at most 4096 chars: two small launches in the
+    library (boundaries + kept tokens, then the sums), per-thread output arrays, one LaToken per kept token."""
+    from .core.latok_utils import LaToken
+    global _FEAT1
+    n = len(text)
+    if n > 4096:
+        return featurize_batch([text])[0]
+    lib = _lib.ensure_init()
+    if _FEAT1 is None:
+        _FEAT1 = threading.local()
+    st = getattr(_FEAT1, "st", None)
+    if st is None:
+        row, count, spans, n_out = np.zeros(2, np.int64), np.zeros(1, np.int32), np.empty((4096, 4), np.int32), C.c_int64(0)
+        feats = np.empty((4096, 25), np.int8)
+        st = _FEAT1.st = (row, count, spans, feats, n_out, row.ctypes.data, count.ctypes.data, spans.ctypes.data,
+                          feats.ctypes.data, C.byref(n_out))
+    row, _, spans, feats, n_out, p_row, p_count, p_spans, p_feats, p_n = st
+    row[1] = n
+    rc = lib.latok_token_features_batch(text.encode("utf-32-le", "surrogatepass"), p_row, 1, n, p_count, p_spans, p_feats, n,
+                                        p_n, _lib.OUT_INT32, None)
+    if rc:
+        _lib.check(rc)
+    k = n_out.value
+    rows = feats[:k].copy()            # the tokens' vectors are views of one fresh array, not of the per-thread buffer
+    return [LaToken(text[c:d], a, b, rows[j]) for j, (a, b, c, d) in enumerate(spans[:k].tolist())]
+
+
+_FEAT1 = None
+
+
 def _record_dtype(row_off):
     """int32 records (LATOK_OUT_INT32: half the device writes and bus traffic) unless a string has 2^31 chars or more"""
     return np.int32 if row_off.size < 2 or int(np.diff(row_off).max()) <= 0x7FFFFFFF else np.int64

@@ -141,4 +141,4 @@ def featurize(text: str):
     if len(text) == 0:
         raise IndexError("index 0 is out of bounds for axis 0 with size 0")
     _sync_rules()
-    yield from _batch.featurize_batch([text])[0]
+    yield from _batch.featurize_one(text)

@@ -1043,8 +1043,9 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         cap = total;
     }
     bool polled = false;
-    if (small && !feats && total <= latok::kTile) {
-        // at most one tile (tokenize(text): one string per call): one single-wave launch does everything
+    if (small && total <= latok::kTile) {
+        // at most one tile (tokenize(text) / featurize(text): one string per call): one single-wave launch does everything
+        // and stores a completion word the host polls
         latok::SplitParams P;
         memset(&P, 0, sizeof(P));
         P.cps = d_cps;
@@ -1052,16 +1053,16 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         P.n_str = n_str;
         P.total = total;
         P.n_tiles = 1;
-        const uint8_t* tables = (const uint8_t*)(g.rules_on ? g.t1rule.p : g.t1.p);
+        const uint8_t* tables = (const uint8_t*)((g.rules_on || feats) ? g.t1rule.p : g.t1.p);   // featurize needs rule codes
         P.t1 = tables;
         P.t2 = tables + latok::kStage1Pad;
         if (g.rules_on) P.rules = g.rules;
         h_tot[0] = 0;
         h_tot[1] = 0;
         const unsigned long long seq = ++g.small_seq;
-        HIP_TRY(latok::launch_small_batch(P, g.rules_on, spans ? 1 : 0, o32, d_counts, d_items, p_tot,
-                                          poll_completion() ? (unsigned long long*)(p_tot + 2) : nullptr, seq, st));
-        polled = poll_completion() && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
+        unsigned long long* d_done = poll_completion() ? (unsigned long long*)(p_tot + 2) : nullptr;
+        HIP_TRY(latok::launch_small_batch(P, g.rules_on, feats ? 2 : (spans ? 1 : 0), o32, d_counts, d_items, d_feat, p_tot, d_done, seq, st));
+        polled = d_done && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
     } else if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
                                             cap, p_tot, h_tot, st))) {
         return rc;

@@ -98,8 +98,9 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
 // batches of at most one tile, everything in one launch (split_kernels.hip: k_small_batch); P.t1 / P.t2 / P.rules / P.cps /
 // P.row_off / P.n_str / P.total must be set, kind 0 = offsets, 1 = token spans.  done (or NULL): a pinned host word that
 // receives seq once every output is visible to the host.
-hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int64_t* n_items,
-                              unsigned long long* done, unsigned long long seq, hipStream_t st);
+// kind 2 = featurize: items = [n_items][4] span records, features = [n_items][25] sums
+hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int8_t* features,
+                              int64_t* n_items, unsigned long long* done, unsigned long long seq, hipStream_t st);
 hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int* flags, hipStream_t st);
 
 // aux_kernels.hip

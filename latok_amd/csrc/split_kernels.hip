@@ -1861,6 +1861,7 @@ struct SmallParams {
     int64_t* n_items;       // [1]
     unsigned long long* done;   // pinned host word that receives `seq` after every output has been stored (or NULL)
     unsigned long long seq;
+    int8_t* features;       // KIND 2 (featurize): [n_items][25] sums; items = [n_items][4] {raw start, raw end, stripped start, stripped end}
 };
 
 template <int MODE, int KIND, typename OUT>
@@ -1881,7 +1882,7 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     if (lane < 2) { s_bits[64 + lane] = 0ull; s_space[64 + lane] = ~0ull; }
     const SplitParams& P = S.P;
     L.small_bits = s_bits;
-    L.small_space = KIND == 1 ? s_space : nullptr;
+    L.small_space = KIND >= 1 ? s_space : nullptr;
     wave_lds_sync();
     const int64_t total = P.total, n_str = P.n_str;
     const int64_t n_words = (total + 63) >> 6;
@@ -1893,9 +1894,9 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     const int64_t base = 64 * (int64_t)lane;
     // ---- which boundaries are items (spans: those whose token holds a non-SPACE char), like k_word_counts -------------
     lk_u64 x = xb;
-    const lk_u64 nn = KIND == 1 ? (~s_space[lane] & valid_mask(lane, total)) : 0ull;
+    const lk_u64 nn = KIND >= 1 ? (~s_space[lane] & valid_mask(lane, total)) : 0ull;
     lk_u64 xb1 = 0, nn1 = 0;
-    if (KIND == 1) {
+    if (KIND >= 1) {
         xb1 = __shfl_down(xb, 1);
         nn1 = __shfl_down(nn, 1);
         if (lane == 63) { xb1 = 0; nn1 = 0; }
@@ -1939,9 +1940,80 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     carry = __shfl_up(carry, 1);
     if (lane == 0) carry = -1;
     const int64_t lo_in = carry >= 0 ? carry : 0;
+    if (KIND == 2) {
+        // ---- featurize: the 25 feature planes of every word go to LDS, then lane = TOKEN: its span from the bitmasks, its
+        //      sums = popcounts of the planes over the span.  (k_features_tiles is built for throughput -- ~7 K dependent
+        //      instructions per tile, 26 us when a single tile is all there is; this is ~1 K.)
+        __shared__ lk_u64 s_planes[64 * LK_N_FEATURES];
+        __shared__ int s_lo[64];
+        __shared__ __attribute__((aligned(16))) uint8_t s_win[64 * kFeatRec + 16];
+        {
+            uint32_t d[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 q = *reinterpret_cast<const uint4*>(L.stage + 80u * lane + 16u * k);
+                d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+            }
+            lk_halo h;
+            h.prev = lane > 0 ? L.stage[80u * lane - 17u] : L.halo[0];
+            h.next0 = lane < 63 ? L.stage[80u * lane + 80u] : L.halo[1];
+            h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
+            lk_u64 plane[8];
+            lk_bitslice64(d, plane);
+            lk_planes F;
+            lk_feature_planes(plane, h, Bw, L.bw[lane + 1] & 3ull, F);
+#pragma unroll
+            for (int c = 0; c < LK_N_FEATURES; ++c) s_planes[lane * LK_N_FEATURES + c] = LK_PLANE_GET(F, c);
+        }
+        s_lo[lane] = (int)lo_in;
+        wave_lds_sync();
+        OUT* spans4 = reinterpret_cast<OUT*>(S.items);
+        for (int k0 = 0; k0 < n_items; k0 += 64) {
+            const int k = k0 + lane;
+            FeatSums sum;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) sum.v[j] = 0;
+            if (k < n_items) {
+                // the word that holds kept token k: the last w with s_pref[w] <= k (s_pref[64] = n_items)
+                int wl = 0, wh = 64;
+                while (wh - wl > 1) {
+                    const int mid = (wl + wh) >> 1;
+                    if (s_pref[mid] <= k) wl = mid; else wh = mid;
+                }
+                lk_u64 m = s_items[wl];
+                for (int r = k - s_pref[wl]; r > 0; --r) m &= m - 1ull;
+                const int b = lk_ctz(m);
+                const int64_t a = 64 * (int64_t)wl + b;                       // raw start
+                const int64_t e = next_set_bit(s_bits, a + 1, total);         // raw end: the next boundary
+                const int64_t a2 = next_zero_bit(s_space, a, e);              // stripped span (a kept token has a non-SPACE char)
+                const int64_t e2 = prev_zero_end(s_space, a2, e);
+                const lk_u64 bl = L.bw[wl] & ((2ull << b) - 1ull);            // string starts at or before the token
+                const int64_t lo = bl ? 64 * (int64_t)wl + 63 - __builtin_clzll(bl) : (int64_t)s_lo[wl];
+                OUT* rec = spans4 + 4 * (int64_t)k;
+                rec[0] = (OUT)(a - lo); rec[1] = (OUT)(e - lo); rec[2] = (OUT)(a2 - lo); rec[3] = (OUT)(e2 - lo);
+                uint32_t acc[LK_N_FEATURES];
+#pragma unroll
+                for (int c = 0; c < LK_N_FEATURES; ++c) acc[c] = 0;
+                for (int64_t w = wl; 64 * w < e; ++w) {
+                    lk_u64 msk = ~0ull;
+                    if (w == wl) msk &= ~0ull << b;
+                    if (e < 64 * w + 64) msk &= (1ull << (e - 64 * w)) - 1ull;
+#pragma unroll
+                    for (int c = 0; c < LK_N_FEATURES; ++c) acc[c] += (uint32_t)__popcll(s_planes[w * LK_N_FEATURES + c] & msk);
+                }
+#pragma unroll
+                for (int c = 0; c < LK_N_FEATURES; ++c) sum.v[c >> 2] |= (acc[c] & 0xFFu) << (8 * (c & 3));   // uint8 wrap-around (latok.c:342-354)
+            }
+            const int n_here = min(64, n_items - k0);
+            if (k < n_items) put_record(s_win, lane, sum);
+            wave_lds_sync();
+            flush_records(s_win, n_here, reinterpret_cast<uint8_t*>(S.features) + (int64_t)k0 * kFeatRec, lane);
+            wave_lds_sync();
+        }
+    }
     // ---- the records, word-major: lane = word walks its items -------------------------------------------------------
     OUT* out = reinterpret_cast<OUT*>(S.items);
-    lk_u64 rest = x;
+    lk_u64 rest = KIND == 2 ? 0ull : x;
     int k = inc - cnt;
     while (rest) {
         const int b = lk_ctz(rest);
@@ -1983,23 +2055,24 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     }
 }
 
-hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int64_t* n_items,
-                              unsigned long long* done, unsigned long long seq, hipStream_t st) {
+hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool out32, void* counts, void* items, int8_t* features,
+                              int64_t* n_items, unsigned long long* done, unsigned long long seq, hipStream_t st) {
     SmallParams S;
     S.P = P;
     S.counts = counts;
     S.items = items;
+    S.features = features;
     S.n_items = n_items;
     S.done = done;
     S.seq = seq;
 #define LATOK_SB(M, K, T) hipLaunchKernelGGL((k_small_batch<M, K, T>), dim3(1), dim3(64), 0, st, S)
+#define LATOK_SB_K(M, T) do { if (kind == 0) LATOK_SB(M, 0, T); else if (kind == 1) LATOK_SB(M, 1, T); else LATOK_SB(M, 2, T); } while (0)
     if (rules) {
-        if (kind == 0) { if (out32) LATOK_SB(kModeRules, 0, int32_t); else LATOK_SB(kModeRules, 0, int64_t); }
-        else { if (out32) LATOK_SB(kModeRules, 1, int32_t); else LATOK_SB(kModeRules, 1, int64_t); }
+        if (out32) LATOK_SB_K(kModeRules, int32_t); else LATOK_SB_K(kModeRules, int64_t);
     } else {
-        if (kind == 0) { if (out32) LATOK_SB(kModeBits, 0, int32_t); else LATOK_SB(kModeBits, 0, int64_t); }
-        else { if (out32) LATOK_SB(kModeBits, 1, int32_t); else LATOK_SB(kModeBits, 1, int64_t); }
+        if (out32) LATOK_SB_K(kModeBits, int32_t); else LATOK_SB_K(kModeBits, int64_t);
     }
+#undef LATOK_SB_K
 #undef LATOK_SB
     return hipGetLastError();
 }

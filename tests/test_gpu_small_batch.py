@@ -1,0 +1,151 @@
+"""The single-launch path of host batches of at most one tile (4096 chars, <= 512 strings): tokenize(text) /
+featurize(text) of the drop-in surface (reference default_tokenizer.py:137-191) and small lists.  One wave computes the
+boundaries, the per-string counts, the records and -- for featurize -- the 25 sums of every token (lane = token, popcounts
+of the feature planes), stores a completion word into pinned memory, and the host polls that word.  Everything is compared
+with the oracle; the sizes sit on the edges of the path (4095 / 4096 / 4097 chars, 512 / 513 strings)."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ALPHABETS, ROOT, pack, random_strings
+
+pytestmark = pytest.mark.gpu
+
+
+def _want(oracle, t):
+    """tokens of one string as (text, raw_start, raw_end, strip_start, strip_end, sums)"""
+    if not t:
+        return []
+    m = oracle.gen_parse_matrix(t).astype(np.uint8)
+    nz = oracle.split_offsets(t).tolist() + [len(t)]
+    out = []
+    for a, b in zip(nz[:-1], nz[1:]):
+        s = t[a:b]
+        if s.strip():
+            a2 = a + len(s) - len(s.lstrip())
+            out.append((s.strip(), a, b, a2, a2 + len(s.strip()), m[a:b].sum(axis=0, dtype=np.uint64).astype(np.uint8).astype(np.int8)))
+    return out
+
+
+def _small_batches():
+    rng = random.Random(40964096)
+    yield ["This is a #test! Testing, Testing, 1 2 3 -- see http://example.com/x or mail bob@host.org, camelCaseWord."]
+    yield ["a"], [" "], ["  \t "], ["#"], ["@a"], ["x" * 64], ["x" * 63 + " "], [" " * 64 + "y"]
+    for n in (4095, 4096):                                   # the largest batches the path takes
+        yield ["".join(rng.choice(ALPHABETS["mixed"]) for _ in range(n))]
+        yield ["http://" + "a" * (n - 7)]                    # one masked token over all 64 words
+        yield ["w" * n]
+        yield [" " * n]
+    yield ["é" * 300 + "@" + "日" * 900 + " end", "", "tail #tag", ""]
+    yield random_strings(rng, 512, 0, 8, ALPHABETS["starts"])            # 512 strings: the most the path takes
+    yield random_strings(rng, 64, 0, 64, ALPHABETS["mixed"])
+    yield random_strings(rng, 65, 0, 60, ALPHABETS["words"])             # counts beyond the first 64 strings
+    yield [""] * 5 + ["a b"] + [""] * 70 + ["c"]
+    for _ in range(40):
+        n_str = rng.randint(1, 80)
+        yield random_strings(rng, n_str, 0, 4096 // n_str, ALPHABETS[rng.choice(["mixed", "words", "rare_space_at", "bmp"])])
+    # tokens that leave their 64-char word, in every alignment
+    for lead in (0, 1, 31, 62, 63, 64, 65):
+        yield ["x" * lead + " http://" + "".join(rng.choice("abcXYZ9_/.:é日") for _ in range(n)) + " e #t"
+               for n in (50, 64, 130, 300)]
+
+
+def _flat():
+    out = []
+    for b in _small_batches():
+        for texts in (b if isinstance(b, tuple) else [b]):
+            texts = list(texts)
+            while sum(map(len, texts)) > 4096:      # (alphabets with multi-char entries overshoot)
+                texts.pop()
+            out.append(texts)
+    return out
+
+
+def _check_batch(batch, oracle, texts, dtype):
+    assert sum(map(len, texts)) <= 4096 and len(texts) <= 512
+    cps, row = pack(texts)
+    want = [_want(oracle, t) for t in texts]
+    counts, offs = batch.split_offsets_csr(cps, row, dtype=dtype)
+    w_off = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
+    assert counts.dtype == offs.dtype == dtype
+    assert counts.tolist() == [len(x) for x in w_off] and offs.tolist() == [int(v) for x in w_off for v in x]
+    tcounts, spans = batch.token_spans_csr(cps, row, dtype=dtype)
+    assert tcounts.tolist() == [len(w) for w in want]
+    assert spans.reshape(-1, 2).tolist() == [[w[3], w[4]] for ws in want for w in ws]
+    fcounts, spans4, feats = batch.token_features_csr(cps, row, dtype=dtype)
+    assert fcounts.tolist() == tcounts.tolist() and spans4.dtype == dtype and feats.dtype == np.int8
+    assert spans4.reshape(-1, 4).tolist() == [[w[1], w[2], w[3], w[4]] for ws in want for w in ws]
+    flat = [w[5] for ws in want for w in ws]
+    assert np.array_equal(feats, np.stack(flat) if flat else np.zeros((0, 25), np.int8))
+
+
+def test_small_batches_equal_the_oracle(gpu, oracle):
+    from latok_amd import batch
+    for i, texts in enumerate(_flat()):
+        _check_batch(batch, oracle, texts, np.int32 if i & 1 else np.int64)
+
+
+def test_small_batches_with_runtime_rule_tables(gpu, oracle):
+    """the same through the rule interpreter (the built-in tables installed as run-time tables give the built-in results)"""
+    from latok_amd import batch
+    from latok_amd.core import default_tokenizer as dt
+    batch.set_rules(dt.C_SPLIT, dt.C_MASK, dt.C_SYM)
+    try:
+        assert batch.rules_active()
+        for i, texts in enumerate(_flat()[::3]):
+            _check_batch(batch, oracle, texts, np.int64 if i & 1 else np.int32)
+    finally:
+        batch.reset_rules()
+
+
+def test_drop_in_calls_one_string_at_a_time(gpu, oracle):
+    from latok_amd.core import default_tokenizer as dt
+    rng = random.Random(77)
+    texts = [t for b in _flat() for t in b if t][:200] + random_strings(rng, 200, 1, 300, ALPHABETS["mixed"])
+    for t in texts:
+        want = _want(oracle, t)
+        assert list(dt.tokenize(t)) == (oracle.tokenize(t))
+        got = list(dt.featurize(t))
+        assert [(x.text, x.start_idx, x.end_idx) for x in got] == [(w[0], w[1], w[2]) for w in want]
+        assert all(np.array_equal(x.features, w[5]) for x, w in zip(got, want))
+    # the vectors of one call are not views of a buffer the next call overwrites
+    first = list(dt.featurize(texts[0]))
+    keep = [x.features.copy() for x in first]
+    list(dt.featurize("something else entirely, #with @other http://tokens.example/x"))
+    assert all(np.array_equal(x.features, k) for x, k in zip(first, keep))
+
+
+def test_edges_of_the_path(gpu, oracle):
+    """one char / one string more than the path takes: the large pipeline gives the same answers"""
+    from latok_amd import batch
+    rng = random.Random(5)
+    for texts in (["".join(rng.choice(ALPHABETS["mixed"]) for _ in range(4097))],
+                  random_strings(rng, 513, 0, 7, ALPHABETS["starts"]),
+                  random_strings(rng, 3, 1300, 1366, ALPHABETS["words"])):
+        cps, row = pack(texts)
+        counts, offs = batch.split_offsets_csr(cps, row)
+        w_off = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
+        assert counts.tolist() == [len(x) for x in w_off] and offs.tolist() == [int(v) for x in w_off for v in x]
+        want = [_want(oracle, t) for t in texts]
+        _, spans4, feats = batch.token_features_csr(cps, row)
+        assert spans4.reshape(-1, 4).tolist() == [[w[1], w[2], w[3], w[4]] for ws in want for w in ws]
+        assert np.array_equal(feats, np.stack([w[5] for ws in want for w in ws]))
+
+
+def test_without_polling_the_call_waits_for_the_stream(gpu):
+    """LATOK_SMALL_POLL=0: the same results with hipStreamSynchronize instead of the completion word"""
+    code = ("from latok_amd.core import default_tokenizer as dt\n"
+            "t = 'This is a #test! see http://a.b/c or mail me@x.org, camelCase 1 2 3'\n"
+            "print(list(dt.tokenize(t)))\n"
+            "print([(x.text, x.start_idx, x.end_idx, x.features.tolist()) for x in dt.featurize(t)])\n")
+    outs = []
+    for poll in ("1", "0"):
+        env = dict(os.environ, LATOK_SMALL_POLL=poll, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and "'#test'" in outs[0]

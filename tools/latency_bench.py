@@ -34,3 +34,6 @@ a32 = (cps.ctypes.data, row.ctypes.data, 1, len(text), c32.ctypes.data, o32.ctyp
 timeit("latok_token_spans_batch, int32 (C ABI)", lambda: lib.latok_token_spans_batch(*a32), 2000)
 timeit("batch.pack([text])", lambda: batch.pack([text]), 2000)
 timeit("dt._sync_rules()", lambda: dt._sync_rules(), 2000)
+f32 = np.empty((len(text), 25), np.int8); s32 = np.empty(4 * len(text), np.int32)
+af = (cps.ctypes.data, row.ctypes.data, 1, len(text), c32.ctypes.data, s32.ctypes.data, f32.ctypes.data, len(text), C.byref(n_out), _lib.OUT_INT32, None)
+timeit("latok_token_features_batch, int32 (C ABI)", lambda: lib.latok_token_features_batch(*af), 2000)

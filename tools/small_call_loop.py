@@ -10,8 +10,14 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cps, row = batch.pack([text])
 counts = np.zeros(1, np.int64); offs = np.empty(len(text), np.int64); n_out = C.c_int64(0)
 args = (cps.ctypes.data, row.ctypes.data, 1, len(text), counts.ctypes.data, offs.ctypes.data, offs.size, C.byref(n_out), 0, None)
-lib.latok_split_offsets_batch(*args)
+fn = lib.latok_split_offsets_batch
+if len(sys.argv) > 2 and sys.argv[2] == "features":
+    spans4 = np.empty(4 * len(text), np.int64); feats = np.empty((len(text), 25), np.int8)
+    args = (cps.ctypes.data, row.ctypes.data, 1, len(text), counts.ctypes.data, spans4.ctypes.data, feats.ctypes.data, len(text),
+            C.byref(n_out), 0, None)
+    fn = lib.latok_token_features_batch
+fn(*args)
 t = time.perf_counter()
 for _ in range(n):
-    lib.latok_split_offsets_batch(*args)
-print(f"{(time.perf_counter() - t) / n * 1e6:.1f} us per call, {n_out.value} offsets")
+    fn(*args)
+print(f"{(time.perf_counter() - t) / n * 1e6:.1f} us per call, {n_out.value} items")

@@ -118,6 +118,8 @@ static bool wait_completion_word(const unsigned long long* word, unsigned long l
     }
 }
 
+static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
 // host-pointer calls up to this size take the pinned zero-copy path (inputs are then read over the bus, including the
 // binary searches over row_off, so it only pays for small batches; larger ones amortise their copies)
 constexpr int64_t kSmallChars = 16384;
@@ -1366,6 +1368,21 @@ int latok_parse_matrix(const uint32_t* cps, int64_t n, int8_t* matrix_out, int f
         HIP_TRY(latok::launch_parse_matrix(cps, n, t1, t2, cw, matrix_out, st));
         return LATOK_OK;
     }
+    if (n <= latok::kSmallMatrixChars) {
+        // one string per call (the reference's pattern): chars and matrix pass through pinned memory, one workgroup, and the
+        // call returns when it has seen the kernel's completion word
+        const size_t po_out = align16((size_t)n * 4);
+        if ((rc = g.pin.ensure(po_out + (size_t)n * LATOK_FEATURE_COUNT + 64))) return rc;
+        if ((rc = g.pin_tot.ensure(64))) return rc;
+        memcpy(g.pin.h, cps, (size_t)n * 4);
+        const unsigned long long seq = ++g.small_seq;
+        unsigned long long* d_done = poll_completion() ? (unsigned long long*)g.pin_tot.d + 2 : nullptr;
+        HIP_TRY(latok::launch_parse_matrix_small((const uint32_t*)g.pin.d, (int)n, t1, t2, cw, (int8_t*)((char*)g.pin.d + po_out), d_done,
+                                                 seq, st));
+        if (!(d_done && wait_completion_word((const unsigned long long*)g.pin_tot.h + 2, seq))) HIP_TRY(hipStreamSynchronize(st));
+        memcpy(matrix_out, (char*)g.pin.h + po_out, (size_t)n * LATOK_FEATURE_COUNT);
+        return LATOK_OK;
+    }
     if ((rc = g.h_cps.ensure((size_t)n * 4))) return rc;
     if ((rc = g.h_out.ensure((size_t)n * LATOK_FEATURE_COUNT))) return rc;
     HIP_TRY(hipMemcpyAsync(g.h_cps.p, cps, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1392,15 +1409,33 @@ int latok_combine_matrix_rows(const int8_t* m, int64_t rows, int64_t cols, int64
         HIP_TRY(latok::launch_combine_rows((const uint8_t*)m, stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out, st));
         return LATOK_OK;
     }
-    // host: gather the (possibly strided) matrix into a dense rows x cols copy, upload, run, download
-    std::vector<int8_t> dense((size_t)rows * (size_t)cols);
-    for (int64_t r = 0; r < rows; ++r)
-        for (int64_t c = 0; c < cols; ++c) dense[(size_t)(r * cols + c)] = m[r * stride_r + c * stride_c];
     // the reference does not bounds-check idx (latok.c:324-327); we refuse out-of-range rows instead of reading wild
     for (int i = 0; i < n_idx; ++i) {
         const uint8_t r = (uint8_t)idx[i];
         if (r != 255 && (int64_t)r >= rows) return fail(LATOK_ERR_INVALID, "idx value %d out of range for %lld rows", (int)r, (long long)rows);
     }
+    if (cols <= latok::kSmallMatrixChars && rows <= 64) {
+        // the matrix of one string: gathered straight into pinned memory, one workgroup, completion word (see latok_parse_matrix)
+        const size_t n_m = (size_t)rows * (size_t)cols;
+        const size_t po_idx = align16(n_m), po_out = po_idx + align16((size_t)n_idx);
+        if ((rc = g.pin.ensure(po_out + (size_t)cols + 64))) return rc;
+        if ((rc = g.pin_tot.ensure(64))) return rc;
+        int8_t* hm = (int8_t*)g.pin.h;
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t c = 0; c < cols; ++c) hm[(size_t)(r * cols + c)] = m[r * stride_r + c * stride_c];
+        if (n_idx) memcpy((char*)g.pin.h + po_idx, idx, (size_t)n_idx);
+        const unsigned long long seq = ++g.small_seq;
+        unsigned long long* d_done = poll_completion() ? (unsigned long long*)g.pin_tot.d + 2 : nullptr;
+        HIP_TRY(latok::launch_combine_rows((const uint8_t*)g.pin.d, cols, 1, cols, (const int8_t*)((char*)g.pin.d + po_idx), idx_ndim,
+                                           irows, icols, (int8_t*)((char*)g.pin.d + po_out), st, d_done, seq));
+        if (!(d_done && wait_completion_word((const unsigned long long*)g.pin_tot.h + 2, seq))) HIP_TRY(hipStreamSynchronize(st));
+        memcpy(out, (char*)g.pin.h + po_out, (size_t)cols);
+        return LATOK_OK;
+    }
+    // host: gather the (possibly strided) matrix into a dense rows x cols copy, upload, run, download
+    std::vector<int8_t> dense((size_t)rows * (size_t)cols);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) dense[(size_t)(r * cols + c)] = m[r * stride_r + c * stride_c];
     if ((rc = g.h_cps.ensure(dense.size() + 16))) return rc;
     if ((rc = g.h_aux.ensure((size_t)n_idx + 16))) return rc;
     if ((rc = g.h_out.ensure((size_t)cols))) return rc;
@@ -1425,6 +1460,30 @@ int latok_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, int8_t* out,
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
     // the block mask of ONE array pair is the batch pipeline over a single "string" [0, n) whose planes are a1 / a2
     const int64_t row[2] = {0, n};
+    if (!dev && n <= latok::kTile) {
+        // at most one tile: one single-wave launch on pinned memory, completion word (see compact_common)
+        const size_t an = align16((size_t)n);
+        if ((rc = g.pin.ensure(3 * an + 16 + 64))) return rc;
+        if ((rc = g.pin_tot.ensure(64))) return rc;
+        memcpy(g.pin.h, a1, (size_t)n);
+        memcpy((char*)g.pin.h + an, a2, (size_t)n);
+        memcpy((char*)g.pin.h + 3 * an, row, 16);
+        latok::SplitParams P;
+        memset(&P, 0, sizeof(P));
+        P.row_off = (const int64_t*)((char*)g.pin.d + 3 * an);
+        P.n_str = 1;
+        P.total = n;
+        P.n_tiles = 1;
+        P.bm_a1 = (const int8_t*)g.pin.d;
+        P.bm_a2 = (const int8_t*)((char*)g.pin.d + an);
+        P.values_out = (uint8_t*)((char*)g.pin.d + 2 * an);
+        const unsigned long long seq = ++g.small_seq;
+        unsigned long long* d_done = poll_completion() ? (unsigned long long*)g.pin_tot.d + 2 : nullptr;
+        HIP_TRY(latok::launch_small_block_mask(P, d_done, seq, st));
+        if (!(d_done && wait_completion_word((const unsigned long long*)g.pin_tot.h + 2, seq))) HIP_TRY(hipStreamSynchronize(st));
+        memcpy(out, (char*)g.pin.h + 2 * an, (size_t)n);
+        return LATOK_OK;
+    }
     if ((rc = g.h_row.ensure(16))) return rc;
     HIP_TRY(hipMemcpyAsync(g.h_row.p, row, 16, hipMemcpyHostToDevice, st));
     const int8_t *d1 = a1, *d2 = a2;

@@ -66,42 +66,92 @@ hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1
     return hipGetLastError();
 }
 
+// One string of at most kSmallMatrixChars chars whose chars and matrix live in pinned host memory (the reference's calling
+// pattern: _gen_parse_matrix(text) per string, latok.c:46-146): ONE workgroup; every char's base word is looked up once
+// (all loads in flight together), the 25-byte rows meet in LDS and leave as dwords -- byte stores over the bus are slow --
+// and the last store is the completion word the host polls (api.cpp: wait_completion_word).
+__global__ __launch_bounds__(256) void k_parse_matrix_small(const uint32_t* __restrict__ cps, int n, const uint8_t* __restrict__ t1,
+                                                           const uint8_t* __restrict__ t2cls, const uint16_t* __restrict__ cw,
+                                                           int8_t* __restrict__ out, unsigned long long* done,
+                                                           unsigned long long seq) {
+    __shared__ uint32_t s_w[kSmallMatrixChars];
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[256 * 25];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) s_w[i] = base_word(t1, t2cls, cw, cps[i]);
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        if (i < n) {
+            const uint32_t bits = feature_row_bits(s_w[i], i > 0 ? s_w[i - 1] : 0u, i + 1 < n ? s_w[i + 1] : 0u,
+                                                   i + 2 < n ? s_w[i + 2] : 0u, i == 0, i + 1 == n);
+#pragma unroll
+            for (int c = 0; c < 25; ++c) s_rows[tid * 25 + c] = (uint8_t)((bits >> c) & 1u);
+        }
+        __syncthreads();
+        const int n_bytes = min(256, n - i0) * 25;
+        int8_t* dst = out + (size_t)i0 * 25;                 // (i0 * 25 is a multiple of 6400: dword aligned when out is)
+        for (int k = tid; k < (n_bytes >> 2); k += 256)
+            reinterpret_cast<uint32_t*>(dst)[k] = reinterpret_cast<const uint32_t*>(s_rows)[k];
+        for (int k = (n_bytes & ~3) + tid; k < n_bytes; k += 256) dst[k] = (int8_t)s_rows[k];
+        __syncthreads();
+    }
+    if (done) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_parse_matrix_small(const uint32_t* cps, int n, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
+                                     int8_t* out, unsigned long long* done, unsigned long long seq, hipStream_t st) {
+    if (n <= 0 || n > kSmallMatrixChars) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_parse_matrix_small, dim3(1), dim3(256), 0, st, cps, n, t1, t2cls, cw, out, done, seq);
+    return hipGetLastError();
+}
+
 // ---- _combine_matrix_rows -----------------------------------------------------------------------------------------
 // One thread per output element k.  uint8 wrap-around; 2-D idx: sum over idx rows of the product over idx columns,
 // -1 skipped; the running product is only re-initialised by column 0 (latok.c:328-333), so an idx row that starts
 // with -1 keeps multiplying the previous row's product -- kept.  1-D idx: plain sum (latok.c:342-354).
 __global__ void k_combine_rows(const uint8_t* __restrict__ m, int64_t stride_r, int64_t stride_c, int64_t cols,
                                const int8_t* __restrict__ idx, int idx_ndim, int irows, int icols,
-                               int8_t* __restrict__ out) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= cols) return;
-    uint8_t acc = 0, prod = 0;
-    if (idx_ndim == 2) {
-        for (int i = 0; i < irows; ++i) {
-            for (int j = 0; j < icols; ++j) {
-                const uint8_t r = (uint8_t)idx[i * icols + j];
-                if (r == 255) continue;
-                const uint8_t v = m[(int64_t)r * stride_r + k * stride_c];
-                prod = j == 0 ? v : (uint8_t)(prod * v);
+                               int8_t* __restrict__ out, unsigned long long* done, unsigned long long seq) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cols; k += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t acc = 0, prod = 0;
+        if (idx_ndim == 2) {
+            for (int i = 0; i < irows; ++i) {
+                for (int j = 0; j < icols; ++j) {
+                    const uint8_t r = (uint8_t)idx[i * icols + j];
+                    if (r == 255) continue;
+                    const uint8_t v = m[(int64_t)r * stride_r + k * stride_c];
+                    prod = j == 0 ? v : (uint8_t)(prod * v);
+                }
+                acc = (uint8_t)(acc + prod);
             }
-            acc = (uint8_t)(acc + prod);
+        } else {
+            for (int j = 0; j < icols; ++j) {
+                const uint8_t r = (uint8_t)idx[j];
+                if (r == 255) continue;
+                acc = (uint8_t)(acc + m[(int64_t)r * stride_r + k * stride_c]);
+            }
         }
-    } else {
-        for (int j = 0; j < icols; ++j) {
-            const uint8_t r = (uint8_t)idx[j];
-            if (r == 255) continue;
-            acc = (uint8_t)(acc + m[(int64_t)r * stride_r + k * stride_c]);
-        }
+        out[k] = (int8_t)acc;
     }
-    out[k] = (int8_t)acc;
+    if (done) {   // one-workgroup launches only (small host arrays in pinned memory): the completion word the host polls
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
-                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st) {
+                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st, unsigned long long* done,
+                               unsigned long long seq) {
     if (cols <= 0) return hipSuccess;
     const int threads = 256;
-    hipLaunchKernelGGL(k_combine_rows, dim3((unsigned)((cols + threads - 1) / threads)), dim3(threads), 0, st, m,
-                       stride_r, stride_c, cols, idx, idx_ndim, irows, icols, out);
+    const unsigned blocks = done ? 1u : (unsigned)((cols + threads - 1) / threads);
+    hipLaunchKernelGGL(k_combine_rows, dim3(blocks), dim3(threads), 0, st, m, stride_r, stride_c, cols, idx, idx_ndim, irows,
+                       icols, out, done, seq);
     return hipGetLastError();
 }
 

@@ -106,8 +106,17 @@ hipError_t launch_any_nonzero(const int8_t* a1, const int8_t* a2, int64_t n, int
 // aux_kernels.hip
 hipError_t launch_parse_matrix(const uint32_t* cps, int64_t n, const uint8_t* t1, const uint8_t* t2cls,
                                const uint16_t* cw, int8_t* out, hipStream_t st);
+// one string of at most kSmallMatrixChars chars in pinned memory: one workgroup; done (or NULL) receives seq after the last store
+constexpr int kSmallMatrixChars = 4096;
+hipError_t launch_parse_matrix_small(const uint32_t* cps, int n, const uint8_t* t1, const uint8_t* t2cls, const uint16_t* cw,
+                                     int8_t* out, unsigned long long* done, unsigned long long seq, hipStream_t st);
+// done != NULL: one workgroup, which stores seq into *done after its last output (small arrays in pinned memory)
 hipError_t launch_combine_rows(const uint8_t* m, int64_t stride_r, int64_t stride_c, int64_t cols, const int8_t* idx,
-                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st);
+                               int idx_ndim, int irows, int icols, int8_t* out, hipStream_t st,
+                               unsigned long long* done = nullptr, unsigned long long seq = 0);
+// _gen_block_mask of one array pair of at most kTile elements (P.bm_a1 / bm_a2 / values_out / row_off = {0, n} in pinned
+// memory, P.total = n): one single-wave launch
+hipError_t launch_small_block_mask(const SplitParams& P, unsigned long long* done, unsigned long long seq, hipStream_t st);
 hipError_t launch_rebase_rows(int64_t* row, int64_t n, int64_t base, hipStream_t st);
 int64_t scan_blocks(int64_t n);   // entries the caller must provide in `block_tot`
 hipError_t launch_exclusive_scan(const int64_t* in, int64_t n, int64_t* out, int64_t* total, int64_t* block_tot,

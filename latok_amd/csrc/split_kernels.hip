@@ -2077,6 +2077,52 @@ hipError_t launch_small_batch(const SplitParams& P, bool rules, int kind, bool o
     return hipGetLastError();
 }
 
+// _gen_block_mask (latok.c:150-270) of ONE small array pair: the tile function in block-mask mode on a single tile, the
+// {any(a1), any(a2)} flags of the reference's element-0 quirk computed by the same wave, the completion word at the end.
+__global__ __launch_bounds__(64) void k_small_block_mask(SmallParams S) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWaveLdsBytes];
+    __shared__ int s_flags[2];
+    const int lane = threadIdx.x;
+    TileLds L;
+    L.t1 = L.t2 = L.lut = L.ctab = nullptr;
+    L.small_bits = L.small_space = nullptr;
+    L.stage = lds;
+    L.halo = lds + kStageBytes;
+    L.bw = reinterpret_cast<lk_u64*>(lds + kStageBytes + 16);
+    SplitParams P = S.P;
+    const int64_t n = P.total;
+    uint32_t f1 = 0, f2 = 0;
+    for (int64_t i = 4 * (int64_t)lane; i < n; i += 256) {
+        if (i + 4 <= n) {
+            f1 |= *reinterpret_cast<const uint32_t*>(P.bm_a1 + i);
+            f2 |= *reinterpret_cast<const uint32_t*>(P.bm_a2 + i);
+        } else {
+            for (int64_t j = i; j < n; ++j) { f1 |= (uint8_t)P.bm_a1[j]; f2 |= (uint8_t)P.bm_a2[j]; }
+        }
+    }
+    const int any1 = __any(f1 != 0u), any2 = __any(f2 != 0u);
+    if (lane == 0) { s_flags[0] = any1; s_flags[1] = any2; }
+    wave_lds_sync();
+    P.bm_flags = s_flags;
+    process_tile<kModeBlockMask, false, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);
+    if (S.done) {
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(S.done, S.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_small_block_mask(const SplitParams& P, unsigned long long* done, unsigned long long seq, hipStream_t st) {
+    SmallParams S;
+    S.P = P;
+    S.counts = S.items = nullptr;
+    S.features = nullptr;
+    S.n_items = nullptr;
+    S.done = done;
+    S.seq = seq;
+    hipLaunchKernelGGL(k_small_block_mask, dim3(1), dim3(64), 0, st, S);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------------------------------------------

@@ -149,3 +149,25 @@ def test_without_polling_the_call_waits_for_the_stream(gpu):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout)
     assert outs[0] == outs[1] and "'#test'" in outs[0]
+
+
+def test_three_native_functions_on_one_string(gpu, oracle):
+    """_gen_parse_matrix / _combine_matrix_rows / _gen_block_mask (reference latok.c:373-378) called per string, as the
+    reference's gen_split_mask does: up to 4096 chars each is one launch on pinned memory with a polled completion word;
+    sizes on both sides of that edge and of the 256-char rounds of the matrix kernel."""
+    from latok_amd import latok as lt
+    from latok_amd.core import default_tokenizer as dt
+    rng = random.Random(2468)
+    for n in (1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 4095, 4096, 4097, 5000):
+        t = "".join(rng.choice(ALPHABETS["mixed"] + ["http://a", "b@c", " #t "]) for _ in range(n))[:n]
+        m = lt._gen_parse_matrix(t)
+        want = oracle.gen_parse_matrix(t)
+        assert m.dtype == np.int8 and m.shape == (n, 25) and np.array_equal(m, want), n
+        mt = m.T
+        for tbl in (dt.C_SPLIT, dt.C_MASK, dt.C_SYM, np.array([0, 3, 5], np.int8)):
+            assert np.array_equal(lt._combine_matrix_rows(mt, tbl), oracle.combine_matrix_rows(want.T, tbl)), n
+        a1 = np.array([rng.random() < 0.05 for _ in range(n)], np.int8)
+        a2 = np.array([rng.random() < 0.2 for _ in range(n)], np.int8)
+        for x1, x2 in ((a1, a2), (a1, np.zeros(n, np.int8)), (np.zeros(n, np.int8), a2), (np.ones(n, np.int8), a2)):
+            assert np.array_equal(lt._gen_block_mask(x1, x2), oracle.gen_block_mask(x1, x2)), n
+        assert np.array_equal(dt.gen_split_mask(m), oracle.gen_split_mask(want)), n

@@ -122,7 +122,8 @@ def split_offsets_csr(cps, row_off, dtype=np.int64):
 
 # host batches beyond the library's small-batch path (api.cpp: kSmallChars / kSmallStrings, served from pinned memory
 # in UTF-32) are shipped as the narrowest PEP 393 kind: 1 or 2 bytes per char over the bus instead of 4
-_SMALL_CHARS, _SMALL_STRINGS = 16384, 512
+_SMALL_CHARS, _SMALL_STRINGS = 262144, 16384     # api.cpp: kSmallChars / kSmallStrings (pinned zero-copy path)
+_ONE_MAX = 16384                                   # split_offsets_one: the per-thread output array
 
 
 _ROW1 = None
@@ -135,14 +136,14 @@ def split_offsets_one(text: str) -> np.ndarray:
     a copy of the offsets out of a per-thread output array."""
     global _ROW1
     n = len(text)
-    if n > _SMALL_CHARS:
+    if n > _ONE_MAX:
         return split_offsets_batch([text])[0]
     lib = _lib.ensure_init()
     if _ROW1 is None:
         _ROW1 = threading.local()
     st = getattr(_ROW1, "st", None)
     if st is None:
-        row, count, offs, n_out = np.zeros(2, np.int64), np.zeros(1, np.int32), np.empty(_SMALL_CHARS, np.int32), C.c_int64(0)
+        row, count, offs, n_out = np.zeros(2, np.int64), np.zeros(1, np.int32), np.empty(_ONE_MAX, np.int32), C.c_int64(0)
         st = _ROW1.st = (row, count, offs, n_out, row.ctypes.data, count.ctypes.data, offs.ctypes.data, C.byref(n_out))
     row, _, offs, n_out, p_row, p_count, p_offs, p_n = st
     row[1] = n

@@ -120,10 +120,13 @@ static bool wait_completion_word(const unsigned long long* word, unsigned long l
 
 static inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// host-pointer calls up to this size take the pinned zero-copy path (inputs are then read over the bus, including the
-// binary searches over row_off, so it only pays for small batches; larger ones amortise their copies)
-constexpr int64_t kSmallChars = 16384;
-constexpr int64_t kSmallStrings = 512;
+// host-pointer calls up to this size take the pinned zero-copy path: the arrays are copied into pinned mapped memory by
+// the host and the kernels read / write them over the bus, including the binary searches over row_off.  Measured against
+// the staged-copy path (tools/batch_size_sweep.py, offsets of strings of ~105 chars, us per call): 16 K chars 70 / 112,
+// 54 K 60 / 120, 108 K 75 / 137; the two meet near 1 M chars, where the host's own memcpy into the pinned area is what
+// the call costs either way.
+constexpr int64_t kSmallChars = 262144;
+constexpr int64_t kSmallStrings = 16384;
 
 // One context = one device, one stream, one set of tables / workspaces / staging buffers, one rule-table state and one
 // lock.  Calls on the same context are serialised by its lock; calls on different contexts (other devices, or the same

@@ -733,7 +733,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     return out_word;
 }
 
-template <int MODE, bool DEFER = false, bool SMALL = false>
+template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
                                              int tail_zero, bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
@@ -772,6 +772,53 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         units_phase1<2>(P, L, t0, lane);
     } else if (MODE == kModeBytes) {
         raw_stage = bytes_phase1(P, L, t0, lane);
+    } else if (FAST_TAIL) {
+        // Small batches: the batch's last, partial tile takes the same road as a full one -- only the rows of 256 chars that
+        // exist are requested, all of them before the first table lookup; chars that do not exist read as 0 and their
+        // codes are masked to 0 ("nothing") -- because its latency is a visible share of the call: a one-tile batch with
+        // its chars in host memory (k_small_batch) spent most of its 13 us in the 16 serial load -> lookup rounds of the
+        // general form below, a 4-tile batch on the pinned path 15 of its 31 us.  (Not for large batches: the shared
+        // loop costs the full-tile path 16 VGPRs and 4 % on C2.)
+        const bool full = t0 + kTile <= total;
+        u32x4 v[16];
+        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
+        const int64_t remain0 = total - t0 - 4 * (int64_t)lane;       // chars that exist from my first char on (row 0)
+        int n_rows = 16;
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        } else {
+            // One 16-byte load per existing row and lane, nothing divergent around it and no zero-fill before it (a divergent
+            // x4 / scalar-tail choice, or a register write the compiler cannot order against loads in flight, makes it wait
+            // for outstanding loads between the rows: they would arrive one by one again).  A lane beyond the end re-reads
+            // the 16-byte block that holds the last char; a lane whose 4 chars straddle the end reads up to 12 bytes past
+            // the last char inside that block (cps is 16-byte aligned: the same page).  The codes of chars that do not
+            // exist are masked below.
+            const int64_t last_blk = (total - 1) & ~(int64_t)3;
+            n_rows = (int)((total - t0 + 255) >> 8);                  // wave-uniform, 1..16
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < n_rows) {
+                    int64_t p = t0 + 256 * i + 4 * (int64_t)lane;
+                    p = p < last_blk ? p : last_blk;
+                    v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(P.cps + p));
+                }
+            }
+        }
+        uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t c = 0;
+            if (i < n_rows) {
+                c = classify4(L.t1, L.t2, v[i]);
+                if (!full) {
+                    const int64_t remain = remain0 - 256 * i;
+                    c &= remain >= 4 ? 0xFFFFFFFFu : (remain <= 0 ? 0u : ((1u << (8 * (int)remain)) - 1u));
+                }
+            }
+            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
+            if (codes) codes[64 * i] = c;
+        }
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
@@ -790,43 +837,9 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
             *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
             if (codes) codes[64 * i] = c;                                     // 256 contiguous bytes per wave instruction
         }
-    } else if (SMALL) {
-        // a batch of at most one tile, latency matters (k_small_batch: the chars sit in host memory, the tables in global
-        // memory).  Only the rows of 256 chars that exist are loaded and classified, all loads before the first lookup
-        // (the 16 serial load -> lookup rounds of the general path below were most of that kernel's time).
-        uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;
-        const int n_rows = (int)((total - t0 + 255) >> 8);            // wave-uniform, 1..16
-        const int64_t remain0 = total - t0 - 4 * (int64_t)lane;       // chars that exist from my first char on (row 0)
-        const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-        u32x4 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] = u32x4{0u, 0u, 0u, 0u};
-            if (i < n_rows) {
-                const int64_t remain = remain0 - 256 * i;
-                if (remain >= 4) {
-                    v[i] = __builtin_nontemporal_load(src + 64 * i);
-                } else {
-                    const uint32_t* q = P.cps + t0 + 256 * i + 4 * lane;
-                    if (remain > 0) v[i].x = q[0];
-                    if (remain > 1) v[i].y = q[1];
-                    if (remain > 2) v[i].z = q[2];
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            uint32_t c = 0;
-            if (i < n_rows) {
-                const int64_t remain = remain0 - 256 * i;
-                const uint32_t exist = remain >= 4 ? 0xFFFFFFFFu : (remain <= 0 ? 0u : ((1u << (8 * (int)remain)) - 1u));
-                c = classify4(L.t1, L.t2, v[i]) & exist;              // a char that does not exist has code 0 ("nothing")
-            }
-            *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
-            if (codes) codes[64 * i] = c;
-        }
     } else {
-        // the batch's last, partial tile (its code bytes are written up to the end of the tile: 0 behind the last char)
+        // the batch's last, partial tile of a large batch (its code bytes are written up to the end of the tile: 0 behind
+        // the last char)
         uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;
 #pragma unroll 1
         for (int i = 0; i < 16; ++i) {
@@ -1078,7 +1091,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 #define LATOK_STAMP_PARAM
 #endif
 
-template <int MODE>
+template <int MODE, bool FAST_TAIL = false>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
                                             int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
@@ -1123,7 +1136,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         if (++slot == 8) flush();
     };
     for (int k = wave, j = 0; k < n_seg; k += kWPB, ++j) {
-        const lk_u64 w = process_tile<MODE, kDefer>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
+        const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
         stamp_acc[0] += 1;
@@ -1150,7 +1163,10 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     __syncthreads();
 }
 
-template <int MODE>
+// FAST_TAIL: the batch's last, partial tile requests all its rows before the first lookup (process_tile).  Chosen for small
+// batches, where that tile's latency is a visible share of the call (a 4-tile batch in pinned host memory: 31 -> 16 us);
+// the large-batch instantiation keeps the serial tail: the unified form costs its full-tile loop 16 VGPRs and 4 % on C2.
+template <int MODE, bool FAST_TAIL = false>
 __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
     const int tid = threadIdx.x;
@@ -1165,7 +1181,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
 #endif
     for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
-        run_segment<MODE>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
+        run_segment<MODE, FAST_TAIL>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
         tables = false;
     }
 #ifdef LATOK_STAMPS
@@ -1889,7 +1905,7 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     // the bounds of the first 64 strings, requested now: they travel over the bus together with the tile's chars
     int64_t ro_a = 0, ro_b = 0;
     if (lane < n_str) { ro_a = P.row_off[lane]; ro_b = P.row_off[lane + 1]; }
-    const lk_u64 xb = process_tile<MODE, false, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);   // boundaries of my word
+    const lk_u64 xb = process_tile<MODE, false, true, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);   // boundaries of my word
     wave_lds_sync();
     const int64_t base = 64 * (int64_t)lane;
     // ---- which boundaries are items (spans: those whose token holds a non-SPACE char), like k_word_counts -------------
@@ -2104,7 +2120,7 @@ __global__ __launch_bounds__(64) void k_small_block_mask(SmallParams S) {
     if (lane == 0) { s_flags[0] = any1; s_flags[1] = any2; }
     wave_lds_sync();
     P.bm_flags = s_flags;
-    process_tile<kModeBlockMask, false, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);
+    process_tile<kModeBlockMask, false, true, true>(P, L, 0, 0, 0, -1, false, nullptr, lane);
     if (S.done) {
         __threadfence_system();
         if (lane == 0) __hip_atomic_store(S.done, S.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2177,6 +2193,7 @@ void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
     *n_segs = (n_tiles + s - 1) / s;
 }
 
+constexpr int64_t kFastTailTiles = 256;   // ~1 M chars: beyond that one tile's latency is noise
 static inline int grid_for(const SplitParams& P, int n_cu) {
     return (int)(P.n_segs < n_cu ? (P.n_segs < 1 ? 1 : P.n_segs) : n_cu);
 }
@@ -2190,7 +2207,10 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
         return hipLaunchCooperativeKernel((const void*)(k_tiles_main<kModeBits>), grid, block, args, 0, st);
     }
 #endif
-    if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
+    const bool fast_tail = P.n_tiles <= kFastTailTiles;
+    if (mode == kModeBits && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeBits, true>), grid, block, 0, st, P);
+    else if (mode == kModeRules && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeRules, true>), grid, block, 0, st, P);
+    else if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
     else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);

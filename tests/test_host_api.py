@@ -107,7 +107,7 @@ def test_pack_kind_picks_the_narrowest_pep393_kind():
         batch._csr_kind(np.zeros(3, np.int32), np.array([0, 3], np.int64))
     with pytest.raises(ValueError):
         batch._csr_kind(np.zeros(3, np.uint16), np.array([0, 5], np.int64))
-    assert batch._narrow_pays(["x" * 20000]) and batch._narrow_pays([""] * 600) and not batch._narrow_pays(["abc"])
+    assert batch._narrow_pays(["x" * 300000]) and batch._narrow_pays([""] * 17000) and not batch._narrow_pays(["abc"])
 
 
 def test_compat_argument_errors_do_not_need_a_gpu():

@@ -29,6 +29,9 @@ REGIMES = [
     ("rare_space_at", (1, 4), (4000, 40000)), ("starts", (500, 4000), (1, 3)), ("words", (1, 6), (8000, 20000)),
     ("latin1", (1, 400), (0, 200)), ("bmp", (1, 400), (0, 200)), ("latin1", (1, 4), (3000, 30000)), ("bmp", (1, 4), (3000, 30000)),
     ("bmp", (500, 3000), (1, 3)),
+    # at most one tile: the single-launch path of small host batches (k_small_batch: offsets, spans, featurize sums)
+    ("mixed", (1, 40), (0, 100)), ("words", (1, 8), (0, 500)), ("bmp", (1, 30), (0, 130)), ("starts", (1, 500), (0, 8)),
+    ("rare_space_at", (1, 2), (1000, 2040)),
 ]
 
 

@@ -31,7 +31,8 @@
  *     reference's own calling pattern, default_tokenizer.py:137-191) are one single-wavefront launch for offsets, spans
  *     and features alike: inputs and outputs pass through pinned memory the kernel reads / writes directly, and the
  *     call returns when it has seen the completion word the kernel stores after its last output (LATOK_SMALL_POLL=0 in
- *     the environment: wait for the stream instead).
+ *     the environment: wait for the stream instead).  Host batches up to 256 K chars / 16 K strings take the same pinned
+ *     route with a handful of launches (up to 24 tiles: one launch for the whole mask pipeline; LATOK_ONE_SEGMENT=0: three).
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H

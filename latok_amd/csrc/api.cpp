@@ -148,6 +148,8 @@ struct Ctx {
     DevBuf h_cps, h_row, h_out, bits, space, kept, wcnt, wpref, counts, bases, scan_tot, scalar, h_aux, tile_first;
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     unsigned long long small_seq = 0;   // completion word of the single-launch small-batch path (pin_tot word 2)
+    DevBuf done_ctr;                    // workgroup counter of latok::DoneSignal (0 between launches)
+    unsigned done_ctr_seen = 0;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
     // chunked host pipeline (compact_host_pipelined): copy streams, events and double buffers
@@ -221,6 +223,12 @@ struct StreamTurn {
     }
 };
 
+// LATOK_ONE_SEGMENT=0 in the environment: small batches take the three-launch pipeline too (A/B, tests)
+static bool one_segment_enabled() {
+    static const bool on = [] { const char* e = getenv("LATOK_ONE_SEGMENT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // enqueue the pipeline on device-resident data
 int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_str, int64_t total, uint64_t* d_bits,
                  uint8_t* d_values, int mode, hipStream_t st, hipEvent_t tiles_begin = nullptr,
@@ -252,6 +260,13 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.total = total;
     P.n_tiles = n_tiles;
     latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
+    // a small UTF-32 batch: one segment, and (below) one launch for the three stages
+    const bool one_launch = stages == 7 && !d_u8 && !tiles_begin && !tiles_end && n_tiles <= latok::kOneSegTiles &&
+                            (mode == latok::kModeBits || mode == latok::kModeRules) && one_segment_enabled();
+    if (one_launch) {
+        P.seg_tiles = (int)(n_tiles < latok::kOneSegTiles ? latok::kOneSegTiles : n_tiles);
+        P.n_segs = 1;
+    }
     if ((size_t)P.n_segs * (sizeof(latok::Fn64) + sizeof(latok::Hd64)) > g.seg_agg.cap || (size_t)n_tiles * 16 > g.summ.cap)
         return fail(LATOK_ERR_INVALID, "internal: workspace too small for %lld segments / %lld tiles", (long long)P.n_segs, (long long)n_tiles);
     if (d_codes && mode != latok::kModeBits && mode != latok::kModeRules)
@@ -275,6 +290,10 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.bm_a1 = bm_a1;
     P.bm_a2 = bm_a2;
     P.bm_flags = bm_flags;
+    if (one_launch) {
+        HIP_TRY(latok::launch_one_segment(P, mode, st));
+        return LATOK_OK;
+    }
     if (stages & 1) HIP_TRY(latok::launch_tile_index(P, st));   // (the kernel-timing loop of latok_bench_split_mask launches stage 1 alone)
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
     if (stages & 2) HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
@@ -371,6 +390,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     g.pin.release();
     g.pin_tot.release();
+    g.done_ctr.release();
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
                       &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
@@ -652,7 +672,7 @@ static int decode_utf8_to_workspace(Ctx& g, const uint8_t* u8, const int64_t* by
 static int enqueue_features(Ctx& g, const uint8_t* d_codes, const int64_t* d_row, int64_t n_str, int64_t total, const uint64_t* d_bits,
                             const uint64_t* d_space, const uint64_t* d_kept, const int64_t* d_rank, const int64_t* d_tile_cnt,
                             const uint16_t* d_pref, const int64_t* d_tile_first, void* d_spans4, int8_t* d_feat, bool out32,
-                            const int64_t* d_n_tokens, int64_t cap, hipStream_t st) {
+                            const int64_t* d_n_tokens, int64_t cap, hipStream_t st, latok::DoneSignal done) {
     latok::FeatParams F;
     F.codes = d_codes;
     F.row_off = d_row;
@@ -671,6 +691,7 @@ static int enqueue_features(Ctx& g, const uint8_t* d_codes, const int64_t* d_row
     F.out32 = out32;
     F.n_tokens_dev = d_n_tokens;
     F.cap = cap;
+    F.done = done;
     HIP_TRY(latok::launch_features_tiles(F, g.n_cu, st));
     return LATOK_OK;
 }
@@ -705,7 +726,8 @@ static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* e
 // host's view of the same two words) when the stream gets there.
 static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, const uint32_t* d_cps, const uint8_t* d_u8, int unit_kind,
                                   const int64_t* d_row, int64_t n_str, int64_t total, void* d_counts, void* d_items, int8_t* d_feat,
-                                  int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st) {
+                                  int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st,
+                                  latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr}) {
     int rc;
     if (d_u8 && unit_kind && (feats || g.rules_on)) {
         // featurize re-reads the code points and the rule interpreter has no narrow-unit form: widen once, on the device
@@ -754,10 +776,10 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
     if (feats) {   // spans and sums come from one kernel
         HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
         return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
-                                d_feat, o32, d_total, cap, st);
+                                d_feat, o32, d_total, cap, st, done);
     }
     HIP_TRY(latok::launch_counts_scatter(spans ? 1 : 0, o32, d_bits, d_space, d_item_mask, d_rank, d_tcnt, d_pref, words, total, d_row,
-                                         n_str, d_tile_first, d_items, d_total, cap, d_counts, d_err, st));
+                                         n_str, d_tile_first, d_items, d_total, cap, d_counts, d_err, st, done));
     return LATOK_OK;
 }
 
@@ -1068,9 +1090,24 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         unsigned long long* d_done = poll_completion() ? (unsigned long long*)(p_tot + 2) : nullptr;
         HIP_TRY(latok::launch_small_batch(P, g.rules_on, feats ? 2 : (spans ? 1 : 0), o32, d_counts, d_items, d_feat, p_tot, d_done, seq, st));
         polled = d_done && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
-    } else if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
-                                            cap, p_tot, h_tot, st))) {
-        return rc;
+    } else {
+        // several tiles in pinned memory: the last kernel's workgroups count themselves in and the last one stores the
+        // completion word (latok::DoneSignal)
+        latok::DoneSignal done{nullptr, 0, nullptr};
+        unsigned long long seq = 0;
+        if (small && poll_completion()) {
+            if ((rc = g.done_ctr.ensure(64))) return rc;
+            if (g.done_ctr.gen != g.done_ctr_seen) {
+                g.done_ctr_seen = g.done_ctr.gen;
+                HIP_TRY(hipMemsetAsync(g.done_ctr.p, 0, 64, st));
+            }
+            seq = ++g.small_seq;
+            done = latok::DoneSignal{(unsigned long long*)(p_tot + 2), seq, (unsigned*)g.done_ctr.p};
+        }
+        if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
+                                         cap, p_tot, h_tot, st, done)))
+            return rc;
+        polled = done.word && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
     }
     // the one synchronisation: total and flag are in pinned memory now (a polled small batch has seen its completion
     // word, which the kernel stores after everything else; the launch itself retires on the stream a moment later)

@@ -238,7 +238,7 @@ __device__ __forceinline__ int64_t scatter_lower_bound(const int64_t* __restrict
 }
 
 template <int KIND, typename OUT>
-__global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
+__device__ __forceinline__ void counts_scatter_block(
     const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
@@ -437,6 +437,18 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
     }
 }
 
+template <int KIND, typename OUT>
+__global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
+    const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space, const uint64_t* __restrict__ item_mask,
+    const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
+    int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
+    const int64_t* __restrict__ tile_first, OUT* __restrict__ out, const int64_t* __restrict__ n_items_dev, int64_t cap,
+    OUT* __restrict__ counts, unsigned n_scatter_blocks, int* __restrict__ err, DoneSignal done) {
+    counts_scatter_block<KIND, OUT>(bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, n_str, tile_first,
+                                    out, n_items_dev, cap, counts, n_scatter_blocks, err);
+    signal_block_done(done);   // (pinned outputs of a small host batch: the host polls the completion word)
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------------------
 int64_t count_blocks(int64_t n_words) { return n_words > 0 ? ((n_words + 63) / 64 + kChainChunk - 1) / kChainChunk : 0; }
 
@@ -474,14 +486,14 @@ static hipError_t launch_counts_scatter_t(const uint64_t* bits, const uint64_t* 
                                           const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref,
                                           int64_t n_words, int64_t total, const int64_t* row_off, int64_t n_str,
                                           const int64_t* tile_first, void* out, const int64_t* n_items_dev, int64_t cap,
-                                          void* counts, int* err, hipStream_t st) {
+                                          void* counts, int* err, hipStream_t st, DoneSignal done) {
     const int64_t per_block = (int64_t)scatter_waves(KIND) * 64;
     const unsigned nb_scatter = out ? (unsigned)((n_words + per_block - 1) / per_block) : 0u;
     const unsigned nb_counts = counts ? (unsigned)((n_str + 255) / 256) : 0u;
     if (nb_scatter + nb_counts == 0) return hipSuccess;
     hipLaunchKernelGGL((k_counts_scatter<KIND, OUT>), dim3(nb_scatter + nb_counts), dim3(scatter_waves(KIND) * 64), 0, st, bits, space,
                        item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, n_str, tile_first, (OUT*)out, n_items_dev,
-                       cap, (OUT*)counts, nb_scatter, err);
+                       cap, (OUT*)counts, nb_scatter, err, done);
     return hipGetLastError();
 }
 
@@ -489,10 +501,10 @@ static hipError_t launch_counts_scatter_t(const uint64_t* bits, const uint64_t* 
 hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                  const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
                                  int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
-                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st) {
+                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st, DoneSignal done) {
     if (n_words <= 0) return hipSuccess;
 #define LATOK_CS(K, T) launch_counts_scatter_t<K, T>(bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, \
-                                                     n_str, tile_first, out, n_items_dev, cap, counts, err, st)
+                                                     n_str, tile_first, out, n_items_dev, cap, counts, err, st, done)
     if (kind == 0) return out32 ? LATOK_CS(0, int32_t) : LATOK_CS(0, int64_t);
     return out32 ? LATOK_CS(1, int32_t) : LATOK_CS(1, int64_t);
 #undef LATOK_CS

@@ -72,6 +72,29 @@ struct SplitParams {
 
 
 // featurize on the tile grid (split_kernels.hip: k_features_tiles)
+// Completion word of a multi-workgroup launch whose outputs land in pinned host memory (small / mid-size host batches): every
+// workgroup drains its stores to system scope and counts itself in; the last one stores `seq` into `word` (which the host
+// polls instead of waiting for the stream) and resets the counter.  word == NULL: off.
+struct DoneSignal {
+    unsigned long long* word;
+    unsigned long long seq;
+    unsigned* counter;     // device memory, 0 between launches
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ void signal_block_done(const DoneSignal& d) {
+    if (!d.word) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned n = gridDim.x;
+        if (atomicAdd(d.counter, 1u) == n - 1u) {
+            *d.counter = 0u;
+            __hip_atomic_store(d.word, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
+
 struct FeatParams {
     const uint8_t* codes;         // rule code of every char (SplitParams::codes_out of the tile kernel), padded by one tile + 256 B
     const int64_t* row_off;
@@ -88,6 +111,7 @@ struct FeatParams {
     bool out32;                   // spans4 holds int32
     const int64_t* n_tokens_dev;  // device: total tokens of the batch (k_word_counts_scan) ...
     int64_t cap;                  // ... nothing is written when it exceeds the caller's capacity
+    DoneSignal done;
 };
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
 
@@ -95,6 +119,10 @@ void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs);
 hipError_t launch_tile_index(const SplitParams& P, hipStream_t st);   // stage 0: P.tile_first (must be set)
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+// the three stages in one launch of one workgroup: batches of at most kOneSegTiles tiles planned as ONE segment
+// (P.n_segs = 1, P.seg_tiles >= P.n_tiles), UTF-32 bitmask modes (kModeBits / kModeRules)
+constexpr int64_t kOneSegTiles = 24;
+hipError_t launch_one_segment(const SplitParams& P, int mode, hipStream_t st);
 // batches of at most one tile, everything in one launch (split_kernels.hip: k_small_batch); P.t1 / P.t2 / P.rules / P.cps /
 // P.row_off / P.n_str / P.total must be set, kind 0 = offsets, 1 = token spans.  done (or NULL): a pinned host word that
 // receives seq once every output is visible to the host.
@@ -133,7 +161,7 @@ hipError_t launch_string_counts(bool out32, const uint64_t* mask, const int64_t*
 hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, const uint64_t* space, const uint64_t* item_mask,
                                  const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
                                  int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
-                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st);
+                                 const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st, DoneSignal done = DoneSignal{nullptr, 0, nullptr});
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

@@ -1086,9 +1086,11 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 #ifdef LATOK_STAMPS
 #define LATOK_STAMP_ARG , stamp_acc
 #define LATOK_STAMP_PARAM , unsigned long long* stamp_acc
+#define LATOK_STAMP_NULL , nullptr
 #else
 #define LATOK_STAMP_ARG
 #define LATOK_STAMP_PARAM
+#define LATOK_STAMP_NULL
 #endif
 
 template <int MODE, bool FAST_TAIL = false>
@@ -1199,20 +1201,18 @@ __global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
 // ---------------------------------------------------------------------------------------------------------------
 // NW = waves per workgroup: NW * 64 threads must cover a segment's tiles (one tile per thread).  Batches whose segments
 // are short (C2: 122 tiles) run it with 2 or 4 waves instead of 12 -- the stage is all latency, fewer waves start faster.
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Stage 2.  ONE = false: k_resolve_fix, every segment of the batch, a workgroup per segment at a time.  ONE = true: the only
+// segment of a small batch, inside the launch that computed it (k_one_segment; the class tables are still in LDS).
+template <int MODE, int NW, bool ONE>
+__device__ __forceinline__ void resolve_segments(const SplitParams& P, uint8_t* lds, int tid, int lane, int wave) {
     const int S = P.seg_tiles;
     ScanLdsT<NW>& scan = *reinterpret_cast<ScanLdsT<NW>*>(lds + kLdsScan);
     int* misc = reinterpret_cast<int*>(lds + kLdsMisc);          // misc[0] = number of tiles to recompute
     int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment (tiles to recompute)
     int2* fix_in = reinterpret_cast<int2*>(lds + kLdsSumm);      // {q_in, tail_zero}
-    bool tables_loaded = false;
+    bool tables_loaded = ONE;
 
-    for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
+    for (int64_t seg = ONE ? 0 : (int64_t)blockIdx.x; seg < (ONE ? 1 : P.n_segs); seg += ONE ? 1 : (int64_t)gridDim.x) {
         const int64_t T0 = seg * S;
         const int64_t T1 = min(T0 + S, P.n_tiles);
         const int n_seg = (int)(T1 - T0);
@@ -1294,6 +1294,61 @@ __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
         }
         __syncthreads();
     }
+}
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    resolve_segments<MODE, NW, false>(P, lds, tid, lane, wave);
+}
+
+// stage 0 (k_tile_index below, k_one_segment): entry s of row_off (s > n_str: nothing); must be called by whole waves (the wide form below uses wave operations)
+__device__ __forceinline__ void tile_index_entry(const int64_t* __restrict__ row_off, int64_t n_str, int64_t n_tiles,
+                                                 int64_t* __restrict__ tile_first, int64_t s, int lane) {
+    int64_t w0 = 0, w1 = -1;
+    if (s <= n_str) {
+        const int64_t p = row_off[s];
+        const int64_t prev = s > 0 ? row_off[s - 1] : -1;
+        w0 = prev < 0 ? 0 : prev / kTile + 1;
+        w1 = p / kTile;
+        if (w1 > n_tiles - 1) w1 = n_tiles - 1;
+    }
+    const bool wide = w1 - w0 >= 16;
+    if (!wide)
+        for (int64_t w = w0; w <= w1; ++w) tile_first[w] = s;
+    unsigned long long m = __ballot(wide);
+    while (m) {   // wave-uniform
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int64_t a = lane_read64(w0, src), b = lane_read64(w1, src), v = lane_read64(s, src);
+        for (int64_t w = a + lane; w <= b; w += 64) tile_first[w] = v;
+    }
+}
+
+
+// A batch of at most kOneSegTiles tiles (P.n_segs == 1, P.seg_tiles >= P.n_tiles): the three stages in ONE launch of one
+// workgroup -- the per-tile string index, the tiles, the resolve stage -- with workgroup barriers where the stream order
+// of the three launches was.  Three dependent launches of a few microseconds of work each cost ~5 us apiece in dispatch
+// and drain; a host batch of 40 ... 1000 short strings is nothing but that.
+template <int MODE>
+__global__ __launch_bounds__(kWPB * 64) void k_one_segment(SplitParams P) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) *P.fix_count = 0;
+    load_tables<kWPB * 64, MODE>(lds, P);                       // (published by the barriers below)
+    for (int64_t base = 0; base <= P.n_str; base += kWPB * 64)  // stage 0
+        tile_index_entry(P.row_off, P.n_str, P.n_tiles, P.tile_first, base + tid, lane);
+    __threadfence_block();
+    __syncthreads();
+    run_segment<MODE, true>(P, lds, 0, tid, lane, wave, true LATOK_STAMP_NULL);   // stage 1 (ends with a barrier)
+    __threadfence_block();
+    __syncthreads();
+    resolve_segments<MODE, kWPB, true>(P, lds, tid, lane, wave);                  // stage 2
 }
 
 // flags[0] = any(a1 != 0), flags[1] = any(a2 != 0) (flags zeroed by the caller)
@@ -1836,20 +1891,23 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 
 template <typename OUT>
 __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P) {
-    if (P.n_tokens_dev && *P.n_tokens_dev > P.cap) return;   // the caller's buffers are too small: nothing is written
     __shared__ __attribute__((aligned(16))) uint8_t lds[kFeatLdsTotal];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    TileLds L;
-    L.small_bits = L.small_space = nullptr;
-    L.t1 = L.t2 = L.lut = L.ctab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
-    uint8_t* mine = lds + wave * kFeatWaveLds;
-    L.stage = mine;
-    L.halo = mine + kFeatWinBytes;
-    L.bw = reinterpret_cast<lk_u64*>(mine + kFeatWinBytes + 16);
-    for (int64_t t = (int64_t)blockIdx.x * kFeatWaves + wave; t < P.n_tiles; t += (int64_t)gridDim.x * kFeatWaves)
-        feature_tile<OUT>(P, L, t, lane);
+    // (the caller's buffers are too small: nothing is written)
+    if (!(P.n_tokens_dev && *P.n_tokens_dev > P.cap)) {
+        TileLds L;
+        L.small_bits = L.small_space = nullptr;
+        L.t1 = L.t2 = L.lut = L.ctab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
+        uint8_t* mine = lds + wave * kFeatWaveLds;
+        L.stage = mine;
+        L.halo = mine + kFeatWinBytes;
+        L.bw = reinterpret_cast<lk_u64*>(mine + kFeatWinBytes + 16);
+        for (int64_t t = (int64_t)blockIdx.x * kFeatWaves + wave; t < P.n_tiles; t += (int64_t)gridDim.x * kFeatWaves)
+            feature_tile<OUT>(P, L, t, lane);
+    }
+    signal_block_done(P.done);   // (pinned outputs of a small host batch: the host polls the completion word)
 }
 
 hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st) {
@@ -2151,26 +2209,7 @@ hipError_t launch_small_block_mask(const SplitParams& P, unsigned long long* don
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tile_index(const int64_t* __restrict__ row_off, int64_t n_str, int64_t n_tiles,
                                                    int64_t* __restrict__ tile_first) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t w0 = 0, w1 = -1;
-    if (s <= n_str) {
-        const int64_t p = row_off[s];
-        const int64_t prev = s > 0 ? row_off[s - 1] : -1;
-        w0 = prev < 0 ? 0 : prev / kTile + 1;
-        w1 = p / kTile;
-        if (w1 > n_tiles - 1) w1 = n_tiles - 1;
-    }
-    const bool wide = w1 - w0 >= 16;
-    if (!wide)
-        for (int64_t w = w0; w <= w1; ++w) tile_first[w] = s;
-    unsigned long long m = __ballot(wide);
-    while (m) {   // wave-uniform
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int64_t a = lane_read64(w0, src), b = lane_read64(w1, src), v = lane_read64(s, src);
-        for (int64_t w = a + lane; w <= b; w += 64) tile_first[w] = v;
-    }
+    tile_index_entry(row_off, n_str, n_tiles, tile_first, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, threadIdx.x & 63);
 }
 
 hipError_t launch_tile_index(const SplitParams& P, hipStream_t st) {
@@ -2217,6 +2256,14 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, block, 0, st, P);
     else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_one_segment(const SplitParams& P, int mode, hipStream_t st) {
+    if (P.n_segs != 1 || P.seg_tiles < P.n_tiles || P.n_tiles > kOneSegTiles || (mode != kModeBits && mode != kModeRules))
+        return hipErrorInvalidValue;
+    if (mode == kModeBits) hipLaunchKernelGGL((k_one_segment<kModeBits>), dim3(1), dim3(kWPB * 64), 0, st, P);
+    else hipLaunchKernelGGL((k_one_segment<kModeRules>), dim3(1), dim3(kWPB * 64), 0, st, P);
     return hipGetLastError();
 }
 

@@ -171,3 +171,58 @@ def test_three_native_functions_on_one_string(gpu, oracle):
         for x1, x2 in ((a1, a2), (a1, np.zeros(n, np.int8)), (np.zeros(n, np.int8), a2), (np.ones(n, np.int8), a2)):
             assert np.array_equal(lt._gen_block_mask(x1, x2), oracle.gen_block_mask(x1, x2)), n
         assert np.array_equal(dt.gen_split_mask(m), oracle.gen_split_mask(want)), n
+
+
+def _multi_tile_batches():
+    """host batches of 2 ... 26 tiles (k_one_segment takes up to 24): blocks that start in one tile and close tiles later, so
+    that the resolve stage inside the single launch has to patch and to recompute tiles"""
+    rng = random.Random(2424)
+    for n_tiles in (2, 3, 5, 12, 23, 24, 25, 26):
+        total = n_tiles * 4096 - rng.randint(0, 4095)
+        for alpha in ("rare_space_at", "nospace_at", "mixed", "words"):
+            texts, left = [], total
+            while left > 0:
+                n = min(left, rng.choice([1, 7, 100, 3000, 9000, 20000]))
+                texts.append("".join(rng.choice(ALPHABETS[alpha]) for _ in range(n))[:n])
+                left -= len(texts[-1])
+            yield texts
+
+
+def test_one_launch_pipeline_of_small_multi_tile_batches(gpu, oracle):
+    from latok_amd import batch
+    for i, texts in enumerate(_multi_tile_batches()):
+        cps, row = pack(texts)
+        vals, bits = oracle.split_batch(cps, row)
+        assert np.array_equal(batch.split_mask_batch(cps, row), bits), i
+        want = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(texts))]
+        dtype = np.int32 if i & 1 else np.int64
+        counts, offs = batch.split_offsets_csr(cps, row, dtype=dtype)
+        assert counts.tolist() == [len(w) for w in want] and np.array_equal(offs, np.concatenate(want)), i
+        if i % 4 == 0:
+            toks = [_want(oracle, t) for t in texts]
+            tcounts, spans = batch.token_spans_csr(cps, row, dtype=dtype)
+            assert spans.reshape(-1, 2).tolist() == [[w[3], w[4]] for ws in toks for w in ws], i
+            _, spans4, feats = batch.token_features_csr(cps, row, dtype=dtype)
+            assert spans4.reshape(-1, 4).tolist() == [[w[1], w[2], w[3], w[4]] for ws in toks for w in ws], i
+            assert np.array_equal(feats, np.stack([w[5] for ws in toks for w in ws])), i
+
+
+def test_one_launch_pipeline_equals_the_three_launch_form(gpu):
+    """LATOK_ONE_SEGMENT=0 / LATOK_SMALL_POLL=0: the same offsets from the three-launch pipeline and from the stream wait"""
+    code = ("import random, hashlib, numpy as np\n"
+            "from latok_amd import batch\n"
+            "rng = random.Random(7)\n"
+            "h = hashlib.sha256()\n"
+            "for n in (5000, 20000, 60000, 98000, 99000, 200000):\n"
+            "    texts = [''.join(rng.choice('abcdefgh@ /:.#') for _ in range(rng.choice([3, 50, 4000]))) for _ in range(n // 700 + 1)]\n"
+            "    cps, row = batch.pack(texts)\n"
+            "    for a in batch.split_offsets_csr(cps, row) + batch.token_spans_csr(cps, row, dtype=np.int32) + (batch.split_mask_batch(cps, row),):\n"
+            "        h.update(np.ascontiguousarray(a).tobytes())\n"
+            "print(h.hexdigest())\n")
+    outs = []
+    for env_add in ({}, {"LATOK_ONE_SEGMENT": "0"}, {"LATOK_SMALL_POLL": "0"}):
+        env = dict(os.environ, PYTHONPATH=ROOT, **env_add)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip())
+    assert len(outs[0]) == 64 and outs[0] == outs[1] == outs[2]

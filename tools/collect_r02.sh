@@ -11,7 +11,8 @@ cp $F/paths_kernel_stats.txt $P/r02_paths_kernel_stats.txt
 cp $F/paths_c2.out $P/r02_paths_c2.jsonl
 cp $F/paths_c3.out $P/r02_paths_c3.jsonl
 cp $F/host_path.out $P/r02_host_path_rate.jsonl
-cp $F/latency.out $P/r02_latency.txt
+cp $F/latency.out $P/r02_latency_final.txt      # (r02_latency.txt keeps the before / after history of the round)
+[ -f $F/sweep.out ] && cp $F/sweep.out $P/r02_batch_size_sweep_final.txt
 for l in c2 c3 paths; do for c in FETCH_SIZE WRITE_SIZE; do cp $F/pmc_${l}_$c.csv $P/r02_pmc_${l}_$c.csv; done; done
 python3 $R/tools/pmc_traffic_summary.py $P/r02_pmc_summary.json \
   "bench:C2:128005325:1000000:$F/pmc_c2_FETCH_SIZE.csv:$F/pmc_c2_WRITE_SIZE.csv:rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0" \

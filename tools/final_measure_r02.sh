@@ -26,6 +26,7 @@ step paths_c2 300 python tools/path_bench.py --workload C2 --iters 20 --cpu 1000
 step paths_c3 300 python tools/path_bench.py --workload C3 --iters 10
 step host_path 300 python tools/host_path_rate.py
 step latency 120 python tools/latency_bench.py
+step sweep 200 python tools/batch_size_sweep.py
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b /tmp/prof_p
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_c2_under_rocprof.json 2>/dev/null

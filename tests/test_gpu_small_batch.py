@@ -226,3 +226,20 @@ def test_one_launch_pipeline_equals_the_three_launch_form(gpu):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip())
     assert len(outs[0]) == 64 and outs[0] == outs[1] == outs[2]
+
+
+def test_c_example_one_string_per_call(gpu, oracle, tmp_path):
+    """examples/tokenize_one.c: a plain C caller tokenizes one string per call (UTF-32 in, int32 stripped spans out) and
+    prints the reference's tokens; the timing it reports goes to stderr."""
+    exe = str(tmp_path / "tokenize_one")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "tokenize_one.c"),
+                           "-L" + os.path.join(ROOT, "latok_amd"), "-llatok_hip", "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"),
+                           "-o", exe])
+    texts = ["This is a #test! Testing, Testing, 1 2 3", "see http://a.b/c or mail me@x.org", "camelCase 日本語 🤓 é", "x" * 5000 + " tail"]
+    r = subprocess.run([exe, "50"] + texts, capture_output=True, timeout=120, check=True)
+    out = r.stdout.decode("utf-8").splitlines()
+    assert out == [f"{i}:" + "".join(f" [{t}]" for t in oracle.tokenize(s)) for i, s in enumerate(texts)]
+    assert r.stderr.decode().count("us per call") == len(texts)
+    # no arguments: the built-in sentence
+    out = subprocess.run([exe, "3"], capture_output=True, timeout=120, check=True).stdout.decode("utf-8")
+    assert out.startswith("0: [This] [is] [a] [#test] [!]")

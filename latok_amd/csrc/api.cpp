@@ -987,7 +987,22 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
                                           utf8 != nullptr, row_off, n_str, total, counts_out, items_out, items_cap, n_items_out,
                                           features_out, st);
     }
-    if (utf8 && byte_space) {
+    // Small host batches of narrow units (the C-extension caller of INTEGRATION.md section C hands over ONE str per call in
+    // its PEP 393 kind) are widened to UTF-32 by the host straight into the pinned area and take the small-batch path below:
+    // positions are chars either way, so the results are the same, and the call costs one launch instead of staged copies
+    // (kind 1, one 105-char string: 110 -> 17 us).  UTF-8 in byte space qualifies when the batch is pure ASCII (byte = char).
+    bool widen = false;
+    if (!dev && utf8 && byte_space && n_str > 0 && total > 0 && total <= kSmallChars && n_str <= kSmallStrings) {
+        widen = unit_kind == 1 || unit_kind == 2;
+        if (unit_kind == 0) {
+            uint8_t any = 0;
+            for (int64_t i = 0; i < total; ++i) any |= utf8[i];
+            widen = any < 0x80;
+        }
+    }
+    if (widen) {
+        d_cps = nullptr;   // (set below, with the pinned area)
+    } else if (utf8 && byte_space) {
         // UTF-8 in byte space, or (unit_kind 1 / 2) PEP 393 code units: `total` positions of unit_bytes each
         if (dev) {
             if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
@@ -1026,7 +1041,7 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     }
     // small host batch: inputs and every output live in pinned mapped memory; nothing is copied by the runtime and the
     // call synchronises once (a string of ~100 chars: ~110 us of blocking copies otherwise)
-    const bool small = !dev && !utf8 && total <= kSmallChars && n_str <= kSmallStrings;
+    const bool small = !dev && (!utf8 || widen) && total <= kSmallChars && n_str <= kSmallStrings;
     size_t po_row = 0, po_counts = 0, po_items = 0, po_feat = 0;
     if (small) {
         po_row = ((size_t)total * 4 + 15) & ~(size_t)15;
@@ -1034,7 +1049,15 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         po_items = po_counts + (((size_t)n_str * elt + 15) & ~(size_t)15);
         po_feat = po_items + (size_t)total * item_bytes;      // at most one item per char
         if ((rc = g.pin.ensure(po_feat + (feats ? (size_t)total * LATOK_FEATURE_COUNT : 0) + 64))) return rc;
-        memcpy(g.pin.h, cps, (size_t)total * 4);
+        if (!widen) {
+            memcpy(g.pin.h, cps, (size_t)total * 4);
+        } else if (unit_kind == 2) {
+            uint32_t* w = (uint32_t*)g.pin.h;
+            for (int64_t i = 0; i < total; ++i) { uint16_t u; memcpy(&u, utf8 + 2 * i, 2); w[i] = u; }
+        } else {
+            uint32_t* w = (uint32_t*)g.pin.h;
+            for (int64_t i = 0; i < total; ++i) w[i] = utf8[i];
+        }
         memcpy((char*)g.pin.h + po_row, row_off, (size_t)(n_str + 1) * 8);
         d_cps = (const uint32_t*)g.pin.d;
         d_row = (const int64_t*)((char*)g.pin.d + po_row);

@@ -243,3 +243,31 @@ def test_c_example_one_string_per_call(gpu, oracle, tmp_path):
     # no arguments: the built-in sentence
     out = subprocess.run([exe, "3"], capture_output=True, timeout=120, check=True).stdout.decode("utf-8")
     assert out.startswith("0: [This] [is] [a] [#test] [!]")
+
+
+def test_small_narrow_unit_batches_take_the_same_path(gpu, oracle):
+    """PEP 393 kind 1 / 2 code units and pure-ASCII UTF-8 in byte space, small host batches (one str per call is what a C
+    extension hands over): widened on the host into the pinned small-batch path; the results
+    are those of the UTF-32 entry points and of the oracle.  Non-ASCII UTF-8 keeps the byte-space kernel."""
+    from latok_amd import batch
+    rng = random.Random(393)
+    cases = [["This is a #test! see http://a.b/c or mail me@x.org, camelCase 1 2 3"], ["a"], ["", "x y", ""],
+             random_strings(rng, 30, 0, 100, ALPHABETS["latin1"]), random_strings(rng, 30, 0, 100, ALPHABETS["bmp"]),
+             random_strings(rng, 200, 0, 60, ALPHABETS["latin1"]), random_strings(rng, 3, 1500, 4000, ALPHABETS["bmp"]),
+             ["".join(rng.choice("abc XYZ.,:/@#1") for _ in range(n)) for n in (4095, 4096, 4097, 20000)]]
+    for i, texts in enumerate(cases):
+        cps, row = pack(texts)
+        units, krow = batch.pack_kind(texts)
+        dtype = np.int32 if i & 1 else np.int64
+        want_o = batch.split_offsets_csr(cps, row, dtype=dtype)
+        w_off = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
+        assert want_o[1].tolist() == [int(v) for x in w_off for v in x]
+        for got, want in ((batch.split_offsets_kind_csr(units, krow, dtype=dtype), want_o),
+                          (batch.token_spans_kind_csr(units, krow, dtype=dtype), batch.token_spans_csr(cps, row, dtype=dtype)),
+                          (batch.token_features_kind_csr(units, krow, dtype=dtype), batch.token_features_csr(cps, row, dtype=dtype))):
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), (i, units.dtype)
+        if all(ord(c) < 128 for t in texts for c in t):
+            utf8, boff = batch.pack_utf8([t.encode() for t in texts])
+            assert all(np.array_equal(a, b) for a, b in zip(batch.split_offsets_utf8_bytes_csr(utf8, boff, dtype=dtype), want_o))
+            assert all(np.array_equal(a, b) for a, b in zip(batch.token_spans_utf8_bytes_csr(utf8, boff, dtype=dtype),
+                                                            batch.token_spans_csr(cps, row, dtype=dtype)))

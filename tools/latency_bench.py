@@ -37,3 +37,8 @@ timeit("dt._sync_rules()", lambda: dt._sync_rules(), 2000)
 f32 = np.empty((len(text), 25), np.int8); s32 = np.empty(4 * len(text), np.int32)
 af = (cps.ctypes.data, row.ctypes.data, 1, len(text), c32.ctypes.data, s32.ctypes.data, f32.ctypes.data, len(text), C.byref(n_out), _lib.OUT_INT32, None)
 timeit("latok_token_features_batch, int32 (C ABI)", lambda: lib.latok_token_features_batch(*af), 2000)
+u8 = np.frombuffer(text.encode("latin-1"), np.uint8)
+ak = (u8.ctypes.data, 1, row.ctypes.data, 1, len(text), c32.ctypes.data, o32.ctypes.data, len(text), C.byref(n_out), _lib.OUT_INT32, None)
+timeit("latok_split_offsets_kind_batch, kind 1 (C ABI)", lambda: lib.latok_split_offsets_kind_batch(*ak), 2000)
+ab = (u8.ctypes.data, row.ctypes.data, 1, len(text), c32.ctypes.data, o32.ctypes.data, len(text), C.byref(n_out), _lib.OUT_INT32, None)
+timeit("latok_split_offsets_utf8_bytes_batch, ASCII (C ABI)", lambda: lib.latok_split_offsets_utf8_bytes_batch(*ab), 2000)

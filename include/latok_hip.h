@@ -33,6 +33,9 @@
  *     call returns when it has seen the completion word the kernel stores after its last output (LATOK_SMALL_POLL=0 in
  *     the environment: wait for the stream instead).  Host batches up to 256 K chars / 16 K strings take the same pinned
  *     route with a handful of launches (up to 24 tiles: one launch for the whole mask pipeline; LATOK_ONE_SEGMENT=0: three).
+ *     Small host batches of PEP 393 kind 1 / 2 units are widened, and small well-formed UTF-8 batches decoded, by the host
+ *     on their way into that pinned area (byte-space results are mapped back to byte positions), so one string per call
+ *     costs the same whatever form it arrives in; malformed UTF-8 and larger batches are read by the device as they are.
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with LATOK_ERR_HIP.
  */
 #ifndef LATOK_HIP_H

@@ -149,6 +149,8 @@ struct Ctx {
     PinBuf pin, pin_tot;   // pin_tot: 64 bytes the scans drop their grand totals into (read after a stream sync, no copy)
     unsigned long long small_seq = 0;   // completion word of the single-launch small-batch path (pin_tot word 2)
     DevBuf done_ctr;                    // workgroup counter of latok::DoneSignal (0 between launches)
+    std::vector<uint32_t> hd_cps;       // host decode of small UTF-8 batches (host_decode_small)
+    std::vector<int64_t> hd_row, hd_pos;
     unsigned done_ctr_seen = 0;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
     DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
@@ -952,6 +954,47 @@ static int compact_host_pipelined_body(Ctx& g, bool spans, bool feats, bool o32,
 }
 
 // Shared body of the compaction entry points: argument checks, staging of host-pointer batches, one synchronisation.
+// Small UTF-8 host batches (one string per call is the usual C caller): decoded by the host with the device decoder's rule
+// -- one code point per lead byte, as many continuation bytes as the lead announces (utf8_decode.h) -- into UTF-32, so
+// that the call takes the pinned small-batch path of the code-point form; byte-space results are mapped back through the
+// byte position of every char.  Only when every string is structurally well-formed (each lead followed by exactly its
+// continuation bytes inside the string, no stray continuation byte): the two device paths define what malformed input
+// means, and they keep doing so.  cps / cp_row / bytepos: code points, code-point row offsets, byte position of every
+// char (+ one entry for the end).
+static bool host_decode_small(const uint8_t* u8, const int64_t* boff, int64_t n_str, std::vector<uint32_t>& cps,
+                              std::vector<int64_t>& cp_row, std::vector<int64_t>& bytepos) {
+    const int64_t total = boff[n_str];
+    cps.clear(); bytepos.clear();
+    cps.reserve((size_t)total); bytepos.reserve((size_t)total + 1);
+    cp_row.assign((size_t)n_str + 1, 0);
+    for (int64_t s = 0; s < n_str; ++s) {
+        const int64_t end = boff[s + 1];
+        for (int64_t i = boff[s]; i < end;) {
+            const uint32_t b0 = u8[i];
+            int extra = 0;
+            uint32_t cp = b0;
+            if (b0 >= 0x80u) {
+                if (b0 < 0xC0u) return false;                       // stray continuation byte
+                if (b0 >= 0xF0u) { cp = b0 & 0x07u; extra = 3; }
+                else if (b0 >= 0xE0u) { cp = b0 & 0x0Fu; extra = 2; }
+                else { cp = b0 & 0x1Fu; extra = 1; }
+                if (i + extra >= end) return false;                 // truncated at the string's end
+                for (int j = 1; j <= extra; ++j) {
+                    const uint32_t b = u8[i + j];
+                    if ((b & 0xC0u) != 0x80u) return false;         // truncated sequence
+                    cp = (cp << 6) | (b & 0x3Fu);
+                }
+            }
+            cps.push_back(cp);
+            bytepos.push_back(i);
+            i += 1 + extra;
+        }
+        cp_row[(size_t)s + 1] = (int64_t)cps.size();
+    }
+    bytepos.push_back(total);
+    return true;
+}
+
 static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           void* counts_out, void* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
@@ -968,6 +1011,27 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
         for (int64_t s = 0; s < n_str; ++s)
             if (row_off[s + 1] - row_off[s] > 0x7FFFFFFFll)
                 return fail(LATOK_ERR_INVALID, "string %lld is too long for LATOK_OUT_INT32; use the 64-bit form", (long long)s);
+    }
+    if (!dev && utf8 && unit_kind == 0 && row_off && n_str > 0 && n_str <= kSmallStrings && counts_out) {
+        int64_t tb = total;
+        if (check_csr_host(row_off, n_str, &tb) == LATOK_OK && tb > 0 && tb <= kSmallChars &&
+            host_decode_small(utf8, row_off, n_str, g.hd_cps, g.hd_row, g.hd_pos)) {
+            rc = compact_common(g, spans, g.hd_cps.data(), g.hd_row.data(), n_str, (int64_t)g.hd_cps.size(), counts_out, items_out,
+                                items_cap, n_items_out, flags, stream, features_out);
+            if (rc != LATOK_OK || !byte_space || !items_out) return rc;
+            // byte space: a char position becomes the byte position of that char, relative to its string
+            const int64_t per = spans ? 2 : 1;
+            int64_t k = 0;
+            for (int64_t s = 0; s < n_str; ++s) {
+                const int64_t n = o32 ? (int64_t)((const int32_t*)counts_out)[s] : ((const int64_t*)counts_out)[s];
+                const int64_t c0 = g.hd_row[(size_t)s], b0 = row_off[s];
+                for (int64_t j = 0; j < n * per; ++j, ++k) {
+                    if (o32) { int32_t* v = (int32_t*)items_out + k; *v = (int32_t)(g.hd_pos[(size_t)(c0 + *v)] - b0); }
+                    else { int64_t* v = (int64_t*)items_out + k; *v = g.hd_pos[(size_t)(c0 + *v)] - b0; }
+                }
+            }
+            return LATOK_OK;
+        }
     }
     StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
@@ -990,15 +1054,10 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     // Small host batches of narrow units (the C-extension caller of INTEGRATION.md section C hands over ONE str per call in
     // its PEP 393 kind) are widened to UTF-32 by the host straight into the pinned area and take the small-batch path below:
     // positions are chars either way, so the results are the same, and the call costs one launch instead of staged copies
-    // (kind 1, one 105-char string: 110 -> 17 us).  UTF-8 in byte space qualifies when the batch is pure ASCII (byte = char).
+    // (kind 1, one 105-char string: 110 -> 17 us).
     bool widen = false;
     if (!dev && utf8 && byte_space && n_str > 0 && total > 0 && total <= kSmallChars && n_str <= kSmallStrings) {
-        widen = unit_kind == 1 || unit_kind == 2;
-        if (unit_kind == 0) {
-            uint8_t any = 0;
-            for (int64_t i = 0; i < total; ++i) any |= utf8[i];
-            widen = any < 0x80;
-        }
+        widen = unit_kind == 1 || unit_kind == 2;   // (small UTF-8 batches were decoded by the host above)
     }
     if (widen) {
         d_cps = nullptr;   // (set below, with the pinned area)

@@ -271,3 +271,41 @@ def test_small_narrow_unit_batches_take_the_same_path(gpu, oracle):
             assert all(np.array_equal(a, b) for a, b in zip(batch.split_offsets_utf8_bytes_csr(utf8, boff, dtype=dtype), want_o))
             assert all(np.array_equal(a, b) for a, b in zip(batch.token_spans_utf8_bytes_csr(utf8, boff, dtype=dtype),
                                                             batch.token_spans_csr(cps, row, dtype=dtype)))
+
+
+def test_small_utf8_batches_are_decoded_by_the_host(gpu, oracle):
+    """UTF-8 host batches up to the pinned path's size: the host decodes (the device decoder's rule) and the call takes the
+    UTF-32 small-batch path; byte-space results are mapped back through the byte position of every char.  Against the
+    oracle, for both forms; malformed strings are left to the device paths and give what they give inside a large batch."""
+    from latok_amd import batch
+    rng = random.Random(8)
+    cases = [["This is a #test! é日🤓 see http://a.b/c or mail me@x.org"], ["é"], ["", "日本語 x", ""], ["a" * 4096], ["é" * 3000],
+             random_strings(rng, 40, 0, 90, ALPHABETS["mixed"]), random_strings(rng, 300, 0, 20, ALPHABETS["bmp"][:18] + ["é", "日"]),
+             random_strings(rng, 4, 3000, 9000, ALPHABETS["mixed"])]
+    for i, texts in enumerate(cases):
+        texts = [t.encode("utf-8", "surrogatepass").decode("utf-8", "surrogatepass") for t in texts]
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        utf8, boff = batch.pack_utf8(blobs)
+        dtype = np.int32 if i & 1 else np.int64
+        w_off = [oracle.split_offsets(t) if t else np.zeros(0, np.int64) for t in texts]
+        toks = [_want(oracle, t) for t in texts]
+        bpos = [np.cumsum([0] + [len(c.encode("utf-8", "surrogatepass")) for c in t]) for t in texts]   # byte position of every char
+        counts, offs = batch.split_offsets_utf8_csr(utf8, boff, dtype=dtype)
+        assert counts.tolist() == [len(x) for x in w_off] and offs.tolist() == [int(v) for x in w_off for v in x], i
+        counts, offs = batch.split_offsets_utf8_bytes_csr(utf8, boff, dtype=dtype)
+        assert offs.dtype == dtype and offs.tolist() == [int(bp[v]) for x, bp in zip(w_off, bpos) for v in x], i
+        _, spans = batch.token_spans_utf8_csr(utf8, boff, dtype=dtype)
+        assert spans.reshape(-1, 2).tolist() == [[w[3], w[4]] for ws in toks for w in ws], i
+        _, spans = batch.token_spans_utf8_bytes_csr(utf8, boff, dtype=dtype)
+        assert spans.reshape(-1, 2).tolist() == [[int(bp[w[3]]), int(bp[w[4]])] for ws, bp in zip(toks, bpos) for w in ws], i
+        assert batch.tokenize_utf8_batch(blobs) == [[w[0].encode("utf-8", "surrogatepass") for w in ws] for ws in toks], i
+    # malformed: stray continuation bytes, a truncated sequence inside and at the end of a string
+    bad = [b"ab \x80\x80 cd", b"x \xe6\x97 y", b"tail \xf0\x9f", b"\xbfstart", b"ok #tag"]
+    filler = [b"filler words and a #tag http://x.y/z " * 40] * 300          # > 256 K bytes: the device paths
+    for fn, width in ((batch.split_offsets_utf8_bytes_csr, 1), (batch.token_spans_utf8_bytes_csr, 2),
+                      (batch.split_offsets_utf8_csr, 1), (batch.token_spans_utf8_csr, 2)):
+        small = fn(*batch.pack_utf8(bad))
+        big = fn(*batch.pack_utf8(bad + filler))
+        n = int(small[0].sum())
+        assert n > 0 and np.array_equal(small[0], big[0][:len(bad)]), fn.__name__
+        assert np.array_equal(np.ravel(small[1]), np.ravel(big[1])[:n * width]), fn.__name__

@@ -237,7 +237,8 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
                  hipEvent_t tiles_end = nullptr, const int8_t* bm_a1 = nullptr, const int8_t* bm_a2 = nullptr,
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
                  const uint8_t* d_u8 = nullptr, int unit_kind = 0, int stages = 7,   // stages: 1 = tile index, 2 = tiles, 4 = resolve
-                 uint8_t* d_codes = nullptr) {   // d_codes: also leave the rule code of every char (featurize)
+                 uint8_t* d_codes = nullptr,     // d_codes: also leave the rule code of every char (featurize)
+                 latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr}) {   // completion word stored by the last launch
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
@@ -292,6 +293,7 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.bm_a1 = bm_a1;
     P.bm_a2 = bm_a2;
     P.bm_flags = bm_flags;
+    P.done = (stages & 4) ? done : latok::DoneSignal{nullptr, 0, nullptr};
     if (one_launch) {
         HIP_TRY(latok::launch_one_segment(P, mode, st));
         return LATOK_OK;
@@ -352,11 +354,23 @@ int split_common(Ctx& g, const uint32_t* cps, const int64_t* row_off, int64_t n_
         memcpy(g.pin.h, cps, (size_t)total * 4);
         memcpy((char*)g.pin.h + o_row, row_off, (size_t)(n_str + 1) * 8);
         char* d = (char*)g.pin.d;
+        latok::DoneSignal done{nullptr, 0, nullptr};
+        unsigned long long seq = 0;
+        if (poll_completion()) {   // the last launch stores a completion word (see compact_common)
+            if ((rc = g.pin_tot.ensure(64)) || (rc = g.done_ctr.ensure(64))) return rc;
+            if (g.done_ctr.gen != g.done_ctr_seen) {
+                g.done_ctr_seen = g.done_ctr.gen;
+                HIP_TRY(hipMemsetAsync(g.done_ctr.p, 0, 64, st));
+            }
+            seq = ++g.small_seq;
+            done = latok::DoneSignal{(unsigned long long*)g.pin_tot.d + 2, seq, (unsigned*)g.done_ctr.p};
+        }
         rc = run_pipeline(g, (const uint32_t*)d, (const int64_t*)(d + o_row), n_str, total,
                           mode == latok::kModeBits ? (uint64_t*)(d + o_out) : nullptr,
-                          mode == latok::kModeValues ? (uint8_t*)(d + o_out) : nullptr, mode, st);
+                          mode == latok::kModeValues ? (uint8_t*)(d + o_out) : nullptr, mode, st, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, 0, 7, nullptr, done);
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(st));
+        if (!(done.word && wait_completion_word((const unsigned long long*)g.pin_tot.h + 2, seq))) HIP_TRY(hipStreamSynchronize(st));
         memcpy(out, (char*)g.pin.h + o_out, out_bytes);
         return LATOK_OK;
     }

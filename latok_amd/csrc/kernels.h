@@ -43,35 +43,6 @@ struct Hd64 {        // head descriptor of a run of tiles: starts before its fir
     int c;
 };
 
-struct SplitParams {
-    const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
-    const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); kModeLatin1 / kModeUcs2: the code units; cps is unused
-    const int64_t* row_off;     // [n_str + 1]
-    int64_t n_str, total, n_tiles;
-    int seg_tiles;              // tiles per segment (kWPB..kSegMax, see plan_segments)
-    int64_t n_segs;             // ceil(n_tiles / seg_tiles)
-    const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
-    const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
-    uint64_t* bits_out;         // kModeBits
-    uint8_t* values_out;        // kModeValues / kModeBlockMask
-    uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
-    uint8_t* codes_out;         // optional (kModeBits / kModeRules on UTF-32 input, t2 = rule codes): the code byte of every char
-                                // (featurize: k_features_tiles reads 1 B/char instead of classifying 4 B/char again)
-    int64_t* tile_first;        // [n_tiles]: first string that starts at or after each tile's first char (k_tile_index; also read by the compaction passes)
-    int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
-    Fn64* seg_fn;               // [n_segs] segment aggregates
-    Hd64* seg_hd;               // [n_segs]
-    int64_t* fix_count;         // [1] statistics: tiles recomputed by the resolve stage
-    // kModeBlockMask only
-    const int8_t* bm_a1;        // "starts" bytes [total]
-    const int8_t* bm_a2;        // "spaces" bytes [total]
-    const int* bm_flags;        // {any(a1), any(a2)}
-    // kModeRules only (t2 then points at the rule-code table)
-    lk_rule_tables rules;
-};
-
-
-// featurize on the tile grid (split_kernels.hip: k_features_tiles)
 // Completion word of a multi-workgroup launch whose outputs land in pinned host memory (small / mid-size host batches): every
 // workgroup drains its stores to system scope and counts itself in; the last one stores `seq` into `word` (which the host
 // polls instead of waiting for the stream) and resets the counter.  word == NULL: off.
@@ -95,6 +66,36 @@ __device__ __forceinline__ void signal_block_done(const DoneSignal& d) {
 }
 #endif
 
+struct SplitParams {
+    const uint32_t* cps;        // packed UTF-32 code points (16-byte aligned)
+    const uint8_t* u8;          // kModeBytes: packed UTF-8 bytes instead (16-byte aligned); kModeLatin1 / kModeUcs2: the code units; cps is unused
+    const int64_t* row_off;     // [n_str + 1]
+    int64_t n_str, total, n_tiles;
+    int seg_tiles;              // tiles per segment (kWPB..kSegMax, see plan_segments)
+    int64_t n_segs;             // ceil(n_tiles / seg_tiles)
+    const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
+    const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
+    uint64_t* bits_out;         // kModeBits
+    uint8_t* values_out;        // kModeValues / kModeBlockMask
+    uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
+    uint8_t* codes_out;         // optional (kModeBits / kModeRules on UTF-32 input, t2 = rule codes): the code byte of every char
+                                // (featurize: k_features_tiles reads 1 B/char instead of classifying 4 B/char again)
+    int64_t* tile_first;        // [n_tiles]: first string that starts at or after each tile's first char (k_tile_index; also read by the compaction passes)
+    int4* summ;                 // [n_tiles] {a, b, head_starts, has_closing | edge-block geometry}
+    Fn64* seg_fn;               // [n_segs] segment aggregates
+    Hd64* seg_hd;               // [n_segs]
+    int64_t* fix_count;         // [1] statistics: tiles recomputed by the resolve stage
+    // kModeBlockMask only
+    const int8_t* bm_a1;        // "starts" bytes [total]
+    const int8_t* bm_a2;        // "spaces" bytes [total]
+    const int* bm_flags;        // {any(a1), any(a2)}
+    DoneSignal done;            // last launch of a host-pointer call on pinned memory (k_one_segment / k_resolve_fix): completion word
+    // kModeRules only (t2 then points at the rule-code table)
+    lk_rule_tables rules;
+};
+
+
+// featurize on the tile grid (split_kernels.hip: k_features_tiles)
 struct FeatParams {
     const uint8_t* codes;         // rule code of every char (SplitParams::codes_out of the tile kernel), padded by one tile + 256 B
     const int64_t* row_off;

@@ -1303,6 +1303,7 @@ __global__ __launch_bounds__(NW * 64) void k_resolve_fix(SplitParams P) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     resolve_segments<MODE, NW, false>(P, lds, tid, lane, wave);
+    signal_block_done(P.done);
 }
 
 // stage 0 (k_tile_index below, k_one_segment): entry s of row_off (s > n_str: nothing); must be called by whole waves (the wide form below uses wave operations)
@@ -1349,6 +1350,7 @@ __global__ __launch_bounds__(kWPB * 64) void k_one_segment(SplitParams P) {
     __threadfence_block();
     __syncthreads();
     resolve_segments<MODE, kWPB, true>(P, lds, tid, lane, wave);                  // stage 2
+    signal_block_done(P.done);
 }
 
 // flags[0] = any(a1 != 0), flags[1] = any(a2 != 0) (flags zeroed by the caller)

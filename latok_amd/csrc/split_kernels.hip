@@ -1428,10 +1428,21 @@ __device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint3
 // to global memory costs +0.4 ms in scattered stores.  So this kernel trades waves for LDS: kFeatWaves waves per CU,
 // each with a window for kFeatRound tokens (a 4096-char tile of word-soup text has ~830), which doubles as the
 // code-byte staging buffer before the planes are built.
+#ifdef LATOK_AB_FEAT7
+constexpr int kFeatWaves = 7;
+#else
 constexpr int kFeatWaves = 6;
-constexpr int kFeatRound = 896;                                       // tokens per round
+#endif
+constexpr int kFeatRound = 896;                                       // tokens per round (word-major form)
 constexpr int kFeatRec = 25;                                          // packed records in the window, as in the output
+#ifdef LATOK_AB_FEAT7
+constexpr int kFeatRoundTm = 768;                                     // token-major form: records + 2-byte (lane, bit) codes share the window
+constexpr int kFeatWinBytes = kFeatRound * kFeatRec;
+static_assert(kFeatRoundTm * (kFeatRec + 2) <= kFeatWinBytes, "token-major round fits the window");
+#else
+constexpr int kFeatRoundTm = kFeatRound;
 constexpr int kFeatWinBytes = kFeatRound * kFeatRec + kFeatRound * 2; // feature records + the (lane, bit) codes of the token-major form
+#endif
 constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | (unused) | string-start words
 constexpr int kFeatLdsTotal = kFeatWaves * kFeatWaveLds;
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
@@ -1683,18 +1694,18 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
     if (maxc * 2 > ((n_wave + 63) >> 6) * 3) {
         uint8_t* fwin = L.stage;
-        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRound * kFeatRec);   // behind the feature records
+        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRoundTm * kFeatRec);   // behind the feature records
         lk_u64 trest = x;
         int tk = off;
-        for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
-            while (trest && tk < win0 + kFeatRound) {
+        for (int win0 = 0; win0 < n_wave; win0 += kFeatRoundTm) {
+            while (trest && tk < win0 + kFeatRoundTm) {
                 const int b = lk_ctz(trest);
                 trest &= trest - 1;
                 codes[tk - win0] = (uint16_t)((lane << 6) | b);
                 ++tk;
             }
             wave_lds_sync();
-            const int n_here = min(kFeatRound, n_wave - win0);
+            const int n_here = min(kFeatRoundTm, n_wave - win0);
             for (int j0 = 0; j0 < n_here; j0 += 64) {
                 const int j = j0 + lane;
                 const bool active = j < n_here;

@@ -1428,21 +1428,12 @@ __device__ __forceinline__ uint32_t feat_row_bits1(uint32_t w, uint32_t p, uint3
 // to global memory costs +0.4 ms in scattered stores.  So this kernel trades waves for LDS: kFeatWaves waves per CU,
 // each with a window for kFeatRound tokens (a 4096-char tile of word-soup text has ~830), which doubles as the
 // code-byte staging buffer before the planes are built.
-#ifdef LATOK_AB_FEAT7
-constexpr int kFeatWaves = 7;
-#else
-constexpr int kFeatWaves = 6;
-#endif
+constexpr int kFeatWaves = 7;                                         // (6 -> 7: C2 -4.5 %, C3 -6 %; 8 would need rounds of < 800 tokens: two rounds per C2 tile)
 constexpr int kFeatRound = 896;                                       // tokens per round (word-major form)
 constexpr int kFeatRec = 25;                                          // packed records in the window, as in the output
-#ifdef LATOK_AB_FEAT7
 constexpr int kFeatRoundTm = 768;                                     // token-major form: records + 2-byte (lane, bit) codes share the window
-constexpr int kFeatWinBytes = kFeatRound * kFeatRec;
+constexpr int kFeatWinBytes = kFeatRound * kFeatRec;                  // (its rounds cost nothing extra: every lane has a token in every step)
 static_assert(kFeatRoundTm * (kFeatRec + 2) <= kFeatWinBytes, "token-major round fits the window");
-#else
-constexpr int kFeatRoundTm = kFeatRound;
-constexpr int kFeatWinBytes = kFeatRound * kFeatRec + kFeatRound * 2; // feature records + the (lane, bit) codes of the token-major form
-#endif
 constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | (unused) | string-start words
 constexpr int kFeatLdsTotal = kFeatWaves * kFeatWaveLds;
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");

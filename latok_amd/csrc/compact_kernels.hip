@@ -31,11 +31,9 @@ namespace latok {
 // One wave per 4096-char tile, lane = word: the tile's item count and every word's exclusive prefix inside its tile
 // (uint16); rank(word) = tile_rank[tile] + word_pref[word], tile_rank = exclusive scan of the tile counts (k_scan_chained).
 template <bool SPANS>
-__global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
-                                                     int64_t n_words, int64_t total, uint64_t* __restrict__ kept_out,
-                                                     int64_t* __restrict__ tile_cnt, uint16_t* __restrict__ word_pref) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__device__ __forceinline__ void word_counts_tile(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                                                 int64_t n_words, int64_t total, uint64_t* __restrict__ kept_out,
+                                                 int64_t* __restrict__ tile_cnt, uint16_t* __restrict__ word_pref, int64_t t, int lane) {
     const int64_t w = t * 64 + lane;
     if (t * 64 >= n_words) return;   // whole wave
     int cnt = 0;
@@ -74,6 +72,14 @@ __global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict_
     }
     if (w < n_words) word_pref[w] = (uint16_t)(inc - cnt);
     if (lane == 63) tile_cnt[t] = inc;
+}
+
+template <bool SPANS>
+__global__ __launch_bounds__(256) void k_word_counts(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ space,
+                                                     int64_t n_words, int64_t total, uint64_t* __restrict__ kept_out,
+                                                     int64_t* __restrict__ tile_cnt, uint16_t* __restrict__ word_pref) {
+    word_counts_tile<SPANS>(bits, space, n_words, total, kept_out, tile_cnt, word_pref,
+                            ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, threadIdx.x & 63);
 }
 
 // Exclusive scan of the tile counts over the whole batch in ONE launch (it used to be three: local scans, scan of the
@@ -243,11 +249,11 @@ __device__ __forceinline__ void counts_scatter_block(
     const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt, const uint16_t* __restrict__ word_pref,
     int64_t n_words, int64_t total, const int64_t* __restrict__ row_off, int64_t n_str,
     const int64_t* __restrict__ tile_first, OUT* __restrict__ out, const int64_t* __restrict__ n_items_dev, int64_t cap,
-    OUT* __restrict__ counts, unsigned n_scatter_blocks, int* __restrict__ err) {
+    OUT* __restrict__ counts, unsigned n_scatter_blocks, int* __restrict__ err, unsigned vb) {   // vb: (virtual) workgroup index
     static_assert(scatter_waves(KIND) * 64 == 256, "both roles use 256-thread workgroups");
-    if (blockIdx.x >= n_scatter_blocks) {   // role 2: one thread per string
+    if (vb >= n_scatter_blocks) {   // role 2: one thread per string
         if (counts)
-            string_counts_role<OUT>((int64_t)(blockIdx.x - n_scatter_blocks) * 256 + threadIdx.x, item_mask, tile_rank, word_pref,
+            string_counts_role<OUT>((int64_t)(vb - n_scatter_blocks) * 256 + threadIdx.x, item_mask, tile_rank, word_pref,
                                     row_off, n_str, total, *n_items_dev, counts, err);
         return;
     }
@@ -259,7 +265,7 @@ __device__ __forceinline__ void counts_scatter_block(
     __shared__ int64_t buf_s[kScatterWaves][kCodes];                // KIND 0: window of values (OUT); KIND 1: the item codes
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t w0 = ((int64_t)blockIdx.x * kScatterWaves + wave) * 64;
+    const int64_t w0 = ((int64_t)vb * kScatterWaves + wave) * 64;
     if (w0 >= n_words) return;                                      // whole wave (no block-wide barrier is used below)
     const int64_t w = w0 + lane;
     const int n_wave = (int)tile_cnt[w0 >> 6];
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
     const int64_t* __restrict__ tile_first, OUT* __restrict__ out, const int64_t* __restrict__ n_items_dev, int64_t cap,
     OUT* __restrict__ counts, unsigned n_scatter_blocks, int* __restrict__ err, DoneSignal done) {
     counts_scatter_block<KIND, OUT>(bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, n_str, tile_first,
-                                    out, n_items_dev, cap, counts, n_scatter_blocks, err);
+                                    out, n_items_dev, cap, counts, n_scatter_blocks, err, blockIdx.x);
     signal_block_done(done);   // (pinned outputs of a small host batch: the host polls the completion word)
 }
 

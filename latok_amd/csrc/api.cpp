@@ -1009,6 +1009,38 @@ static bool host_decode_small(const uint8_t* u8, const int64_t* boff, int64_t n_
     return true;
 }
 
+static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
+                          void* items_out, int64_t items_cap, int64_t* n_items_out, int flags, void* stream, int8_t* features_out,
+                          const uint8_t* utf8, bool byte_space, int unit_kind);
+
+// A small UTF-8 host batch through the UTF-32 small-batch path (host_decode_small); *taken = false: not this route (too
+// large, or malformed), nothing was done.  Byte space: a char position becomes the byte position of that char, relative
+// to its string.
+static int compact_small_utf8_host(Ctx& g, bool spans, const uint8_t* utf8, bool byte_space, const int64_t* byte_off, int64_t n_str,
+                                   int64_t total_bytes, void* counts_out, void* items_out, int64_t items_cap, int64_t* n_items_out,
+                                   int flags, void* stream, int8_t* features_out, bool* taken) {
+    *taken = false;
+    int64_t tb = total_bytes;
+    if (check_csr_host(byte_off, n_str, &tb) != LATOK_OK || tb <= 0 || tb > kSmallChars) return LATOK_OK;
+    if (!host_decode_small(utf8, byte_off, n_str, g.hd_cps, g.hd_row, g.hd_pos)) return LATOK_OK;
+    *taken = true;
+    const int rc = compact_common(g, spans, g.hd_cps.data(), g.hd_row.data(), n_str, (int64_t)g.hd_cps.size(), counts_out, items_out,
+                                  items_cap, n_items_out, flags, stream, features_out, nullptr, false, 0);
+    if (rc != LATOK_OK || !byte_space || !items_out) return rc;
+    const bool o32 = (flags & LATOK_OUT_INT32) != 0;
+    const int64_t per = spans ? 2 : 1;
+    int64_t k = 0;
+    for (int64_t s = 0; s < n_str; ++s) {
+        const int64_t n = o32 ? (int64_t)((const int32_t*)counts_out)[s] : ((const int64_t*)counts_out)[s];
+        const int64_t c0 = g.hd_row[(size_t)s], b0 = byte_off[s];
+        for (int64_t j = 0; j < n * per; ++j, ++k) {
+            if (o32) { int32_t* v = (int32_t*)items_out + k; *v = (int32_t)(g.hd_pos[(size_t)(c0 + *v)] - b0); }
+            else { int64_t* v = (int64_t*)items_out + k; *v = g.hd_pos[(size_t)(c0 + *v)] - b0; }
+        }
+    }
+    return LATOK_OK;
+}
+
 static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total,
                           void* counts_out, void* items_out, int64_t items_cap, int64_t* n_items_out, int flags,
                           void* stream, int8_t* features_out = nullptr, const uint8_t* utf8 = nullptr,
@@ -1027,25 +1059,10 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
                 return fail(LATOK_ERR_INVALID, "string %lld is too long for LATOK_OUT_INT32; use the 64-bit form", (long long)s);
     }
     if (!dev && utf8 && unit_kind == 0 && row_off && n_str > 0 && n_str <= kSmallStrings && counts_out) {
-        int64_t tb = total;
-        if (check_csr_host(row_off, n_str, &tb) == LATOK_OK && tb > 0 && tb <= kSmallChars &&
-            host_decode_small(utf8, row_off, n_str, g.hd_cps, g.hd_row, g.hd_pos)) {
-            rc = compact_common(g, spans, g.hd_cps.data(), g.hd_row.data(), n_str, (int64_t)g.hd_cps.size(), counts_out, items_out,
-                                items_cap, n_items_out, flags, stream, features_out);
-            if (rc != LATOK_OK || !byte_space || !items_out) return rc;
-            // byte space: a char position becomes the byte position of that char, relative to its string
-            const int64_t per = spans ? 2 : 1;
-            int64_t k = 0;
-            for (int64_t s = 0; s < n_str; ++s) {
-                const int64_t n = o32 ? (int64_t)((const int32_t*)counts_out)[s] : ((const int64_t*)counts_out)[s];
-                const int64_t c0 = g.hd_row[(size_t)s], b0 = row_off[s];
-                for (int64_t j = 0; j < n * per; ++j, ++k) {
-                    if (o32) { int32_t* v = (int32_t*)items_out + k; *v = (int32_t)(g.hd_pos[(size_t)(c0 + *v)] - b0); }
-                    else { int64_t* v = (int64_t*)items_out + k; *v = g.hd_pos[(size_t)(c0 + *v)] - b0; }
-                }
-            }
-            return LATOK_OK;
-        }
+        bool taken = false;
+        rc = compact_small_utf8_host(g, spans, utf8, byte_space, row_off, n_str, total, counts_out, items_out, items_cap, n_items_out,
+                                     flags, stream, features_out, &taken);
+        if (taken) return rc;
     }
     StreamTurn turn(g, stream);
     hipStream_t st = turn.st;

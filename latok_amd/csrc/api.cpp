@@ -1788,6 +1788,23 @@ int latok_debug_set_scan_epoch(unsigned epoch) {
     return LATOK_OK;
 }
 
+/* test hook (not part of the ABI; needs no device): the host decoder of small UTF-8 batches (host_decode_small).  Returns 1 and
+ * fills cps_out[<= total bytes], cp_row_out[n_str + 1], bytepos_out[<= total bytes + 1] when every string is well formed,
+ * 0 when the batch is left to the device paths, < 0 on a bad argument. */
+extern "C" int latok_debug_host_decode_utf8(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, uint32_t* cps_out,
+                                            int64_t* cp_row_out, int64_t* bytepos_out, int64_t* n_cps_out) {
+    int64_t total = -1;
+    if (!byte_off || n_str <= 0 || check_csr_host(byte_off, n_str, &total) != LATOK_OK) return LATOK_ERR_INVALID;
+    std::vector<uint32_t> cps;
+    std::vector<int64_t> row, pos;
+    if (!host_decode_small(utf8, byte_off, n_str, cps, row, pos)) return 0;
+    memcpy(cps_out, cps.data(), cps.size() * 4);
+    memcpy(cp_row_out, row.data(), row.size() * 8);
+    memcpy(bytepos_out, pos.data(), pos.size() * 8);
+    *n_cps_out = (int64_t)cps.size();
+    return 1;
+}
+
 int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out) {
     LATOK_ENTER();
     int rc = need_init(g);

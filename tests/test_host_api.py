@@ -190,3 +190,45 @@ def test_header_is_plain_c_and_example_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), src, "-L" + os.path.join(ROOT, "latok_amd"),
                            "-llatok_hip", "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"), "-o", exe])
     assert os.path.exists(exe)
+
+
+def test_host_decoder_of_small_utf8_batches():
+    """api.cpp: host_decode_small (small UTF-8 host batches are decoded by the host into the UTF-32 small-batch path): equal
+    to Python's decoder on well-formed strings, including surrogatepass forms and 4-byte chars; malformed batches are
+    refused (they stay with the device paths).  No device needed."""
+    import ctypes as C
+    import random
+    from latok_amd import _lib
+    lib = _lib.load()
+    fn = lib.latok_debug_host_decode_utf8
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+
+    def run(blobs):
+        buf = np.frombuffer(b"".join(blobs) + b"\0", np.uint8)
+        off = np.zeros(len(blobs) + 1, np.int64)
+        np.cumsum([len(b) for b in blobs], out=off[1:])
+        n = int(off[-1])
+        cps, row, pos, k = np.zeros(n + 1, np.uint32), np.zeros(len(blobs) + 1, np.int64), np.zeros(n + 2, np.int64), C.c_int64(0)
+        rc = fn(buf.ctypes.data, off.ctypes.data, len(blobs), cps.ctypes.data, row.ctypes.data, pos.ctypes.data, C.byref(k))
+        return rc, cps[:k.value], row, pos[:k.value + 1]
+
+    rng = random.Random(11)
+    alphabet = list("ab \t#@:/.é\xff日あ🤓\U0010ffff́𐏿\x00\x7f\x80߿ࠀ￿")
+    for _ in range(200):
+        texts = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 40))) for _ in range(rng.randint(1, 8))]
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        if sum(map(len, blobs)) == 0:
+            continue
+        rc, cps, row, pos = run(blobs)
+        assert rc == 1
+        assert cps.tolist() == [ord(c) for t in texts for c in t]
+        assert row.tolist() == np.cumsum([0] + [len(t) for t in texts]).tolist()
+        want_pos, b = [], 0
+        for t in texts:
+            for c in t:
+                want_pos.append(b)
+                b += len(c.encode("utf-8", "surrogatepass"))
+        assert pos.tolist() == want_pos + [b]
+    for bad in ([b"ab\x80"], [b"\xbf"], [b"x\xe6\x97", b"\xa5y"], [b"\xf0\x9f\xa4"], [b"\xc3"], [b"ok", b"\xe6\x97 z"], [b"\xc3\x28"]):
+        assert run(bad)[0] == 0, bad

@@ -227,3 +227,50 @@ def test_default_context_can_be_shut_down_and_come_back(gpu, oracle):
     assert np.array_equal(batch.split_mask_batch(cps, row), want)          # ensure_init brings it back
     c, o = batch.split_offsets_csr(cps, row, dtype=np.int32)
     assert int(c.sum()) == len(o) > 0
+
+
+def test_small_calls_from_three_threads_poll_their_own_completion_words(gpu, oracle):
+    """One string / a few tiles per call from three threads at once (two contexts of their own + the default one): every
+    call polls the completion word of ITS context while the kernels of the others run on the same GPU; tokenize(text),
+    featurize(text) and small batches of every path stay exact."""
+    from latok_amd import _lib, batch
+    from latok_amd.core import default_tokenizer as dt
+    rng = random.Random(31337)
+    texts = random_strings(rng, 150, 1, 300, ALPHABETS["mixed"]) + random_strings(rng, 6, 5000, 30000, ALPHABETS["words"])
+    want_tok = [oracle.tokenize(t) for t in texts]
+    want_off = [oracle.split_offsets(t) for t in texts]
+    small = [random_strings(rng, rng.randint(2, 60), 0, 400, ALPHABETS["mixed"]) for _ in range(12)]
+    small_want = []
+    for b in small:
+        cps, row = pack(b)
+        small_want.append(_oracle_offsets(oracle, cps, row))
+    errors = []
+
+    def run(own_context):
+        try:
+            ctx = _lib.Context(0) if own_context else None
+            if ctx:
+                ctx.make_current()
+            for rep in range(3):
+                for t, wt, wo in zip(texts, want_tok, want_off):
+                    assert list(dt.tokenize(t)) == wt
+                    assert np.array_equal(batch.split_offsets_one(t), wo)
+                    if len(t) <= 300 and rep == 0:
+                        assert [x.text for x in dt.featurize(t)] == wt
+                for b, (wc, wo, wb) in zip(small, small_want):
+                    cps, row = pack(b)
+                    c, o = batch.split_offsets_csr(cps, row, dtype=np.int32)
+                    assert np.array_equal(c, wc) and np.array_equal(o, wo)
+                    assert np.array_equal(batch.split_mask_batch(cps, row), wb)
+            if ctx:
+                _lib.load().latok_ctx_set_current(None)
+                ctx.destroy()
+        except BaseException as exc:   # noqa: BLE001 - reported to the main thread
+            errors.append(exc)
+
+    ths = [threading.Thread(target=run, args=(k < 2,)) for k in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(600)
+    assert not errors, errors[0]

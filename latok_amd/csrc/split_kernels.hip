@@ -1432,8 +1432,8 @@ constexpr int kFeatWaves = 7;                                         // (6 -> 7
 constexpr int kFeatRound = 896;                                       // tokens per round (word-major form)
 constexpr int kFeatRec = 25;                                          // packed records in the window, as in the output
 constexpr int kFeatRoundTm = 768;                                     // token-major form: records + 2-byte (lane, bit) codes share the window
-constexpr int kFeatWinBytes = kFeatRound * kFeatRec;                  // (its rounds cost nothing extra: every lane has a token in every step)
-static_assert(kFeatRoundTm * (kFeatRec + 2) <= kFeatWinBytes, "token-major round fits the window");
+constexpr int kFeatWinBytes = kFeatRound * kFeatRec + 16;             // (+ 16: the records start at record_shift(dst); token-major rounds cost nothing extra)
+static_assert(kFeatRoundTm * (kFeatRec + 2) + 16 <= kFeatWinBytes, "token-major round fits the window");
 constexpr int kFeatWaveLds = kFeatWinBytes + 16 + 66 * 8;             // window | (unused) | string-start words
 constexpr int kFeatLdsTotal = kFeatWaves * kFeatWaveLds;
 static_assert(kFeatLdsTotal <= 160 * 1024, "LDS budget of one CU");
@@ -1450,20 +1450,22 @@ __device__ __forceinline__ void put_record(uint8_t* win, int slot, const FeatSum
     for (int q = 0; q < 6; ++q) __builtin_memcpy(rec + 4 * q, &s.v[q], 4);
     rec[24] = (uint8_t)s.v[6];
 }
-// stream n_rec records out as n_rec * 25 contiguous bytes at dst (any alignment): bytes up to the first dword boundary of
-// the output, then dwords
+// Stream n_rec records out as n_rec * 25 contiguous bytes at dst (any alignment).  The records were put at
+// win + record_shift(dst): LDS and global address then agree modulo 16, so after at most 15 head bytes the stream leaves as
+// aligned 16-byte vectors (one ds_read_b128 + one global_store_dwordx4 per lane and step).  With the records at the
+// window's start the LDS side was unaligned whenever dst was: four byte reads + shifts per dword, ~800 of the kernel's
+// ~7 K instructions per tile.
+__device__ __forceinline__ int record_shift(const void* dst) { return (int)((uintptr_t)dst & 15u); }
 __device__ __forceinline__ void flush_records(const uint8_t* win, int n_rec, uint8_t* dst, int lane) {
     const int n_bytes = n_rec * 25;
-    const int hb = min((int)((4u - ((uintptr_t)dst & 3u)) & 3u), n_bytes);
-    if (lane < hb) dst[lane] = win[lane];
-    const int n_dw = (n_bytes - hb) >> 2;
-    for (int i = lane; i < n_dw; i += 64) {
-        uint32_t v;
-        __builtin_memcpy(&v, win + hb + 4 * i, 4);
-        *reinterpret_cast<uint32_t*>(dst + hb + 4 * i) = v;
-    }
-    const int tail0 = hb + 4 * n_dw;
-    if (lane < n_bytes - tail0) dst[tail0 + lane] = win[tail0 + lane];
+    const uint8_t* src = win + record_shift(dst);
+    const int head = min((16 - record_shift(dst)) & 15, n_bytes);
+    if (lane < head) dst[lane] = src[lane];
+    const int n_vec = (n_bytes - head) >> 4;
+    for (int i = lane; i < n_vec; i += 64)
+        *reinterpret_cast<uint4*>(dst + head + 16 * i) = *reinterpret_cast<const uint4*>(src + head + 16 * i);
+    const int tail0 = head + 16 * n_vec;
+    if (lane < n_bytes - tail0) dst[tail0 + lane] = src[tail0 + lane];
 }
 // span records (4 x OUT per token) go through the same window in rounds of what fits
 template <typename OUT>
@@ -1685,10 +1687,12 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
     if (maxc * 2 > ((n_wave + 63) >> 6) * 3) {
         uint8_t* fwin = L.stage;
-        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRoundTm * kFeatRec);   // behind the feature records
+        uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRoundTm * kFeatRec + 16);   // behind the feature records
         lk_u64 trest = x;
         int tk = off;
         for (int win0 = 0; win0 < n_wave; win0 += kFeatRoundTm) {
+            uint8_t* const fdst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
+            const int shift = record_shift(fdst);
             while (trest && tk < win0 + kFeatRoundTm) {
                 const int b = lk_ctz(trest);
                 trest &= trest - 1;
@@ -1727,7 +1731,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                     if (!above) sum.v[q] = swar_add_u8(sum.v[q], cq);
                 }
                 if (active) {
-                    put_record(fwin, j, sum);
+                    put_record(fwin + shift, j, sum);
                     const lk_u64 o_nn = ~o_S & ovalid;
                     const int64_t p = obase + b;
                     const lk_u64 bl = o_B & ((2ull << b) - 1ull);
@@ -1764,7 +1768,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
                 }
             }
             wave_lds_sync();
-            flush_records(fwin, n_here, reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25, lane);
+            flush_records(fwin, n_here, fdst, lane);
             wave_lds_sync();
         }
         return;
@@ -1785,6 +1789,8 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     int k = off;
     for (int win0 = 0; win0 < n_wave; win0 += kFeatRound) {
         const int lim = win0 + kFeatRound;
+        uint8_t* const fdst = reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25;
+        uint8_t* const rwin = win + record_shift(fdst);   // where this round's records go (flush_records)
         while (rest_lo && k < lim) {
             const int b = __builtin_ctz(rest_lo);
             rest_lo &= rest_lo - 1u;
@@ -1793,7 +1799,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
             if (above) seg &= (above & (0u - above)) - 1u;
             const FeatSums sum = feat_popc_half<0>(F, seg);
             if (above) {
-                put_record(win, k - win0, sum);
+                put_record(rwin, k - win0, sum);
             } else {                      // no boundary up to char 31: the token goes on in the high half (the last low token)
                 S_str = sum;
                 str_slot = k;
@@ -1811,7 +1817,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #pragma unroll
                     for (int j = 0; j < 7; ++j) S_str.v[j] = swar_add_u8(S_str.v[j], C.v[j]);
                 }
-                put_record(win, str_slot - win0, S_str);
+                put_record(rwin, str_slot - win0, S_str);
                 str_slot = -1;
             }
         }
@@ -1826,11 +1832,11 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #pragma unroll
                 for (int j = 0; j < 7; ++j) sum.v[j] = swar_add_u8(sum.v[j], C.v[j]);
             }
-            put_record(win, k - win0, sum);
+            put_record(rwin, k - win0, sum);
             ++k;
         }
         wave_lds_sync();
-        flush_records(win, min(kFeatRound, n_wave - win0), reinterpret_cast<uint8_t*>(P.features) + (base_out + win0) * 25, lane);
+        flush_records(win, min(kFeatRound, n_wave - win0), fdst, lane);
         wave_lds_sync();
     }
 
@@ -2083,9 +2089,10 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
                 for (int c = 0; c < LK_N_FEATURES; ++c) sum.v[c >> 2] |= (acc[c] & 0xFFu) << (8 * (c & 3));   // uint8 wrap-around (latok.c:342-354)
             }
             const int n_here = min(64, n_items - k0);
-            if (k < n_items) put_record(s_win, lane, sum);
+            uint8_t* const fdst = reinterpret_cast<uint8_t*>(S.features) + (int64_t)k0 * kFeatRec;
+            if (k < n_items) put_record(s_win + record_shift(fdst), lane, sum);
             wave_lds_sync();
-            flush_records(s_win, n_here, reinterpret_cast<uint8_t*>(S.features) + (int64_t)k0 * kFeatRec, lane);
+            flush_records(s_win, n_here, fdst, lane);
             wave_lds_sync();
         }
     }

@@ -262,7 +262,12 @@ __device__ __forceinline__ void counts_scatter_block(
     if (*n_items_dev > cap) return;
     constexpr int kScatterWaves = scatter_waves(KIND);
     constexpr int kCodes = 1024;                                    // items per round
-    __shared__ int64_t buf_s[kScatterWaves][kCodes];                // KIND 0: window of values (OUT); KIND 1: the item codes
+    // KIND 0: window of values (OUT); KIND 1: the item codes (2 B each) + the 48-byte mask rows of the 64 words.  Sized for
+    // what the form needs (it was 8 KB per wave for every form: 4 workgroups per CU).  Measured on C2, same box: int32 offsets
+    // 0.174 -> 0.165 ms and int32 spans 0.233 -> 0.222 at 7 - 8 workgroups per CU, but int64 spans 0.247 -> 0.256 (twice
+    // the store stream per token): that form keeps the footprint that holds it at 4.
+    constexpr int kBufBytes = KIND == 0 ? kCodes * (int)sizeof(OUT) : (sizeof(OUT) == 8 ? kCodes * 8 : kCodes * 2 + 64 * 48);
+    __shared__ __attribute__((aligned(16))) uint8_t buf_s[kScatterWaves][kBufBytes];
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w0 = ((int64_t)vb * kScatterWaves + wave) * 64;
@@ -382,7 +387,7 @@ __device__ __forceinline__ void counts_scatter_block(
     }
     // the lanes' masks as 48-byte rows in LDS (behind the codes): in the token-major loop lane j reads the row of the
     // word that owns its item with three 16-byte reads (six 64-bit shuffles = twelve ds_bpermute before)
-    uint64_t* rows = reinterpret_cast<uint64_t*>(buf_s[wave]) + (kCodes * 2) / 8;     // codes take kCodes * 2 bytes
+    uint64_t* rows = reinterpret_cast<uint64_t*>(buf_s[wave] + kCodes * 2);            // codes take kCodes * 2 bytes
     {
         uint64_t* r = rows + 6 * lane;
         r[0] = xb; r[1] = nn; r[2] = xb1; r[3] = nn1; r[4] = Bw; r[5] = (uint64_t)lo_in;

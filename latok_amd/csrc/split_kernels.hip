@@ -1462,8 +1462,16 @@ __device__ __forceinline__ void flush_records(const uint8_t* win, int n_rec, uin
     const int head = min((16 - record_shift(dst)) & 15, n_bytes);
     if (lane < head) dst[lane] = src[lane];
     const int n_vec = (n_bytes - head) >> 4;
-    for (int i = lane; i < n_vec; i += 64)
-        *reinterpret_cast<uint4*>(dst + head + 16 * i) = *reinterpret_cast<const uint4*>(src + head + 16 * i);
+    for (int i = lane; i < n_vec; i += 64) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + head + 16 * i);
+#ifdef LATOK_AB_FEAT_NO_FLUSH
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u) dst[0] = 1;   // ablation (timing only): nothing is written
+#elif defined(LATOK_AB_FEAT_PLAIN_FLUSH)
+        *reinterpret_cast<u32x4*>(dst + head + 16 * i) = v;
+#else
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + head + 16 * i));
+#endif
+    }
     const int tail0 = head + 16 * n_vec;
     if (lane < n_bytes - tail0) dst[tail0 + lane] = src[tail0 + lane];
 }
@@ -1660,6 +1668,10 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         }
     }
 
+#ifdef LATOK_AB_FEAT_PREAMBLE_ONLY
+    if (C.v[0] == 0x12345678u && H.v[1] == 0x9abcdef0u) P.features[0] = 1;   // ablation (timing only): keep the preamble alive, stop here
+    return;
+#endif
     // ---- per-word values both forms below need --------------------------------------------------------------------
     const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
     lk_u64 xb1 = __shfl_down(xb, 1), nn1 = __shfl_down(nn, 1);  // the next word's masks
@@ -1685,7 +1697,13 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
-    if (maxc * 2 > ((n_wave + 63) >> 6) * 3) {
+#ifndef LATOK_AB_FEAT_THRESH
+#define LATOK_AB_FEAT_THRESH 5
+#endif
+    // The word-major walk below runs as long as the fullest word (maxc steps of ~160 instructions with the span records), once
+    // per window round; the token-major form takes ceil(n_wave / 64) steps of ~300 whatever the spread.
+    const int wm_rounds = (n_wave + kFeatRound - 1) / kFeatRound;
+    if (maxc * 2 * wm_rounds > ((n_wave + 63) >> 6) * LATOK_AB_FEAT_THRESH) {
         uint8_t* fwin = L.stage;
         uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRoundTm * kFeatRec + 16);   // behind the feature records
         lk_u64 trest = x;
@@ -1779,7 +1797,11 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // planes only), then the part of the one token that may reach from the low half into the high half, then the tokens that
     // start in chars 32..63 (high halves only).  Ranks grow in that order, so the records land at consecutive slots.
     uint8_t* win = L.stage;
+#ifdef LATOK_AB_FEAT_NO_SUMS
+    uint32_t rest_lo = 0, rest_hi = 0;   // ablation (timing only): no token walks for the sums
+#else
     uint32_t rest_lo = (uint32_t)x, rest_hi = (uint32_t)(x >> 32);
+#endif
     const uint32_t xb_lo = (uint32_t)xb, xb_hi = (uint32_t)(xb >> 32);
     const uint32_t valid_lo = (uint32_t)valid, valid_hi = (uint32_t)(valid >> 32);
     FeatSums S_str;                       // low-half sums of the straddling token
@@ -1840,6 +1862,9 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         wave_lds_sync();
     }
 
+#ifdef LATOK_AB_FEAT_NO_SPANS
+    return;   // ablation (timing only): no span records
+#endif
     // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
     OUT* swin = reinterpret_cast<OUT*>(L.stage);

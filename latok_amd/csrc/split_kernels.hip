@@ -114,6 +114,20 @@ __device__ __forceinline__ int wave_sum(int v) {
     return lane_read(v, 15) + lane_read(v, 31) + lane_read(v, 47) + lane_read(v, 63);
 }
 
+// inclusive prefix maximum over the 64 lanes of values >= `floor` (six DPP steps; the __shfl_up form is six dependent
+// ds_bpermute round trips through the LDS pipe, ~0.7 us per call at the occupancy of the featurize kernel)
+__device__ __forceinline__ int wave_scan_max(int v, int floor) {
+    v = max(v, dpp_mov<kDppRowShr1, 0xF>(floor, v));
+    v = max(v, dpp_mov<kDppRowShr2, 0xF>(floor, v));
+    v = max(v, dpp_mov<kDppRowShr4, 0xF>(floor, v));
+    v = max(v, dpp_mov<kDppRowShr8, 0xF>(floor, v));
+    v = max(v, dpp_mov<kDppRowBcast15, 0xA>(floor, v));
+    v = max(v, dpp_mov<kDppRowBcast31, 0xC>(floor, v));
+    return v;
+}
+// maximum over the wave, in every lane (wave-uniform)
+__device__ __forceinline__ int wave_max(int v, int floor) { return lane_read(wave_scan_max(v, floor), 63); }
+
 // inclusive scan over the 64 lanes of the queue transfer functions, earlier lanes applied first; (0,0) is neutral
 // for the functions that occur here (a <= b, b >= 0)
 template <int CTRL, int ROW_MASK>
@@ -1539,8 +1553,8 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     lk_planes F;
     {
         lk_halo h;
-        const uint32_t up = (uint32_t)__shfl_up((int)(d[15] >> 24), 1);
-        const uint32_t dn = (uint32_t)__shfl_down((int)(d[0] & 0xFFFFu), 1);
+        const uint32_t up = (uint32_t)dpp_mov<kDppWaveShr1, 0xF>(0, (int)(d[15] >> 24));      // from lane - 1
+        const uint32_t dn = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)(d[0] & 0xFFFFu));   // from lane + 1
         h.prev = lane > 0 ? up : edge;
         h.next0 = lane < 63 ? (dn & 0xFFu) : (edge & 0xFFu);
         h.next1 = lane < 63 ? (dn >> 8) : (edge >> 8);
@@ -1561,12 +1575,13 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     for (int j = 0; j < 7; ++j) C.v[j] = 0;
     bool open = need_tail;                                     // still collecting
     lk_u64 xb_next_tile = 0, nn_next_tile = 0;                 // boundary / non-SPACE masks of the next tile's first word
+    FeatSums Hs = H;                                           // H / full of lane + d: one more DPP shift per step
+    int fs = full;
     for (int d = 1; d < 64; ++d) {
         if (!__ballot(open && lane + d < 64)) break;
-        FeatSums Hs;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) Hs.v[j] = __shfl_down(H.v[j], d);
-        const int fs = __shfl_down(full, d);
+        for (int j = 0; j < 7; ++j) Hs.v[j] = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)Hs.v[j]);
+        fs = dpp_mov<kDppWaveShl1, 0xF>(0, fs);
         if (open && lane + d < 64) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) C.v[j] = swar_add_u8(C.v[j], Hs.v[j]);
@@ -1674,28 +1689,23 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
 #endif
     // ---- per-word values both forms below need --------------------------------------------------------------------
     const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
-    lk_u64 xb1 = __shfl_down(xb, 1), nn1 = __shfl_down(nn, 1);  // the next word's masks
+    // the next word's masks (from lane + 1)
+    lk_u64 xb1 = (lk_u64)(uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)(uint32_t)xb) |
+                 ((lk_u64)(uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)(uint32_t)(xb >> 32)) << 32);
+    lk_u64 nn1 = (lk_u64)(uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)(uint32_t)nn) |
+                 ((lk_u64)(uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)(uint32_t)(nn >> 32)) << 32);
     if (lane == 63) { xb1 = xb_next_tile; nn1 = nn_next_tile; }
     // start of the string that is open at my word's first char: the last string start before my word inside the tile,
     // else the one that was open when the tile began
     int last_b = B ? 64 * lane + 63 - __builtin_clzll(B) : -1;  // tile-relative position of my word's last string start
-    int carry = last_b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(carry, d);
-        if (lane >= d && o > carry) carry = o;
-    }
-    carry = __shfl_up(carry, 1);
-    if (lane == 0) carry = -1;
+    const int carry = dpp_mov<kDppWaveShr1, 0xF>(-1, wave_scan_max(last_b, -1));   // exclusive: lane 0 gets -1
     const int64_t lo_in = carry >= 0 ? t0 + carry : start_before;
 
     // ---- skewed tiles (some word holds many more tokens than the mean, e.g. CJK text where every char is a token):
     // token-major form.  Every lane lists its tokens as (lane, bit) codes at their rank inside the tile, then lane j
     // takes the j-th token and pulls the owner word's 25 planes (and masks) through shuffles, so all lanes stay busy.
     // ~70 64-bit shuffles per token make it the slower form for evenly filled tiles, hence the choice per tile.
-    int maxc = lk_popc(x);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
+    const int maxc = wave_max(lk_popc(x), 0);
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
 #ifndef LATOK_AB_FEAT_THRESH
 #define LATOK_AB_FEAT_THRESH 5

@@ -392,6 +392,10 @@ __device__ __forceinline__ void counts_scatter_block(
         uint64_t* r = rows + 6 * lane;
         r[0] = xb; r[1] = nn; r[2] = xb1; r[3] = nn1; r[4] = Bw; r[5] = (uint64_t)lo_in;
     }
+#ifdef LATOK_AB_SCATTER_SETUP_ONLY
+    if (rows[0] == 0x123456789abcull) out[0] = 1;   // ablation (timing only): stop before the item loop
+    return;
+#endif
     for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
         while (rest && k < win0 + kCodes) {
             const int b = __builtin_ctzll(rest);
@@ -439,7 +443,11 @@ __device__ __forceinline__ void counts_scatter_block(
                     out2 v;
                     v.x = (OUT)(a2 - lo);
                     v.y = (OUT)(e2 - lo);
+#ifdef LATOK_AB_SCATTER_NO_STORE
+                    if (v.x == (OUT)0x12345678 && v.y == (OUT)0x1abcdef0) out[0] = 1;   // ablation (timing only)
+#else
                     __builtin_nontemporal_store(v, reinterpret_cast<out2*>(out) + base_out + win0 + j);
+#endif
                 }
             }
         }

@@ -191,11 +191,17 @@ __device__ __forceinline__ void slice_lut64(const uint32_t (&d)[16], const uint8
             l |= *reinterpret_cast<const uint32_t*>(e);
             h |= *reinterpret_cast<const uint32_t*>(e + kSliceHiOff);
         }
-        // pin the two words here: without it the compiler requests all 128 lookups first (one result register each, spills)
-        // and ORs them afterwards; 16 in flight per group is plenty
-        asm volatile("" : "+v"(l), "+v"(h));
         lo[g] = l;
         hi[g] = h;
+#ifndef LATOK_AB_SLICE_PIN
+#define LATOK_AB_SLICE_PIN 2
+#endif
+        // pin the words every LATOK_AB_SLICE_PIN groups: without it the compiler requests all 128 lookups first (one result
+        // register each, spills) and ORs them afterwards
+        if ((g + 1) % LATOK_AB_SLICE_PIN == 0) {
+#pragma unroll
+            for (int q = g + 1 - LATOK_AB_SLICE_PIN; q <= g; ++q) asm volatile("" : "+v"(lo[q]), "+v"(hi[q]));
+        }
     }
     lk_planes_from_groups(lo, hi, plane);
 }

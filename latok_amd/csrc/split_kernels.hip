@@ -356,8 +356,8 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
     // halo bytes: lane 0 looks at the 4 bytes before the tile, lanes 1..11 at the 11 bytes after it
     uint32_t hb = 0;
     if (lane == 0) {
-        for (int k = 1; k <= 4; ++k)
-            if (t0 - k >= 0) hb |= (uint32_t)u8[t0 - k] << (8 * (k - 1));      // byte k-1 of hb = byte t0-k
+        // byte k-1 of hb = byte t0-k: the dword before the tile (t0 is a multiple of 4096, u8 is 16-byte aligned), byte-swapped
+        if (t0 > 0) hb = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(u8 + t0 - 4));
     } else if (lane < 12) {
         const int64_t q = t0 + kTile + (lane - 1);
         if (q < total) hb = u8[q];

@@ -266,7 +266,10 @@ __device__ __forceinline__ void counts_scatter_block(
     // what the form needs (it was 8 KB per wave for every form: 4 workgroups per CU).  Measured on C2, same box: int32 offsets
     // 0.174 -> 0.165 ms and int32 spans 0.233 -> 0.222 at 7 - 8 workgroups per CU, but int64 spans 0.247 -> 0.256 (twice
     // the store stream per token): that form keeps the footprint that holds it at 4.
-    constexpr int kBufBytes = KIND == 0 ? kCodes * (int)sizeof(OUT) : (sizeof(OUT) == 8 ? kCodes * 8 : kCodes * 2 + 64 * 48);
+#ifndef LATOK_AB_SPAN64_BUF
+#define LATOK_AB_SPAN64_BUF 6656   // int64 spans: 5 workgroups per CU (4: C3 +2.5 %; 7: C2 +4 %)
+#endif
+    constexpr int kBufBytes = KIND == 0 ? kCodes * (int)sizeof(OUT) : (sizeof(OUT) == 8 ? LATOK_AB_SPAN64_BUF : kCodes * 2 + 64 * 48);
     __shared__ __attribute__((aligned(16))) uint8_t buf_s[kScatterWaves][kBufBytes];
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: input UTF-8 GB/s tokenized by the fused feature+split-mask path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3                       # one GPU
+    python bench.py --gpus N --steps K --warmup W                        # N GPUs of one node from ONE process, no launcher
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W                        # one rank per GPU
+           bench.py --gpus N --steps K --warmup W                        # one process per GPU (gloo carries the barriers)
+
+Without a launcher (WORLD_SIZE unset) the N ranks are N library contexts (latok_ctx_create(device)) driven by N host
+threads of this process -- the product's own way of using a node (include/latok_hip.h "contexts"): every
+string is independent, so there is no collective on the data path, RCCL is not linked and torch is not imported.
+`--devices 0,0 [--take-turns]` rehearses N ranks on fewer GPUs.  Under a launcher every process is one rank and
+torch.distributed (gloo) is used for the barriers and the gather of the per-rank records only.
 
 A "step" is one pass of the whole pipeline (tile index -> fused tiles kernel -> resolve/repair) over one batch of
 synthetic strings that is already resident in HBM.  Default workload at every N = BASELINE.json configs[1] per GPU
@@ -12,20 +18,20 @@ same corpus (string ids rank*1M ...) -> "scaling": "weak".  The other workloads:
     C3   configs[2]  1 M mixed-Unicode strings per GPU (weak)
     C4   configs[3]  100 M strings as C2, the WHOLE batch split over the N ranks (strong; 51 GB resident at N = 1)
     C5   configs[4]  10 K documents x 1 M chars, split over the N ranks (strong; 40 GB resident at N = 1)
-No collective on the data path: strings are independent.  torch is imported only for N > 1, and only for
-the barriers and the reductions of the report (max of the per-rank times, sums of byte counts).
 
-Timing: W untimed warm-up steps, then EXACTLY K steps between a barrier + device synchronisation on both sides.  Every
-rank times its K steps twice over the same region: with one pair of HIP events on the launch stream (GPU time) and with
-the host clock (wall).  `value` = bytes of all ranks x K / max over ranks of the HIP-event time; the max of the wall
-times rides along as `ms_per_step_wall` (with 8 Python processes around a 2 ms region the slowest host's jitter, not a
-GPU, would otherwise decide the number).  `ms_per_rank` lists every rank's event time so that a straggler is visible.
+Timing: W untimed warm-up steps, then EXACTLY K steps.  The timed region of a rank is ONE library call
+(latok_bench_split_mask_gated): rendezvous of all ranks -> host monotonic clock -> HIP event -> K passes -> HIP event ->
+stream synchronise -> host clock -> rendezvous.  `value` = UTF-8 bytes of all ranks x K / whole-job WALL time (in
+process: last rank out - first rank in, one clock; under a launcher: max over ranks of the rank's wall time).  The
+HIP-event time of the same K steps rides along (`ms_per_step_events`, `value_events`, `ms_per_rank`); round 2 reported
+that one as `value` (0.7-2 % higher), round 1 and this round the wall time, as the contract reads.
 
-Prints ONE JSON line on rank 0.  Besides the contract keys it carries
-  roofline     -- dominant kernel (k_tiles_main): algorithmic HBM bytes per launch / its HIP-event time, vs 8 TB/s
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline     -- dominant kernel (k_tiles_main): algorithmic HBM bytes per launch / its HIP-event time, vs 8 TB/s; measured
+                  on every rank (frac_per_rank), `frac` is the slowest rank's
   sustained    -- >= 1 s of back-to-back steps outside the timed region (clock / thermal drift shows here)
-  cpu_baseline -- the reference's own C functions (oracle/_ref, built from the reference's latok.c) under a restated
-                  NumPy glue, 1 thread, timed on this host on the same corpus (N = 1, rank 0 only);
+  cpu_baseline -- at every N: the reference's own C functions (oracle/_ref, built from the reference's latok.c) under a
+                  restated NumPy glue, 1 thread, timed on this host on the same corpus;
                   cpu_baseline_port = oracle/latok_oracle.c (1 thread); cpu_baseline_fused_allcores = the fused CPU
                   model (oracle/fused_model.cpp) over all host cores.
 """
@@ -44,6 +50,7 @@ sys.path.insert(0, ROOT)
 
 from latok_amd import _lib  # noqa: E402
 
+GATE_TIMEOUT_S = 900.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 WORKLOADS = {
@@ -54,7 +61,7 @@ WORKLOADS = {
     "C5": (_lib.CORPUS_ASCII, 0x1A70C0E0, 1_000_000, 1_000_000, 10_000, "10K documents x 1M chars, split over the ranks (BASELINE configs[4])"),
 }
 SCALING = {"C2": "weak", "C3": "weak", "C4": "strong", "C5": "strong"}
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_summary.json", "r02_pmc_summary.json")]
 
 
 def shard_string_ids(n_per_gpu: int, rank: int):
@@ -191,22 +198,323 @@ def cpu_fused_allcores(workload, cps, row, utf8_bytes, repeats=3):
 
 
 def pmc_traffic(workload: str, total_chars: int):
-    """HBM bytes per k_tiles_main launch from the committed PMC passes of the same workload (profiles/, collected with
-    rocprofv3 --pmc as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections); a
-    counter pass cannot run inside this process, so the figure is null for a workload / size that has none."""
-    try:
-        with open(PMC_SUMMARY) as f:
-            pmc = json.load(f)
-        for rec in pmc.get("runs", []):
-            if (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
-                    and rec.get("total_chars") == total_chars):
-                return rec.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    """HBM bytes per k_tiles_main launch from the committed PMC passes of the same workload and size (profiles/, collected
+    with rocprofv3 --pmc as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
+    a counter pass cannot run inside this process, so the figure is null for a workload / size that has none."""
+    for path in PMC_SUMMARIES:
+        try:
+            with open(path) as f:
+                pmc = json.load(f)
+            for rec in pmc.get("runs", []):
+                if (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
+                        and rec.get("total_chars") == total_chars):
+                    return rec.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     return None
 
 
-def main():
+class RealApi:
+    """What the job runner needs from the product: the C ABI and a context per device.  tests/test_bench_launcher.py
+    drives the same runner with a fake of this (no GPU)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def device_count(self):
+        return int(self.lib.latok_device_count())
+
+    def context(self, device):
+        return _lib.Context(device)
+
+    def check(self, rc):
+        _lib.check(rc)
+
+    def last_error(self):
+        return _lib.last_error()
+
+
+class Shard:
+    """One rank's work: an independent contiguous string-id range of the corpus, resident in ITS device's HBM.  Every
+    method must run on the host thread whose current context is the rank's (in-process mode: the rank's own thread)."""
+
+    def __init__(self, api, args, rank, world):
+        self.api, self.lib, self.args, self.rank, self.world = api, api.lib, args, rank, world
+        model, seed, lo, hi, n_default, _ = WORKLOADS[args.workload]
+        if SCALING[args.workload] == "weak":
+            self.sid0, self.n_str = shard_string_ids(args.strings or n_default, rank)
+        else:
+            self.sid0, self.n_str = split_string_ids(args.strings or n_default, rank, world)
+        self.total = self.utf8 = 0
+        self.d_row = self.d_cps = self.d_bits = None
+
+    def build(self):
+        """the shard directly in HBM: offsets on the host (8 B/string), code points generated on the device"""
+        lib, chk = self.lib, self.api.check
+        model, seed, lo, hi, _, _ = WORKLOADS[self.args.workload]
+        row = np.zeros(self.n_str + 1, np.int64)
+        chk(lib.latok_corpus_offsets(seed, self.sid0, self.n_str, lo, hi, row.ctypes.data))
+        self.total = int(row[-1])
+        self.d_row = lib.latok_dev_alloc(row.nbytes)
+        self.d_cps = lib.latok_dev_alloc(self.total * 4)
+        self.d_bits = lib.latok_dev_alloc(((self.total + 63) // 64) * 8)
+        if not (self.d_row and self.d_cps and self.d_bits):
+            raise RuntimeError(self.api.last_error())
+        chk(lib.latok_memcpy_h2d(self.d_row, row.ctypes.data, row.nbytes))
+        chk(lib.latok_corpus_fill_device(seed, model, self.sid0, self.n_str, self.d_row, self.d_cps, None))
+        u = C.c_int64(0)
+        chk(lib.latok_utf8_bytes(self.d_cps, self.total, C.byref(u), _lib.DEVICE_PTRS))
+        self.utf8 = int(u.value)
+        chk(lib.latok_reserve(self.total, self.n_str))
+
+    def warmup(self, n):
+        if n > 0:
+            self.api.check(self.lib.latok_bench_split_mask(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, n, 0,
+                                                           None, None, None))
+        self.api.check(self.lib.latok_sync())
+
+    def timed(self, steps, gate):
+        """EXACTLY `steps` pipeline passes: gate -> host clock -> HIP event -> passes -> HIP event -> stream sync -> host
+        clock -> gate, all inside one library call (no interpreter between the clocks)"""
+        ms, t0, t1 = C.c_float(0), C.c_int64(0), C.c_int64(0)
+        self.api.check(self.lib.latok_bench_split_mask_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, steps, gate,
+                                                             C.byref(ms), C.byref(t0), C.byref(t1)))
+        return {"ms_events": float(ms.value), "t0_ns": int(t0.value), "t1_ns": int(t1.value)}
+
+    def kernel_only(self, steps):
+        """the dominant kernel alone: `steps` back-to-back launches of k_tiles_main between one HIP event pair"""
+        ms, n_fix = C.c_float(0), C.c_int64(0)
+        self.api.check(self.lib.latok_bench_split_mask(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, 0, steps, None,
+                                                       C.byref(ms), C.byref(n_fix)))
+        return float(ms.value) / steps, int(n_fix.value)
+
+    def sustained(self, seconds, ms_per_step):
+        """>= `seconds` of back-to-back pipeline passes, in chunks of <= 2000 passes per event pair"""
+        want = max(self.args.steps, int(seconds / (ms_per_step / 1e3)) + 1)
+        done, t_ms, chunks = 0, 0.0, []
+        while done < want:
+            k = min(2000, want - done)
+            ms = C.c_float(0)
+            self.api.check(self.lib.latok_bench_split_mask(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, 0, k,
+                                                           C.byref(ms), None, None))
+            chunks.append(ms.value / k)
+            t_ms += ms.value
+            done += k
+        return {"steps": done, "seconds": t_ms / 1e3, "ms_per_step": t_ms / done,
+                "value": self.utf8 * done / (t_ms / 1e3) / 1e9, "unit": "GB/s (rank 0)",
+                "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1]}
+
+    def stream_read(self):
+        """streaming-read ceiling of this GPU on the same buffer"""
+        nbytes = min((self.total * 4 // 16384) * 16384, 1 << 31)
+        if nbytes <= 0:
+            return None
+        ms = C.c_float(0)
+        self.api.check(self.lib.latok_bench_stream_read(self.d_cps, nbytes, 3, 20, C.byref(ms)))
+        return nbytes / (ms.value / 20 / 1e3) / 1e9 if ms.value > 0 else None
+
+    def free(self):
+        for p in (self.d_row, self.d_cps, self.d_bits):
+            if p:
+                self.lib.latok_dev_free(p)
+        self.d_row = self.d_cps = self.d_bits = None
+
+    def alg_read(self):
+        return 4 * self.total + 8 * (self.n_str + 1)   # SURVEY 8d: 4 B/code point + 8 B/string row offset
+
+
+def measure_shard(sh, args, gate, phase):
+    """The measurement protocol of one rank of the in-process job.  `phase()` is a no-op context when every rank has a GPU
+    of its own (the gate inside latok_bench_split_mask_gated then starts the timed regions together) and one global lock
+    under --take-turns, where ranks share a GPU and must not overlap."""
+    lib, chk = sh.lib, sh.api.check
+    sh.build()
+    sh.warmup(args.warmup)
+    chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
+    with phase():
+        rec = sh.timed(args.steps, None if args.take_turns else gate)
+    chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
+    with phase():
+        k_ms, n_fix = sh.kernel_only(args.steps)
+    rec.update(rank=sh.rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
+               sustained=None, measured_read=None)
+    chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
+    if sh.rank == 0:   # outside the timed region, the other ranks are done
+        if args.sustain_s > 0 and rec["ms_events"] > 0:
+            rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+        rec["measured_read"] = sh.stream_read()
+    sh.free()
+    return rec
+
+
+class _NoLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def run_in_process(api, args, devices):
+    """N > 1 (and N = 1) without a launcher: one context + one host thread per entry of `devices`; the threads meet at a
+    gate inside the library, so the timed regions start within microseconds of each other whatever the interpreter does.
+    No torch, no RCCL: the shards are independent."""
+    world = len(devices)
+    gate = C.c_void_p()
+    api.check(api.lib.latok_gate_create(world, C.byref(gate)))
+    turn_lock = threading.Lock()
+    phase = (lambda: turn_lock) if args.take_turns else _NoLock
+    results, errors = [None] * world, []
+
+    def body(rank):
+        ctx = None
+        try:
+            ctx = api.context(devices[rank])
+            ctx.make_current()
+            results[rank] = measure_shard(Shard(api, args, rank, world), args, gate, phase)
+        except BaseException as exc:
+            errors.append((rank, exc))
+            api.lib.latok_gate_break(gate)   # the other ranks fail at their next wait instead of sitting out the timeout
+        finally:
+            if ctx is not None:
+                try:
+                    api.lib.latok_ctx_set_current(None)
+                    ctx.destroy()
+                except Exception:
+                    pass
+
+    threads = [threading.Thread(target=body, args=(r,), name=f"bench-rank{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    api.lib.latok_gate_destroy(gate)
+    if errors:
+        errors.sort(key=lambda e: "gate: broken" in str(e[1]))   # the root cause first, not the ranks it took along
+        rank, exc = errors[0]
+        raise RuntimeError(f"rank {rank} (device {devices[rank]}) failed: {exc}") from exc
+    return results
+
+
+def run_under_launcher(api, args, rank, world, local_rank):
+    """One process per GPU (torchrun): this process is ONE rank.  torch.distributed carries the barriers and the gather of
+    the per-rank records only -- gloo by default (nothing here needs RCCL: no collective on the data path)."""
+    import torch.distributed as dist
+    tdev = None   # the reductions run on host tensors
+    n_dev = max(1, api.device_count())
+    device = args.device if args.device >= 0 else local_rank % n_dev   # a launcher may narrow HIP_VISIBLE_DEVICES per rank
+    dist.init_process_group(backend="gloo")
+
+    class _Barrier:
+        def __init__(self, phase):
+            pass
+
+        def __enter__(self):
+            if args.take_turns:
+                for _ in range(rank):
+                    dist.barrier()
+
+        def __exit__(self, *exc):
+            if args.take_turns:
+                for _ in range(world - rank):
+                    dist.barrier()
+            return False
+
+    ctx = api.context(device)
+    ctx.make_current()
+    try:
+        sh = Shard(api, args, rank, world)
+        sh.build()
+        sh.warmup(args.warmup)
+        dist.barrier()
+        with _Barrier("timed"):
+            rec = sh.timed(args.steps, None)
+        dist.barrier()
+        with _Barrier("kernel"):
+            k_ms, n_fix = sh.kernel_only(args.steps)
+        rec.update(rank=rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
+                   sustained=None, measured_read=None)
+        dist.barrier()
+        if rank == 0:
+            if args.sustain_s > 0 and rec["ms_events"] > 0:
+                rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+            rec["measured_read"] = sh.stream_read()
+        sh.free()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rec)
+        # the contract's reductions, spelled out (max of the per-rank times, sum of the bytes): must agree with the records
+        wall_max = reduce_max_seconds(dist, (rec["t1_ns"] - rec["t0_ns"]) / 1e9, tdev)
+        assert abs(wall_max - max((g["t1_ns"] - g["t0_ns"]) / 1e9 for g in gathered)) < 1e-9
+        return gathered, dist
+    finally:
+        api.lib.latok_ctx_set_current(None)
+        ctx.destroy()
+
+
+def build_line(args, recs, mode, devices, same_start):
+    """the ONE JSON line, from the per-rank records (rank order)"""
+    world = len(recs)
+    _, _, _, _, _, desc = WORKLOADS[args.workload]
+    K = args.steps
+    utf8_all = sum(r["utf8"] for r in recs)
+    walls = [(r["t1_ns"] - r["t0_ns"]) / 1e9 for r in recs]
+    # whole-job wall time: first rank in to last rank out when the ranks share one clock and one start (in-process gate),
+    # otherwise the slowest rank's own wall time
+    if same_start:
+        job_s = (max(r["t1_ns"] for r in recs) - min(r["t0_ns"] for r in recs)) / 1e9
+    else:
+        job_s = max(walls)
+    ev_max = max(r["ms_events"] for r in recs) / 1e3
+    fracs = [r["alg_read"] / (r["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs]
+    worst = min(range(world), key=lambda i: fracs[i])
+    r0 = recs[0]
+    achieved = recs[worst]["alg_read"] / (recs[worst]["kernel_ms"] / 1e3) / 1e9
+    value = utf8_all * K / job_s / 1e9
+    line = {
+        "metric": "input UTF-8 GB/s tokenized (fused feature+split-mask path)",
+        "value": value, "unit": "GB/s",
+        "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": job_s / K * 1e3,
+        "higher_is_better": True, "scaling": SCALING[args.workload], "vs_baseline": None,
+        "dtype": "u64", "dtype_note": "u32 code points in, 64-bit bit-sliced boolean words, u64 bitmask out (integer / bit ops)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "strings_per_gpu": r0["n_str"], "strings_total": sum(r["n_str"] for r in recs),
+                   "chars_total": sum(r["total"] for r in recs), "utf8_bytes_total": utf8_all,
+                   "sharding": f"{world} x independent contiguous string-id shards, no collective on the data path",
+                   "launch": mode, "devices": devices},
+        "timing": ("host monotonic clock, inputs resident in HBM: every rank's region = [gate ->] clock -> K pipeline passes -> "
+                   "stream synchronise -> clock inside one library call; value = bytes of all ranks x K / "
+                   + ("(last rank out - first rank in)" if same_start else "max over ranks of the rank's own wall time")
+                   + "; the HIP-event time of the same K steps rides along as ms_per_step_events / value_events"),
+        "ms_per_step_events": ev_max / K * 1e3,
+        "value_events": utf8_all * K / ev_max / 1e9,
+        "ms_per_rank": [r["ms_events"] / K for r in recs],
+        "ms_per_rank_wall": [w / K * 1e3 for w in walls],
+        "start_skew_us": (max(r["t0_ns"] for r in recs) - min(r["t0_ns"] for r in recs)) / 1e3 if same_start else None,
+        "sustained": r0["sustained"],
+        "fix_tiles_rank0": r0["n_fix"], "tiles_rank0": (r0["total"] + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
+        "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": fracs[worst], "traffic": pmc_traffic(args.workload, recs[worst]["total"]),
+                     "alg_bytes_per_launch": recs[worst]["alg_read"], "kernel_ms": recs[worst]["kernel_ms"],
+                     "kernel_timing": f"{K} back-to-back launches between one HIP event pair on the launch stream, per rank; "
+                                      "frac / achieved = the SLOWEST rank's",
+                     "frac_per_rank": fracs, "kernel_ms_per_rank": [r["kernel_ms"] for r in recs],
+                     "pipeline_frac": min(r["alg_read"] / (r["ms_events"] / K / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs),
+                     "measured_stream_read": r0["measured_read"],
+                     "frac_of_measured_read": (r0["alg_read"] / (r0["kernel_ms"] / 1e3) / 1e9 / r0["measured_read"]) if r0["measured_read"] else None},
+    }
+    if args.take_turns:
+        line["rehearsal"] = ("ranks took turns on shared GPU(s): per-rank times are single-GPU times; value_projected is what "
+                             f"{world} such GPUs would give -- a rehearsal of the N > 1 code path, not a measurement of {world} GPUs")
+        proj = max(walls)
+        line["value_projected"] = utf8_all * K / proj / 1e9
+        line["ms_per_step_projected"] = proj / K * 1e3
+        line["value"] = None
+        line["ms_per_step"] = None
+    return line
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -216,172 +524,67 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-strings", type=int, default=1_000_000)
     ap.add_argument("--sustain-s", type=float, default=1.0, help="length of the sustained run after the timed region (0 = off)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL) for real runs; gloo lets several ranks rehearse on one GPU")
-    ap.add_argument("--device", type=int, default=-1, help="HIP device for this rank (default: LOCAL_RANK)")
+    ap.add_argument("--devices", default="", help="in-process mode: comma-separated HIP device of each rank (default 0..N-1); "
+                                                  "a device may repeat (rehearsal on fewer GPUs)")
+    ap.add_argument("--dist-backend", default="gloo", choices=["gloo"],
+                    help="under torchrun only: what carries the barriers and the gather of the report.  The data path has no "
+                         "collective and RCCL is not linked, so there is nothing for an RCCL backend to do")
+    ap.add_argument("--device", type=int, default=-1, help="under torchrun only: HIP device of this rank (default LOCAL_RANK mod device count)")
     ap.add_argument("--take-turns", action="store_true",
-                    help="rehearsal on ONE shared GPU: the ranks run their timed regions one after the other, so each rank's "
-                         "time is what a GPU of its own would give; the line is marked as a rehearsal")
-    args = ap.parse_args()
+                    help="rehearsal on shared GPU(s): the ranks run their timed regions one after the other, so each rank's "
+                         "time is what a GPU of its own would give; the line is marked as a rehearsal and carries no `value`")
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus and --steps must be >= 1, --warmup >= 0")
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU", file=sys.stderr)
-        sys.exit(2)
 
-    device = args.device if args.device >= 0 else local_rank
-    dist = tdev = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.dist_backend == "nccl":
-            torch.cuda.set_device(device)
-            tdev = torch.device("cuda", device)
-            dist.init_process_group(backend="nccl", device_id=tdev)
-        else:
-            dist.init_process_group(backend="gloo")
-
-    lib = _lib.ensure_init(device)
-    model, seed, lo, hi, n_default, desc = WORKLOADS[args.workload]
-    scaling = SCALING[args.workload]
-    if scaling == "weak":
-        sid0, n_str = shard_string_ids(args.strings or n_default, rank)
+def pick_devices(args, n_dev):
+    """in-process mode: the HIP device of each of the N ranks"""
+    if args.devices:
+        devices = [int(x) for x in args.devices.split(",") if x != ""]
+        if len(devices) != args.gpus:
+            raise SystemExit(f"bench.py: --devices lists {len(devices)} devices for --gpus {args.gpus}")
     else:
-        sid0, n_str = split_string_ids(args.strings or n_default, rank, world)
+        devices = list(range(args.gpus))
+    bad = [d for d in devices if d < 0 or d >= n_dev]
+    if bad:
+        raise SystemExit(f"bench.py: device(s) {bad} not present ({n_dev} HIP device(s) visible); "
+                         f"use --devices (a device may repeat) to rehearse --gpus {args.gpus} on fewer GPUs")
+    return devices
 
-    # ---- build this rank's shard directly in HBM (offsets on host: 8 B/string; code points on device) -------------
-    row = np.zeros(n_str + 1, np.int64)
-    _lib.check(lib.latok_corpus_offsets(seed, sid0, n_str, lo, hi, row.ctypes.data))
-    total = int(row[-1])
-    d_row = lib.latok_dev_alloc(row.nbytes)
-    d_cps = lib.latok_dev_alloc(total * 4)
-    d_bits = lib.latok_dev_alloc(((total + 63) // 64) * 8)
-    if not (d_row and d_cps and d_bits):
-        raise RuntimeError(_lib.last_error())
-    _lib.check(lib.latok_memcpy_h2d(d_row, row.ctypes.data, row.nbytes))
-    _lib.check(lib.latok_corpus_fill_device(seed, model, sid0, n_str, d_row, d_cps, None))
-    utf8 = C.c_int64(0)
-    _lib.check(lib.latok_utf8_bytes(d_cps, total, C.byref(utf8), _lib.DEVICE_PTRS))
-    _lib.check(lib.latok_reserve(total, n_str))
-    del row
 
-    def sync_all():
-        _lib.check(lib.latok_sync())
-        if dist is not None:
-            if tdev is not None:
-                import torch
-                torch.cuda.synchronize()
-            dist.barrier()
-
-    # ---- W untimed warm-up steps, then exactly K timed steps ------------------------------------------------------
-    if args.warmup > 0:
-        _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, args.warmup, 0, None, None, None))
-    sync_all()
-    ms_events = C.c_float(0)
-    wall = 0.0
-    for turn in range(world if args.take_turns else 1):
-        if not args.take_turns or turn == rank:
-            t0 = time.perf_counter()
-            # K pipeline passes between one pair of HIP events on the launch stream; returns after the second event
-            _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, args.steps, C.byref(ms_events), None, None))
-            _lib.check(lib.latok_sync())
-            if tdev is not None:
-                import torch
-                torch.cuda.synchronize()
-            wall = time.perf_counter() - t0
-        if dist is not None:
-            dist.barrier()
-    ev_s = ms_events.value / 1e3
-    if dist is not None:
-        per_rank_ms = [x * 1e3 / args.steps for x in gather_per_rank(dist, ev_s, rank, world, tdev)]
-        ev_max = reduce_max_seconds(dist, ev_s, tdev)
-        wall_max = reduce_max_seconds(dist, wall, tdev)
-        utf8_all = reduce_sum_int(dist, utf8.value, tdev)
-        chars_all = reduce_sum_int(dist, total, tdev)
-        strs_all = reduce_sum_int(dist, n_str, tdev)
+def main(argv=None, api=None, out=None):
+    args = parse_args(argv)
+    api = api or RealApi()
+    env_world = os.environ.get("WORLD_SIZE", "")
+    dist = None
+    if env_world != "" and int(env_world) > 1:
+        # started by a launcher, one process per GPU (python -m torch.distributed.run ... bench.py --gpus N)
+        rank, world, local_rank = int(os.environ.get("RANK", "0")), int(env_world), int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            if rank == 0:
+                print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            sys.exit(2)
+        recs, dist = run_under_launcher(api, args, rank, world, local_rank)
+        mode, devices, same_start = f"one process per GPU (launcher, {args.dist_backend} for barriers only)", None, False
     else:
-        per_rank_ms = [ev_s * 1e3 / args.steps]
-        ev_max, wall_max, utf8_all, chars_all, strs_all = ev_s, wall, utf8.value, total, n_str
-
-    # ---- everything below is outside the timed region ------------------------------------------------------------------
-    # dominant kernel alone: `steps` back-to-back launches of k_tiles_main between one pair of HIP events on the launch
-    # stream (per-launch event pairs charge each interval with ~6 us of marker dispatch)
-    ms_tiles, n_fix = C.c_float(0), C.c_int64(0)
-    sustained = None
-    ms_read = C.c_float(0)
-    read_bytes = min((total * 4 // 16384) * 16384, 1 << 31)
-    if rank == 0 or not args.take_turns:
-        _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, args.steps, None, C.byref(ms_tiles),
-                                              C.byref(n_fix)))
+        # no launcher: N contexts + N host threads in THIS process (also for N = 1)
+        rank = 0
+        devices = pick_devices(args, api.device_count())
+        recs = run_in_process(api, args, devices)
+        mode, same_start = "one process, one context + host thread per GPU (no launcher, no torch, no RCCL)", not args.take_turns
     if rank == 0:
-        # sustained: >= sustain_s of back-to-back pipeline passes, in chunks of <= 2000 passes per event pair
-        if args.sustain_s > 0 and ev_s > 0:
-            per = ev_s / args.steps
-            want = max(args.steps, int(args.sustain_s / per) + 1)
-            done, t_ms, chunks = 0, 0.0, []
-            while done < want:
-                k = min(2000, want - done)
-                ms = C.c_float(0)
-                _lib.check(lib.latok_bench_split_mask(d_cps, d_row, n_str, total, d_bits, 0, k, C.byref(ms), None, None))
-                chunks.append(ms.value / k)
-                t_ms += ms.value
-                done += k
-            sustained = {"steps": done, "seconds": t_ms / 1e3, "ms_per_step": t_ms / done,
-                         "value": utf8.value * done / (t_ms / 1e3) / 1e9, "unit": "GB/s (rank 0)",
-                         "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1]}
-        # streaming-read ceiling of this box on the same buffer
-        if read_bytes > 0:
-            _lib.check(lib.latok_bench_stream_read(d_cps, read_bytes, 3, 20, C.byref(ms_read)))
-    for p in (d_row, d_cps, d_bits):
-        lib.latok_dev_free(p)
-
-    if rank == 0:
-        alg_read = 4 * total + 8 * (n_str + 1)          # 4 B/code point + 8 B/string row offset
-        t_kernel = ms_tiles.value / args.steps / 1e3     # s per launch
-        achieved = alg_read / t_kernel / 1e9
-        measured_read = (read_bytes / (ms_read.value / 20 / 1e3) / 1e9) if ms_read.value > 0 else None
-        traffic = pmc_traffic(args.workload, total)
-        line = {
-            "metric": "input UTF-8 GB/s tokenized (fused feature+split-mask path)",
-            "value": utf8_all * args.steps / ev_max / 1e9,
-            "unit": "GB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ev_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "u64", "dtype_note": "u32 code points in, 64-bit bit-sliced boolean words, u64 bitmask out (integer / bit ops)",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "strings_per_gpu": n_str, "strings_total": strs_all,
-                       "chars_total": chars_all, "utf8_bytes_total": utf8_all,
-                       "sharding": f"{world} x independent contiguous string-id shards, no collective on the data path"},
-            "timing": "max over ranks of the HIP-event time of the K steps (one event pair on the launch stream per rank), "
-                      "region bracketed by barrier + device sync on both sides",
-            "ms_per_step_wall": wall_max / args.steps * 1e3,
-            "value_wall": utf8_all * args.steps / wall_max / 1e9,
-            "ms_per_rank": per_rank_ms,
-            "sustained": sustained,
-            "fix_tiles_rank0": n_fix.value, "tiles_rank0": (total + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
-            "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_read, "kernel_ms": t_kernel * 1e3,
-                         "kernel_timing": f"{args.steps} back-to-back launches between one HIP event pair on the launch stream (rank 0)",
-                         "pipeline_frac": alg_read / (per_rank_ms[0] / 1e3) / 1e9 / HBM_PEAK_GBS,
-                         "measured_stream_read": measured_read,
-                         "frac_of_measured_read": (achieved / measured_read) if measured_read else None},
-        }
-        if args.take_turns:
-            line["rehearsal"] = ("ranks took turns on ONE shared GPU: per-rank times are single-GPU times and `value` is what "
-                                 f"{world} such GPUs would give -- a rehearsal of the N > 1 code path, not a measurement of {world} GPUs")
-        if world == 1 and not args.no_cpu_baseline:
-            line.update(cpu_baselines("C2" if args.workload in ("C4",) else args.workload,
-                                      min(args.cpu_strings, n_str, 1_000_000 if args.workload != "C5" else 64)))
-        print(json.dumps(line), flush=True)
+        line = build_line(args, recs, mode, devices, same_start)
+        if not args.no_cpu_baseline:   # next to the GPU number at every N: the host's cores, same corpus (rank 0's shard head)
+            n_cpu = min(args.cpu_strings, recs[0]["n_str"], 1_000_000 if args.workload != "C5" else 64)
+            line.update(cpu_baselines("C2" if args.workload == "C4" else args.workload, n_cpu))
+        print(json.dumps(line), file=out or sys.stdout, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

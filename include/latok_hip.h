@@ -270,6 +270,27 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
  * launches after `warmup` untimed ones.  Measurement aid for SURVEY.md 8(d) ("vs. a measured streaming-read kernel"). */
 int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out);
 
+/* Several contexts in one process, timed as ONE job (one host thread + one context per GPU, no collective).
+ * A gate is a rendezvous of `parties` host threads that lives outside any context (no device needed):
+ * latok_gate_wait returns on every thread once all of them have arrived (it spins inside the library, so a ctypes
+ * caller has released the GIL) and fails with LATOK_ERR_INVALID after `timeout_s` seconds without the full set.  A gate
+ * can be passed any number of times.  latok_gate_break makes every present and future wait fail at once (a party that
+ * cannot reach the gate calls it so that the others do not sit out the timeout).
+ * latok_bench_split_mask_gated = the timed region of the whole-job measurement on the CURRENT context:
+ *   wait at `gate` (NULL: no wait) -> host clock t0 -> HIP event -> `iters` whole-pipeline passes -> HIP event ->
+ *   stream synchronise -> host clock t1 -> wait at `gate` again (so that no thread starts anything else on the node while
+ *   another is still inside its region).
+ * ms_events_out = the event pair; t0_ns_out / t1_ns_out = the host's monotonic clock (one clock for every thread of the
+ * process), so the job took max(t1) - min(t0) over the contexts. */
+typedef struct latok_gate latok_gate;
+int latok_gate_create(int parties, latok_gate** gate_out);
+int latok_gate_destroy(latok_gate* gate);
+int latok_gate_wait(latok_gate* gate, double timeout_s);
+int latok_gate_break(latok_gate* gate);
+int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                                 uint64_t* mask_dev, int iters, latok_gate* gate, float* ms_events_out,
+                                 int64_t* t0_ns_out, int64_t* t1_ns_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,11 @@ SIGNATURES = {
     "latok_reset_rules": (ci, []),
     "latok_rules_active": (ci, []),
     "latok_bench_stream_read": (ci, [vp, i64, ci, ci, C.POINTER(C.c_float)]),
+    "latok_gate_create": (ci, [ci, C.POINTER(vp)]),
+    "latok_gate_destroy": (ci, [vp]),
+    "latok_gate_wait": (ci, [vp, C.c_double]),
+    "latok_gate_break": (ci, [vp]),
+    "latok_bench_split_mask_gated": (ci, [vp, vp, i64, i64, vp, ci, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)]),
 }
 
 
@@ -141,22 +146,38 @@ class Context:
         h = vp()
         check(lib.latok_ctx_create(int(device), C.byref(h)))
         self._lib, self.handle, self.device = lib, h, int(device)
-        self._prev = []
+        # the saved "previous current context" stack is PER THREAD: the current context is a thread-local of the library,
+        # and one Context object may be entered from several threads at once
+        self._tls = threading.local()
+        self._entered = 0
+        self._count_lock = threading.Lock()
 
     def make_current(self):
         check(self._lib.latok_ctx_set_current(self.handle))
 
     def __enter__(self):
-        self._prev.append(self._lib.latok_ctx_get_current())
+        if not self.handle:
+            raise RuntimeError("context has been destroyed")
+        stack = self._tls.__dict__.setdefault("prev", [])
+        stack.append(self._lib.latok_ctx_get_current())
+        with self._count_lock:
+            self._entered += 1
         self.make_current()
         return self
 
     def __exit__(self, *exc):
-        check(self._lib.latok_ctx_set_current(self._prev.pop()))
+        with self._count_lock:
+            self._entered -= 1
+        check(self._lib.latok_ctx_set_current(self._tls.prev.pop()))
         return False
 
     def destroy(self):
+        """Destroy the library context.  Refused while some thread is still inside ``with ctx:`` (its thread-local
+        current context would dangle)."""
         if self.handle:
+            with self._count_lock:
+                if self._entered > 0:
+                    raise RuntimeError(f"context is still entered by {self._entered} thread(s)")
             check(self._lib.latok_ctx_destroy(self.handle))
             self.handle = vp()
 

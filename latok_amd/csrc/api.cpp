@@ -10,10 +10,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/latok_hip.h"
@@ -103,6 +105,15 @@ struct PinBuf {
 // Bounded: after kPollNs without the word (first launch of a code object, a busy stream, a faulted kernel) the caller
 // falls back to hipStreamSynchronize, which also surfaces errors.  LATOK_SMALL_POLL=0 turns polling off.
 constexpr long long kPollNs = 200000;
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 static bool poll_completion() {
     static const bool on = [] { const char* e = getenv("LATOK_SMALL_POLL"); return !(e && e[0] == '0'); }();
     return on;
@@ -112,7 +123,7 @@ static bool wait_completion_word(const unsigned long long* word, unsigned long l
     for (;;) {
         for (int i = 0; i < 256; ++i) {
             if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == seq) return true;
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kPollNs) return false;
     }
@@ -1872,6 +1883,93 @@ int latok_bench_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, 
         *n_fix_tiles_out = 0;
         if (total > 0) HIP_TRY(hipMemcpy(n_fix_tiles_out, g.fix_count.p, 8, hipMemcpyDeviceToHost));
     }
+    return LATOK_OK;
+}
+
+
+// ---- several contexts timed as one job ---------------------------------------------------------------------------------
+}  // extern "C"
+struct latok_gate {
+    int parties = 1;
+    std::atomic<int> arrived{0};
+    std::atomic<unsigned> phase{0};
+    std::atomic<bool> broken{false};
+};
+extern "C" {
+
+int latok_gate_create(int parties, latok_gate** gate_out) {
+    if (parties < 1 || !gate_out) return fail(LATOK_ERR_INVALID, "gate: parties must be >= 1");
+    latok_gate* g = new (std::nothrow) latok_gate;
+    if (!g) return fail(LATOK_ERR_NOMEM, "out of host memory");
+    g->parties = parties;
+    *gate_out = g;
+    return LATOK_OK;
+}
+int latok_gate_destroy(latok_gate* gate) {
+    delete gate;
+    return LATOK_OK;
+}
+int latok_gate_break(latok_gate* gate) {
+    if (gate) gate->broken.store(true, std::memory_order_release);
+    return LATOK_OK;
+}
+int latok_gate_wait(latok_gate* gate, double timeout_s) {
+    if (!gate) return LATOK_OK;
+    if (gate->broken.load(std::memory_order_acquire)) return fail(LATOK_ERR_INVALID, "gate: broken by another party");
+    const unsigned ph = gate->phase.load(std::memory_order_acquire);
+    if (gate->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == gate->parties) {   // last one in opens the gate
+        gate->arrived.store(0, std::memory_order_relaxed);
+        gate->phase.store(ph + 1, std::memory_order_release);
+        return LATOK_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (gate->phase.load(std::memory_order_acquire) != ph) return LATOK_OK;
+        if (gate->broken.load(std::memory_order_acquire)) return fail(LATOK_ERR_INVALID, "gate: broken by another party");
+        cpu_relax();
+        if ((spins & 1023) == 1023) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return fail(LATOK_ERR_INVALID, "gate: %d parties expected, not all arrived within %.1f s", gate->parties, timeout_s);
+            std::this_thread::yield();   // more host threads than cores (rehearsals): let the others arrive
+        }
+    }
+}
+
+static inline int64_t mono_ns() {
+    return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total,
+                                 uint64_t* mask_dev, int iters, latok_gate* gate, float* ms_events_out, int64_t* t0_ns_out,
+                                 int64_t* t1_ns_out) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (iters < 1) return fail(LATOK_ERR_INVALID, "iters must be >= 1");
+    if (((uintptr_t)cps_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    StreamTurn turn(g, nullptr);
+    hipStream_t st = turn.st;
+    if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = latok_gate_wait(gate, 120.0))) return rc;
+    const int64_t t0 = mono_ns();
+    HIP_TRY(hipEventRecord(g.ev[0], st));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) break;
+    if (!rc) {
+        hipError_t e = hipEventRecord(g.ev[1], st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(LATOK_ERR_HIP, "timed region failed: %s", hipGetErrorString(e));
+    }
+    const int64_t t1 = mono_ns();
+    const int rc_gate = latok_gate_wait(gate, 120.0);   // also on failure: the other threads must not wait for this one
+    if (rc) return rc;
+    if (rc_gate) return rc_gate;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
+    if (ms_events_out) *ms_events_out = ms;
+    if (t0_ns_out) *t0_ns_out = t0;
+    if (t1_ns_out) *t1_ns_out = t1;
     return LATOK_OK;
 }
 

@@ -58,9 +58,12 @@ __device__ __forceinline__ void signal_block_done(const DoneSignal& d) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned n = gridDim.x;
-        if (atomicAdd(d.counter, 1u) == n - 1u) {
+        // acq_rel at agent scope: the last workgroup's increment synchronises with every earlier workgroup's, so their
+        // (system-fenced) output stores happen-before the word store below -- not only by posted-write ordering
+        if (__hip_atomic_fetch_add(d.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == n - 1u) {
             *d.counter = 0u;
-            __hip_atomic_store(d.word, d.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(d.word, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }

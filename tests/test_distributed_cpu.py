@@ -92,3 +92,50 @@ def test_two_rank_gloo_sharding_and_reductions(oracle):
     row = np.zeros(1001, np.int64)
     lib.latok_corpus_offsets(seed, 0, 1000, lo, hi, row.ctypes.data)
     assert int(row[-1]) == tot0 and int(row[500]) == c0
+
+
+def _launcher_worker(rank, world, port, q, take_turns):
+    """what `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` does in each rank, with the device half
+    of the C ABI faked (tests/test_bench_launcher.py): bench.main's launcher branch end to end over gloo"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import io
+    import bench
+    from test_bench_launcher import FakeApi
+    api = FakeApi(n_dev=1)     # a launcher that narrows HIP_VISIBLE_DEVICES to one GPU per rank: LOCAL_RANK 1 -> device 0
+    out = io.StringIO()
+    argv = ["--gpus", str(world), "--steps", "4", "--warmup", "1", "--strings", "1500", "--no-cpu-baseline", "--sustain-s", "0"]
+    rc = bench.main(argv + (["--take-turns"] if take_turns else []), api=api, out=out)
+    q.put((rank, rc, out.getvalue(), [c.device for c in api.contexts], list(api.lib.fills), list(api.lib.timed)))
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("take_turns", [False, True])
+def test_two_rank_gloo_bench_main_under_a_launcher(take_turns):
+    import json
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_launcher_worker, args=(r, 2, port, q, take_turns)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, rc0, out0, dev0, fills0, timed0), (_, rc1, out1, dev1, fills1, timed1) = res
+    assert rc0 == rc1 == 0 and out1.strip() == ""          # ONE line, from rank 0
+    line = json.loads(out0)
+    assert dev0 == dev1 == [0]                              # LOCAL_RANK mod visible device count
+    assert fills0 == [(0, 0, 1500)] and fills1 == [(0, 1500, 1500)]
+    assert line["n_gpus"] == 2 and line["config"]["strings_total"] == 3000 and len(line["ms_per_rank"]) == 2
+    assert "launcher" in line["config"]["launch"]
+    (a0, b0), (a1, b1) = timed0[0][2:], timed1[0][2:]       # CLOCK_MONOTONIC is one clock for every process of the host
+    if take_turns:
+        assert b0 <= a1 or b1 <= a0
+        assert line["value"] is None and line["value_projected"] > 0
+    else:
+        assert line["value"] == pytest.approx(line["config"]["utf8_bytes_total"] * 4 / (max(b0 - a0, b1 - a1) / 1e9) / 1e9, rel=1e-6)

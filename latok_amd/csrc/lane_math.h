@@ -231,6 +231,41 @@ LATOK_HD lk_u64 lk_nl(lk_u64 X, lk_u64 Xn, lk_u64 m0, lk_u64 m1, lk_u64 m2) {
     return X | (m0 & ((X >> 1) | (Xn << 63))) | (m1 & ((X >> 2) | (Xn << 62))) | (m2 & ((X >> 3) | (Xn << 61)));
 }
 
+// Byte space, "smearing": a continuation byte carries the code of the char that owns it -- the nearest non-continuation
+// byte at most 3 positions back; a 4th continuation byte in a row (malformed input) carries nothing.  Phase 1 of the tile
+// kernel leaves codes at LEAD bytes only (0 at continuation bytes); the smear is mask arithmetic on the word's planes.
+//
+// lk_owner_before: the owner state in front of a word from the four lead-only code bytes before it (codes4: byte 3 =
+// position -1 .. byte 0 = position -4) and the continuation bits of positions -1, -2, -3:  *code = smeared code of byte
+// -1, *left = how many more continuation bytes that char may still take.
+LATOK_HD void lk_owner_before(uint32_t codes4, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* code, int* left) {
+    const uint32_t b1 = codes4 >> 24, b2 = (codes4 >> 16) & 0xFFu, b3 = (codes4 >> 8) & 0xFFu, b4 = codes4 & 0xFFu;
+    *code = !c1 ? b1 : (!c2 ? b2 : (!c3 ? b3 : b4));
+    *left = !c1 ? 3 : (!c2 ? 2 : (!c3 ? 1 : 0));
+}
+// lk_smear_planes: planes PLANES (bit b = plane b) of p, lead-only on entry, smeared on return.  C = continuation bits of
+// the word, (cin_code, cin_left) = owner state in front of it.
+template <unsigned PLANES>
+LATOK_HD void lk_smear_planes(lk_u64 p[8], lk_u64 C, uint32_t cin_code, int cin_left) {
+    // leading continuation bytes of the word that the entering char still takes
+    const lk_u64 nC = ~C;
+    const int run = nC ? lk_ctz(nC) : 64;
+    const int take = run < cin_left ? run : cin_left;              // 0..3
+    const lk_u64 in_mask = (1ull << take) - 1ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int b = 0; b < 8; ++b) {
+        if (!((PLANES >> b) & 1u)) continue;
+        lk_u64 x = p[b];                      // the leads inside the word reach at most 3 continuation bytes each
+        x |= (x << 1) & C;
+        x |= (x << 1) & C;
+        x |= (x << 1) & C;
+        // the entering char: only the word's leading continuation bytes (which no lead of the word reaches), `take` of them
+        p[b] = x | (((cin_code >> b) & 1u) ? in_mask : 0ull);
+    }
+}
+
 // p = bit-sliced SMEARED code planes of the word, C = its continuation bytes.  *Ss_out = smeared SPACE plane (a byte of
 // a SPACE char), which is what token stripping needs in byte space.
 LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {

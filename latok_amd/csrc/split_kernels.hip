@@ -235,25 +235,28 @@ __device__ __forceinline__ void build_latin1_tables(uint8_t* lds, const SplitPar
 // With write_summary the tile summary is written to *summ_l (LDS copy of the segment).
 // Returns this lane's 64-bit boundary word (kModeBits); with DEFER the caller stores it later (write combining).
 // ---------------------------------------------------------------------------------------------------------------
-// kModeBytes, phase 1: the tile is 4096 BYTES of UTF-8.  Every byte position of the staging buffer receives the split
-// code of the char that owns the byte (a lead byte and its <= 3 continuation bytes: "smeared" codes; stray
-// continuation bytes keep 0).  The continuation-byte bits of row r (64 positions) go into the row's 16 pad bytes
-// (offset 80 r + 64).  Halo: halo[0] = smeared code of byte t0-1, halo[3] = continuation bits of the 8 bytes after the
-// tile, halo[8..15] = their smeared codes.  An all-ASCII tile (the common case) is one table lookup per byte.
+// kModeBytes: the tile is 4096 BYTES of UTF-8; a char lives at its lead byte.  An all-ASCII tile (the common case) is one
+// table lookup per byte.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool u8_is_cont(uint32_t b) { return (b & 0xC0u) == 0x80u; }
 
-// code of the sequence that starts at byte J of the 19-byte window (meaningful when byte J is a lead byte)
-template <int J>
-__device__ __forceinline__ uint32_t bytes_code_at(const TileLds& L, const uint32_t (&w)[5]) {
-    return classify1(L.t1, L.t2, utf8_decode_at<J>(w));
+// Code point of the multi-byte sequence whose lead byte (>= 0xC0) is the LOW byte of W (W = 4 bytes in memory order).
+// Branch-free restatement of utf8_decode_at (utf8_decode.h): a truncated sequence yields U+FFFD, "surrogatepass" and
+// overlong forms decode as they are, 0xF8..0xFF count as 4-byte leads with 3 payload bits.
+__device__ __forceinline__ uint32_t utf8_cp_of(uint32_t W) {
+    const uint32_t b0 = W & 0xFFu;
+    const uint32_t X = (((W >> 8) & 0x3Fu) << 12) | (((W >> 16) & 0x3Fu) << 6) | ((W >> 24) & 0x3Fu);   // payload of bytes 1..3
+    // pure arithmetic on the sequence length n = 2, 3, 4 (selects between three forms end up as divergent control flow,
+    // and that serialises the table lookups of the slots of a row)
+    const uint32_t n = 2u + (uint32_t)(b0 >= 0xE0u) + (uint32_t)(b0 >= 0xF0u);
+    const uint32_t sh = 24u - 6u * n;                                   // payload bits of bytes 1..3 that are not used
+    const uint32_t cp = ((b0 & (0x7Fu >> n)) << (18u - sh)) | (X >> sh);
+    const uint32_t notc = (W ^ 0x80808000u) & 0xC0C0C000u;            // byte j != 0  <=>  byte j is not 10xxxxxx
+    const uint32_t need = (0xC0C0C000u >> (32u - 8u * n)) & 0xFFFFFF00u;
+    return (notc & need) ? 0xFFFDu : cp;
 }
-
-// The "owner" state after a run of bytes: the code of the last char and how many more continuation bytes it may take.
-struct ByteCarry {
-    uint32_t code;
-    int left;
-};
+// bit i = byte i of the dword has its top bit set (is not ASCII)
+__device__ __forceinline__ uint32_t u8_high_nibble(uint32_t w) { return ((((w >> 7) & 0x01010101u) * 0x00204081u) >> 21) & 0xFu; }
 
 // kModeLatin1 / kModeUcs2 (PEP 393 kinds 1 / 2: Latin-1 / UCS-2 code units), phase 1: the tile is 4096 CHARS of 1 or
 // 2 bytes each.  Nothing is decoded and there are no continuation bytes, so the staging buffer receives plain codes and
@@ -334,6 +337,23 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
     }
 }
 
+// kModeBytes, phase 1 (lane = 16 consecutive bytes per 1 KiB row).  What reaches the staging buffer: the split code of
+// its char at every LEAD byte (any non-continuation byte), 0 at continuation bytes; the continuation bits of row r in the
+// row's pad bytes.  Nothing is carried from lane to lane: the continuation bytes take their owner's code in phase 2, as
+// mask arithmetic on the word's planes (lane_math.h: lk_smear_planes).  An ASCII byte is one table lookup; only the
+// NON-ASCII LEAD bytes are decoded and classified through the two-stage table -- two slots per dword (well-formed UTF-8
+// has at most two multi-byte leads in 4 bytes), all eight slots of a row independent and branch-free so that their LDS
+// lookups overlap; a dword with more (malformed input) takes a wave-uniform loop afterwards.
+// Halo: halo[0] = code of the char that owns byte t0-1, halo[4] = how many more continuation bytes it may take,
+// halo[3] = continuation bits of the 8 bytes after the tile, halo[8..15] = their lead-only codes.
+// the window of slot (dword Q, lead mask m within the dword): its 4 bytes and where in the dword the lead sits
+template <int Q>
+__device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], uint32_t m, uint32_t* r_out) {
+    const uint32_t r = (uint32_t)__builtin_ctz(m | 0x10u) & 3u;      // m == 0: a dummy decode of byte 0, dropped later
+    *r_out = r;
+    return __builtin_amdgcn_alignbyte(w[Q + 1], w[Q], r);
+}
+
 __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
     const int64_t total = P.total;
     const uint8_t* __restrict__ u8 = P.u8;
@@ -353,11 +373,11 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
             v[i].x = d[0]; v[i].y = d[1]; v[i].z = d[2]; v[i].w = d[3];
         }
     }
-    // halo bytes: lane 0 looks at the 4 bytes before the tile, lanes 1..11 at the 11 bytes after it
+    // halo bytes: lane 0 holds the dword before the tile (t0 is a multiple of 4096 and u8 is 16-byte aligned; byte j of it
+    // = byte t0 - 4 + j), lanes 1..11 the 11 bytes after the tile (0 where the batch has ended)
     uint32_t hb = 0;
     if (lane == 0) {
-        // byte k-1 of hb = byte t0-k: the dword before the tile (t0 is a multiple of 4096, u8 is 16-byte aligned), byte-swapped
-        if (t0 > 0) hb = __builtin_bswap32(*reinterpret_cast<const uint32_t*>(u8 + t0 - 4));
+        if (t0 > 0) hb = *reinterpret_cast<const uint32_t*>(u8 + t0 - 4);
     } else if (lane < 12) {
         const int64_t q = t0 + kTile + (lane - 1);
         if (q < total) hb = u8[q];
@@ -370,137 +390,124 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
     const bool all_ascii = __all(hi_bits == 0u);
     wave_lds_sync();   // the zero stores are ordered before everything below
 
-    // the char that owns byte t0-1 (its lead is at most 3 bytes further back): halo[0], and the state that enters the tile
-    ByteCarry in0;
-    in0.code = 0;
-    in0.left = 0;
-    if (!all_ascii && lane == 0 && t0 > 0) {
-        int k = 1;                                                              // candidate lead at t0 - k
-        while (k < 4 && t0 - k > 0 && u8_is_cont((hb >> (8 * (k - 1))) & 0xFFu)) ++k;
-        const uint32_t b0 = (hb >> (8 * (k - 1))) & 0xFFu;
-        if (!u8_is_cont(b0)) {
-            uint32_t nb[3];
-            for (int j = 1; j <= 3; ++j) {
-                const int64_t q = t0 - k + j;
-                nb[j - 1] = q < total ? (uint32_t)u8[q] : 0xFFu;
-            }
-            const uint32_t code = classify1(L.t1, L.t2, utf8_decode_bytes(b0, nb[0], nb[1], nb[2]));
-            in0.code = code;
-            in0.left = 3 - (k - 1);                     // k-1 continuation bytes were already taken before the tile
-            L.halo[0] = (uint8_t)code;                  // byte t0-1 is the lead itself or one of those continuation bytes
-        }
-    } else if (all_ascii && lane == 0 && t0 > 0) {
-        L.halo[0] = L.t2[hb & 0xFFu];
-    }
-
     if (all_ascii) {
         // no multi-byte char in or around the tile (the common case): the RAW bytes go to the staging buffer and phase 2
         // classifies and bit-slices them with one table (slice_lut64), exactly like a Latin-1 tile
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(v[i].x, v[i].y, v[i].z, v[i].w);
+        if (lane == 0 && t0 > 0) L.halo[0] = L.t2[hb >> 24];
         if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.t2[hb & 0xFFu];
         return true;
     }
-    ByteCarry row_in = in0;                             // state entering lane 0 of the current row (wave-uniform use)
+
+    // The char that owns byte t0-1: its lead is byte t0-k, k = 1..4 (further back: nobody owns it).  The 8 bytes
+    // t0-4 .. t0+3 sit in lane 0's registers; every lane computes (no divergence), lane 0 stores.
+    {
+        const bool c1 = u8_is_cont(hb >> 24), c2 = u8_is_cont((hb >> 16) & 0xFFu), c3 = u8_is_cont((hb >> 8) & 0xFFu);
+        const uint32_t k = !c1 ? 1u : (!c2 ? 2u : (!c3 ? 3u : 4u));
+        const lk_u64 Z = (lk_u64)hb | ((lk_u64)v[0].x << 32);
+        const uint32_t W = (uint32_t)(Z >> (8u * (4u - k)));
+        const uint32_t b0 = W & 0xFFu;
+        const uint32_t code = classify1(L.t1, L.t2, b0 < 0x80u ? b0 : utf8_cp_of(W));
+        if (lane == 0 && t0 > 0 && !u8_is_cont(b0)) {
+            L.halo[0] = (uint8_t)code;
+            L.halo[4] = (uint8_t)(4u - k);
+        }
+    }
+
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-        if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {
-            // this 1 KiB row is pure ASCII (no char reaches into it or out of it): one lookup per byte
-            uint32_t cc[4];
+        // every byte as if it were ASCII: one lookup each in the stage-2 block of U+0000 (t1[0] == 0 by construction of the
+        // tables); the results at non-ASCII positions are cleared below
+        uint32_t out[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                cc[j] = (uint32_t)L.t2[d[j] & 0xFFu] | ((uint32_t)L.t2[(d[j] >> 8) & 0xFFu] << 8) |
-                        ((uint32_t)L.t2[(d[j] >> 16) & 0xFFu] << 16) | ((uint32_t)L.t2[d[j] >> 24] << 24);
-            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
-            row_in.code = 0;
-            row_in.left = 0;
+        for (int j = 0; j < 4; ++j)
+            out[j] = (uint32_t)L.t2[d[j] & 0x7Fu] | ((uint32_t)L.t2[(d[j] >> 8) & 0x7Fu] << 8) |
+                     ((uint32_t)L.t2[(d[j] >> 16) & 0x7Fu] << 16) | ((uint32_t)L.t2[(d[j] >> 24) & 0x7Fu] << 24);
+        const uint32_t st = stage_addr(1024u * i + 16u * lane);
+        if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {        // this 1 KiB row is pure ASCII
+            *reinterpret_cast<uint4*>(L.stage + st) = make_uint4(out[0], out[1], out[2], out[3]);
             continue;
         }
         // bytes 16..18 after my chunk: the next lane's first dword; lane 63: lane 0's next row, or the bytes after the tile
-        uint32_t nx = __shfl_down(d[0], 1);
-        const uint32_t wrap = __shfl(v[(i + 1) & 3].x, 0);
-        if (lane == 63) {
-            nx = wrap;
-            if (i == 3) {
-                nx = 0;
-                for (int j = 0; j < 3; ++j)
-                    if (t0 + kTile + j < total) nx |= (uint32_t)u8[t0 + kTile + j] << (8 * j);
-            }
+        uint32_t nx = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)d[0]);
+        {
+            const uint32_t wrap = i < 3 ? (uint32_t)lane_read((int)v[(i + 1) & 3].x, 0)
+                                        : ((uint32_t)lane_read((int)hb, 1) | ((uint32_t)lane_read((int)hb, 2) << 8) |
+                                           ((uint32_t)lane_read((int)hb, 3) << 16));
+            if (lane == 63) nx = wrap;
         }
-        const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx | 0xFF000000u};
-        const int64_t p0 = t0 + 1024 * i + 16 * lane;
-        const int64_t remain = total - p0;                                    // bytes that exist from p0 on
-        const uint32_t exist19 = remain >= 19 ? 0x7FFFFu : (remain <= 0 ? 0u : ((1u << remain) - 1u));
-        const uint32_t lead19 = utf8_lead_nibble(w[0]) | (utf8_lead_nibble(w[1]) << 4) | (utf8_lead_nibble(w[2]) << 8) |
-                                (utf8_lead_nibble(w[3]) << 12) | (utf8_lead_nibble(w[4]) << 16);
-        const uint32_t cont16 = ~lead19 & exist19 & 0xFFFFu;                   // bytes beyond the end are not continuations
-        // all 16 candidate codes at once (independent chains: the LDS lookups overlap)
-        uint32_t code[16];
-#define LATOK_BC(J) code[J] = bytes_code_at<J>(L, w);
-        LATOK_BC(0) LATOK_BC(1) LATOK_BC(2) LATOK_BC(3) LATOK_BC(4) LATOK_BC(5) LATOK_BC(6) LATOK_BC(7)
-        LATOK_BC(8) LATOK_BC(9) LATOK_BC(10) LATOK_BC(11) LATOK_BC(12) LATOK_BC(13) LATOK_BC(14) LATOK_BC(15)
-#undef LATOK_BC
-        // owner scan over my 16 bytes from the empty state; the state after 16 bytes does not depend on what entered
-        uint32_t cur = 0;
-        int left = 0;
-        uint32_t out[4] = {0, 0, 0, 0};
+        const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx};
+        const int64_t remain = total - (t0 + 1024 * i + 16 * lane);            // bytes that exist from my chunk on
+        const uint32_t exist16 = remain >= 16 ? 0xFFFFu : (remain <= 0 ? 0u : ((1u << remain) - 1u));
+        const uint32_t lead16 = utf8_lead_nibble(d[0]) | (utf8_lead_nibble(d[1]) << 4) | (utf8_lead_nibble(d[2]) << 8) |
+                                (utf8_lead_nibble(d[3]) << 12);
+        const uint32_t cont16 = ~lead16 & exist16;                              // bytes beyond the end are not continuations
+        const uint32_t nl16 = lead16 & (u8_high_nibble(d[0]) | (u8_high_nibble(d[1]) << 4) | (u8_high_nibble(d[2]) << 8) |
+                                        (u8_high_nibble(d[3]) << 12));          // the leads that need a decode
+        uint32_t rest = 0;                                                      // leads beyond two per dword (malformed input)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const bool is_c = (cont16 >> k) & 1u;
-            const bool keep = is_c && left > 0;
-            cur = is_c ? (keep ? cur : 0u) : code[k];
-            left = is_c ? (keep ? left - 1 : 0) : 3;
-            out[k >> 2] |= cur << (8 * (k & 3));
+        for (int q = 0; q < 4; ++q) out[q] &= ~(((d[q] >> 7) & 0x01010101u) * 0xFFu);   // non-ASCII positions: 0
+        {
+            uint32_t m[4], m2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                m[q] = (nl16 >> (4 * q)) & 0xFu;
+                m2[q] = m[q] & (m[q] - 1u);
+                rest |= (m2[q] & (m2[q] - 1u)) << (4 * q);
+            }
+            // stage by stage over the eight slots, so that the 8 + 8 table lookups are in flight together
+            uint32_t r[8], cp[8], blk[8], code[8];
+            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, m[0], &r[0]));
+            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, m[1], &r[1]));
+            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, m[2], &r[2]));
+            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, m[3], &r[3]));
+            cp[4] = utf8_cp_of(bytes_slot_window<0>(w, m2[0], &r[4]));
+            cp[5] = utf8_cp_of(bytes_slot_window<1>(w, m2[1], &r[5]));
+            cp[6] = utf8_cp_of(bytes_slot_window<2>(w, m2[2], &r[6]));
+            cp[7] = utf8_cp_of(bytes_slot_window<3>(w, m2[3], &r[7]));
+#pragma unroll
+            for (int s = 0; s < 8; ++s) blk[s] = L.t1[min(cp[s] >> kTblShift, (uint32_t)(kStage1Len - 1))];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) code[s] = L.t2[(blk[s] << kTblShift) | (cp[s] & ((1u << kTblShift) - 1u))];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) out[s & 3] |= ((s < 4 ? m[s & 3] : m2[s & 3]) ? code[s] : 0u) << (8u * r[s]);
         }
-        // what enters my chunk: the previous lane's final state (lane 0: the previous row's lane 63 / the tile's entry)
-        ByteCarry cin;
-        cin.code = __shfl_up(cur, 1);
-        cin.left = __shfl_up(left, 1);
-        if (lane == 0) cin = row_in;
-        {   // leading continuation bytes of my chunk belong to that char
-            const uint32_t lead_run = cont16 & 1u ? ((cont16 & 3u) == 3u ? ((cont16 & 7u) == 7u ? 3u : 2u) : 1u) : 0u;
-            const uint32_t take = min(lead_run, (uint32_t)max(cin.left, 0));
-            const uint32_t m = take == 0u ? 0u : (take == 1u ? 0xFFu : (take == 2u ? 0xFFFFu : 0xFFFFFFu));
-            out[0] = (out[0] & ~m) | ((cin.code * 0x010101u) & m);
+        while (__any(rest != 0u)) {                                             // wave-uniform; never taken on well-formed UTF-8
+            const uint32_t k = (uint32_t)__builtin_ctz(rest | 0x10000u) & 15u, q = k >> 2, r = k & 3u;
+            const uint32_t lo = q == 0u ? w[0] : (q == 1u ? w[1] : (q == 2u ? w[2] : w[3]));
+            const uint32_t hi = q == 0u ? w[1] : (q == 1u ? w[2] : (q == 2u ? w[3] : w[4]));
+            const uint32_t code = classify1(L.t1, L.t2, utf8_cp_of(__builtin_amdgcn_alignbyte(hi, lo, r)));
+            const uint32_t ins = (rest ? code : 0u) << (8u * r);
+            out[0] |= q == 0u ? ins : 0u;
+            out[1] |= q == 1u ? ins : 0u;
+            out[2] |= q == 2u ? ins : 0u;
+            out[3] |= q == 3u ? ins : 0u;
+            rest &= rest - 1u;
         }
-        *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<uint4*>(L.stage + st) = make_uint4(out[0], out[1], out[2], out[3]);
         // continuation bits of my 16 positions -> pad of row (16 i + lane / 4), 16-bit slot (lane % 4)
         *reinterpret_cast<uint16_t*>(L.stage + 80u * (16u * i + ((uint32_t)lane >> 2)) + 64u + 2u * ((uint32_t)lane & 3u)) =
             (uint16_t)cont16;
-        row_in.code = __shfl(cur, 63);
-        row_in.left = __shfl(left, 63);
     }
-    // the 8 bytes after the tile: smeared codes into halo[8..15], continuation bits into halo[3].  Lane k+1 owns byte k.
+    // the 8 bytes after the tile: lead-only codes into halo[8..15], continuation bits into halo[3].  Lane k+1 owns byte k.
     {
         const int k = lane - 1;
         const int64_t q0 = t0 + kTile + k;
         const bool in_win = lane >= 1 && lane < 9 && q0 < total;
         const bool is_c = in_win && u8_is_cont(hb & 0xFFu);
         const lk_u64 cm = __ballot(is_c);
-        const uint32_t cbits = (uint32_t)((cm >> 1) & 0xFFull);
-        if (lane == 1) L.halo[3] = (uint8_t)cbits;
-        const uint32_t b1 = (uint32_t)__shfl_down(hb, 1), b2 = (uint32_t)__shfl_down(hb, 2), b3 = (uint32_t)__shfl_down(hb, 3);
-        const uint32_t e1 = q0 + 1 < total ? (b1 & 0xFFu) : 0xFFu, e2 = q0 + 2 < total ? (b2 & 0xFFu) : 0xFFu,
-                       e3 = q0 + 3 < total ? (b3 & 0xFFu) : 0xFFu;
-        const uint32_t my_code = classify1(L.t1, L.t2, utf8_decode_bytes(hb & 0xFFu, e1, e2, e3));
-        // owner of byte k: the nearest lead at k, k-1, k-2, k-3 inside the window, else the char that leaves the tile
-        uint32_t own = 0;
-        const uint32_t c1 = (uint32_t)__shfl_up(my_code, 1), c2 = (uint32_t)__shfl_up(my_code, 2), c3 = (uint32_t)__shfl_up(my_code, 3);
-        if (in_win) {
-            if (!is_c) {
-                own = my_code;
-            } else {
-                // run of continuation bytes that ends at k, limited to 3
-                const bool p1c = k >= 1 && ((cbits >> (k - 1)) & 1u), p2c = k >= 2 && ((cbits >> (k - 2)) & 1u);
-                if (k >= 1 && !p1c) own = c1;
-                else if (k >= 2 && p1c && !p2c) own = c2;
-                else if (k >= 3 && p1c && p2c && !((cbits >> (k - 3)) & 1u)) own = c3;
-                else if (k < row_in.left && (k == 0 || (p1c && (k == 1 || p2c)))) own = row_in.code;   // all bytes before k are continuations
-            }
-            L.halo[8 + k] = (uint8_t)own;
-        }
+        if (lane == 1) L.halo[3] = (uint8_t)((cm >> 1) & 0xFFull);
+        // the 3 bytes after mine (lanes 2..11 hold them; 0 = "no such byte", which is not a continuation byte)
+        const uint32_t b1 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)hb) & 0xFFu;
+        const uint32_t b2 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)b1) & 0xFFu;
+        const uint32_t b3 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)b2) & 0xFFu;
+        const uint32_t W = (hb & 0xFFu) | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        const uint32_t b0 = W & 0xFFu;
+        const uint32_t my_code = classify1(L.t1, L.t2, b0 < 0x80u ? b0 : utf8_cp_of(W));
+        if (in_win) L.halo[8 + k] = (uint8_t)(is_c ? 0u : my_code);
     }
     return false;
 }
@@ -619,6 +626,22 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 loc = lk_rules(lk_decode(plane), ha, B, Bn);
                 space_plane = loc.S;
             } else {
+                // codes sit at lead bytes only: give the continuation bytes their owner's code in the planes the PREV_*
+                // columns and the token stripping read (SPACE, SYMBOL, LOWER, ALPHA_NUM, ALPHA = bits 0, 1, 2, 4, 5).  What
+                // enters the word: the last four code bytes and continuation bits of the row before (lane 0: the halo)
+                uint32_t own_code;
+                int own_left;
+                {
+                    const uint32_t codes4 = lane > 0 ? *reinterpret_cast<const uint32_t*>(L.stage + 80u * lane - 20u) : 0u;
+                    const uint32_t ctop = lane > 0 ? (uint32_t)L.stage[80u * lane - 9u] : 0u;    // bits 56..63 of the row's C word
+                    lk_owner_before(codes4, (ctop >> 7) & 1u, (ctop >> 6) & 1u, (ctop >> 5) & 1u, &own_code, &own_left);
+                    if (lane == 0) {
+                        own_code = L.halo[0];
+                        own_left = L.halo[4];
+                    }
+                }
+                lk_smear_planes<0x37u>(plane, C, own_code, own_left);
+                hb.prev = own_code;
                 loc = lk_rules_bytes(plane, C, hb, B, &space_plane);
             }
         } else if (MODE == kModeRules) {

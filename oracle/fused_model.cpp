@@ -8,6 +8,7 @@
 //
 //   g++ -O2 -shared -fPIC -I../latok_amd/csrc fused_model.cpp -o libfused_model.so
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -88,8 +89,10 @@ struct Model {
         }
         return classify(cp);
     }
+    // byte mode, what phase 1 of the tile kernel leaves in the staging buffer: the code at LEAD bytes, 0 at continuation bytes
+    uint32_t lead_code_at(int64_t p) const { return cont_at(p) ? 0u : byte_code_at(p); }
     uint32_t code_at(int64_t p) const {
-        if (u8) return byte_code_at(p);
+        if (u8) return lead_code_at(p);
         return (cps && p >= 0 && p < total) ? classify(cps[p], rules != nullptr) : 0u;
     }
 
@@ -141,8 +144,14 @@ struct Model {
                 loc[j] = lk_local();
                 loc[j].start = st; loc[j].S = sp; loc[j].raw = ~0ull; loc[j].sym = 0;
             } else if (u8) {
+                // the tile kernel's phase 2 in byte space: lead-only codes in, the planes the PREV_* columns and the token
+                // stripping need are smeared over the continuation bytes by mask arithmetic (lane_math.h)
                 lk_halo_bytes hb;
-                hb.prev = code_at(base - 1);
+                uint32_t codes4 = 0;
+                for (int k = 1; k <= 4; ++k) codes4 |= lead_code_at(base - k) << (8 * (4 - k));
+                int cin_left = 0;
+                lk_owner_before(codes4, cont_at(base - 1), cont_at(base - 2), cont_at(base - 3), &hb.prev, &cin_left);
+                if (hb.prev != byte_code_at(base - 1)) abort();   // the owner state agrees with the per-byte definition
                 hb.next_codes = 0;
                 hb.next_cont = 0;
                 for (int k = 0; k < 8; ++k) {
@@ -152,6 +161,10 @@ struct Model {
                 hb.next_B = (uint32_t)(Bw[j + 1] & 0xFFFFull);
                 lk_u64 C = 0, Ss = 0;
                 for (int i = 0; i < 64; ++i) C |= (lk_u64)cont_at(base + i) << i;
+                lk_smear_planes<0x37u>(plane, C, hb.prev, cin_left);
+                for (int i = 0; i < 64; ++i)   // smeared planes == per-byte definition
+                    for (int b = 0; b < 8; ++b)
+                        if (((0x37u >> b) & 1u) && ((plane[b] >> i) & 1ull) != ((byte_code_at(base + i) >> b) & 1u)) abort();
                 loc[j] = lk_rules_bytes(plane, C, hb, Bw[j], &Ss);
                 if (space_bits && base < total) {
                     const int64_t remain = total - base;

@@ -146,3 +146,27 @@ def test_model_utf8_byte_space(model, oracle):
         gsp = np.unpackbits(sp.view(np.uint8), bitorder="little")[:total].astype(bool)
         assert np.array_equal(got, flags), (it, texts if total < 200 else total)
         assert np.array_equal(gsp, space), (it, "space plane")
+
+
+def test_model_smear_arithmetic_on_malformed_utf8(model):
+    """lane_math.h lk_owner_before / lk_smear_planes (the tile kernel's phase 2 in byte space: codes at lead bytes only, the
+    continuation bytes filled by mask arithmetic) against the per-byte definition "owner = nearest non-continuation byte at
+    most 3 back" on RANDOM bytes: runs of > 3 continuation bytes, truncated sequences, lone leads, 0xF8..0xFF, at every
+    word and tile phase.  The model checks both forms against each other internally and aborts on a difference."""
+    model.fused_split_batch_utf8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    pools = [np.arange(256, dtype=np.uint8),
+             np.array([0x20, 0x61, 0x80, 0x80, 0xBF, 0xC3, 0xE3, 0xF0, 0xFF, 0x2E, 0x40], np.uint8),
+             np.array([0x80, 0x81, 0xE3, 0x61], np.uint8)]
+    for it in range(60):
+        n_str = int(rng.integers(1, 40))
+        lens = rng.integers(0, [20, 300, 9000][it % 3], n_str)
+        boff = np.zeros(n_str + 1, np.int64)
+        np.cumsum(lens, out=boff[1:])
+        total = int(boff[-1])
+        if total == 0:
+            continue
+        u8 = np.ascontiguousarray(rng.choice(pools[it % len(pools)], total))
+        bits = np.zeros((total + 63) // 64, np.uint64)
+        sp = np.zeros_like(bits)
+        assert model.fused_split_batch_utf8(u8.ctypes.data, boff.ctypes.data, n_str, bits.ctypes.data, sp.ctypes.data, None) == 0

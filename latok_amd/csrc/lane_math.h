@@ -221,8 +221,8 @@ LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
 // ---------------------------------------------------------------------------------------------------------------
 struct lk_halo_bytes {
     uint32_t prev;         // smeared code of byte base-1 (0 when it does not exist)
-    lk_u64 next_codes;     // smeared codes of bytes base+64 .. base+71 (byte k of the word = byte base+64+k)
-    uint32_t next_cont;    // bit k: byte base+64+k is a continuation byte
+    lk_u64 next_codes;     // staging bytes of bytes base+64 .. base+71 (byte k of the word = byte base+64+k): the code at a lead
+                           // byte, LK_CODE_CONT at a continuation byte
     uint32_t next_B;       // bit k: a string starts at byte base+64+k (k = 0..15)
 };
 
@@ -235,12 +235,20 @@ LATOK_HD lk_u64 lk_nl(lk_u64 X, lk_u64 Xn, lk_u64 m0, lk_u64 m1, lk_u64 m2) {
 // byte at most 3 positions back; a 4th continuation byte in a row (malformed input) carries nothing.  Phase 1 of the tile
 // kernel leaves codes at LEAD bytes only (0 at continuation bytes); the smear is mask arithmetic on the word's planes.
 //
-// lk_owner_before: the owner state in front of a word from the four lead-only code bytes before it (codes4: byte 3 =
-// position -1 .. byte 0 = position -4) and the continuation bits of positions -1, -2, -3:  *code = smeared code of byte
-// -1, *left = how many more continuation bytes that char may still take.
-LATOK_HD void lk_owner_before(uint32_t codes4, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* code, int* left) {
+// lk_take_cont_plane: the continuation bytes of the word from the bit-sliced staging bytes (LK_CODE_CONT); the planes are
+// left with the lead-only codes.
+LATOK_HD lk_u64 lk_take_cont_plane(lk_u64 p[8]) {
+    const lk_u64 C = p[7] & ~p[LK_BIT_SYMBOL];
+    p[7] &= ~C;
+    return C;
+}
+// lk_owner_before: the owner state in front of a word from the four staging bytes before it (codes4: byte 3 = position -1
+// .. byte 0 = position -4; LK_CODE_CONT at continuation bytes):  *code = smeared code of byte -1, *left = how many more
+// continuation bytes that char may still take.
+LATOK_HD void lk_owner_before(uint32_t codes4, uint32_t* code, int* left) {
     const uint32_t b1 = codes4 >> 24, b2 = (codes4 >> 16) & 0xFFu, b3 = (codes4 >> 8) & 0xFFu, b4 = codes4 & 0xFFu;
-    *code = !c1 ? b1 : (!c2 ? b2 : (!c3 ? b3 : b4));
+    const bool c1 = b1 == LK_CODE_CONT, c2 = b2 == LK_CODE_CONT, c3 = b3 == LK_CODE_CONT, c4 = b4 == LK_CODE_CONT;
+    *code = !c1 ? b1 : (!c2 ? b2 : (!c3 ? b3 : (!c4 ? b4 : 0u)));
     *left = !c1 ? 3 : (!c2 ? 2 : (!c3 ? 1 : 0));
 }
 // lk_smear_planes: planes PLANES (bit b = plane b) of p, lead-only on entry, smeared on return.  C = continuation bits of
@@ -272,8 +280,8 @@ LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, l
     const lk_feat fs = lk_decode(p);                 // smeared features
     const lk_u64 Lead = ~C;
     // the next 8 byte positions as a mini word (only its low bits matter)
-    const lk_u64 Cn = (lk_u64)(h.next_cont & 0xFFu);
     const lk_u64 Tn = lk_transpose8(h.next_codes);
+    const lk_u64 Cn = (Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull;      // LK_CODE_CONT: bit 7 without SYMBOL
     const lk_u64 Ln = ~Cn & 0xFFull;
 #define LK_PN(b) ((Tn >> (8 * (b))) & 0xFFull)
     const lk_u64 Sn = LK_PN(0) & Ln, Lwn = LK_PN(2) & Ln, ANn = LK_PN(4) & Ln, An = LK_PN(5) & ~LK_PN(1) & Ln,

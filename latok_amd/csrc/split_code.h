@@ -21,6 +21,10 @@
 #define LK_BIT_UPPER 3
 #define LK_BIT_ALNUM 4
 
+// Byte space (UTF-8 input): the staging byte of a CONTINUATION byte holds this marker -- bit 7 without SYMBOL, which no
+// split code and no rule code has -- so that the continuation plane of a word falls out of the bit-slicing (plane 7 & ~plane 1)
+#define LK_CODE_CONT 0x80u
+
 // Rule code (runtime rule tables): the split code with NUM added in bit 6 for non-symbols, so that all 12 base
 // features can be decoded from the byte (tools/gen_unicode_tables.py:rule_code, lane_math.h:lk_feature_planes).
 // Runtime rule tables: each row of C_SPLIT / C_MASK / C_SYM is the SET of feature columns it multiplies

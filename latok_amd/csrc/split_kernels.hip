@@ -338,18 +338,20 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
 }
 
 // kModeBytes, phase 1 (lane = 16 consecutive bytes per 1 KiB row).  What reaches the staging buffer: the split code of
-// its char at every LEAD byte (any non-continuation byte), 0 at continuation bytes; the continuation bits of row r in the
-// row's pad bytes.  Nothing is carried from lane to lane: the continuation bytes take their owner's code in phase 2, as
+// its char at every LEAD byte (any non-continuation byte), the marker LK_CODE_CONT at continuation bytes (the continuation
+// plane of a word then falls out of phase 2's bit-slicing).  Nothing is carried from lane to lane: the continuation bytes take their owner's code in phase 2, as
 // mask arithmetic on the word's planes (lane_math.h: lk_smear_planes).  An ASCII byte is one table lookup; only the
 // NON-ASCII LEAD bytes are decoded and classified through the two-stage table -- two slots per dword (well-formed UTF-8
 // has at most two multi-byte leads in 4 bytes), all eight slots of a row independent and branch-free so that their LDS
 // lookups overlap; a dword with more (malformed input) takes a wave-uniform loop afterwards.
 // Halo: halo[0] = code of the char that owns byte t0-1, halo[4] = how many more continuation bytes it may take,
-// halo[3] = continuation bits of the 8 bytes after the tile, halo[8..15] = their lead-only codes.
+// halo[8..15] = staging bytes of the 8 bytes after the tile.
 // the window of slot (dword Q, lead mask m within the dword): its 4 bytes and where in the dword the lead sits
+// the window of a slot of dword Q: m = lead mask within the dword in "bit 7 of the byte" form; the slot takes its lowest
+// lead: *r_out = which byte of the dword, returns the 4 bytes from there on
 template <int Q>
 __device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], uint32_t m, uint32_t* r_out) {
-    const uint32_t r = (uint32_t)__builtin_ctz(m | 0x10u) & 3u;      // m == 0: a dummy decode of byte 0, dropped later
+    const uint32_t r = ((uint32_t)__builtin_ctz(m | 0x80000000u) >> 3) & 3u;   // m == 0: a dummy decode, dropped by the caller
     *r_out = r;
     return __builtin_amdgcn_alignbyte(w[Q + 1], w[Q], r);
 }
@@ -385,7 +387,6 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
     uint32_t hi_bits = hb & 0x80808080u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) hi_bits |= (v[i].x | v[i].y | v[i].z | v[i].w) & 0x80808080u;
-    *reinterpret_cast<lk_u64*>(L.stage + 80u * lane + 64u) = 0ull;              // continuation bits of row `lane`
     if (lane < 2) *reinterpret_cast<lk_u64*>(L.halo + 8u * lane) = 0ull;
     const bool all_ascii = __all(hi_bits == 0u);
     wave_lds_sync();   // the zero stores are ordered before everything below
@@ -440,30 +441,26 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
             if (lane == 63) nx = wrap;
         }
         const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx};
-        const int64_t remain = total - (t0 + 1024 * i + 16 * lane);            // bytes that exist from my chunk on
-        const uint32_t exist16 = remain >= 16 ? 0xFFFFu : (remain <= 0 ? 0u : ((1u << remain) - 1u));
-        const uint32_t lead16 = utf8_lead_nibble(d[0]) | (utf8_lead_nibble(d[1]) << 4) | (utf8_lead_nibble(d[2]) << 8) |
-                                (utf8_lead_nibble(d[3]) << 12);
-        const uint32_t cont16 = ~lead16 & exist16;                              // bytes beyond the end are not continuations
-        const uint32_t nl16 = lead16 & (u8_high_nibble(d[0]) | (u8_high_nibble(d[1]) << 4) | (u8_high_nibble(d[2]) << 8) |
-                                        (u8_high_nibble(d[3]) << 12));          // the leads that need a decode
-        uint32_t rest = 0;                                                      // leads beyond two per dword (malformed input)
+        // Per dword, all masks in "bit 7 of the byte" form (no bit gathering): hi = not ASCII, cont = 10xxxxxx, nl = the
+        // leads that need a decode.  (Bytes past the end of the batch were loaded as 0: ASCII, never a continuation.)
+        uint32_t m1[4], m2[4], rest[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[q] &= ~(((d[q] >> 7) & 0x01010101u) * 0xFFu);   // non-ASCII positions: 0
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t hi = d[q] & 0x80808080u;
+            const uint32_t cont = hi & ~(d[q] << 1);
+            const uint32_t ff = hi | (hi - (hi >> 7));                          // 0xFF at the non-ASCII bytes
+            out[q] = (out[q] & ~ff) | cont;                                     // ASCII codes | LK_CODE_CONT at continuation bytes
+            m1[q] = hi ^ cont;
+            m2[q] = m1[q] & (m1[q] - 1u);
+            rest[q] = m2[q] & (m2[q] - 1u);                                     // leads beyond two per dword (malformed input)
+        }
         {
-            uint32_t m[4], m2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                m[q] = (nl16 >> (4 * q)) & 0xFu;
-                m2[q] = m[q] & (m[q] - 1u);
-                rest |= (m2[q] & (m2[q] - 1u)) << (4 * q);
-            }
             // stage by stage over the eight slots, so that the 8 + 8 table lookups are in flight together
             uint32_t r[8], cp[8], blk[8], code[8];
-            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, m[0], &r[0]));
-            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, m[1], &r[1]));
-            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, m[2], &r[2]));
-            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, m[3], &r[3]));
+            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, m1[0], &r[0]));
+            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, m1[1], &r[1]));
+            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, m1[2], &r[2]));
+            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, m1[3], &r[3]));
             cp[4] = utf8_cp_of(bytes_slot_window<0>(w, m2[0], &r[4]));
             cp[5] = utf8_cp_of(bytes_slot_window<1>(w, m2[1], &r[5]));
             cp[6] = utf8_cp_of(bytes_slot_window<2>(w, m2[2], &r[6]));
@@ -473,33 +470,27 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
 #pragma unroll
             for (int s = 0; s < 8; ++s) code[s] = L.t2[(blk[s] << kTblShift) | (cp[s] & ((1u << kTblShift) - 1u))];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) out[s & 3] |= ((s < 4 ? m[s & 3] : m2[s & 3]) ? code[s] : 0u) << (8u * r[s]);
+            for (int s = 0; s < 8; ++s) out[s & 3] |= ((s < 4 ? m1[s & 3] : m2[s & 3]) ? code[s] : 0u) << (8u * r[s]);
         }
-        while (__any(rest != 0u)) {                                             // wave-uniform; never taken on well-formed UTF-8
-            const uint32_t k = (uint32_t)__builtin_ctz(rest | 0x10000u) & 15u, q = k >> 2, r = k & 3u;
-            const uint32_t lo = q == 0u ? w[0] : (q == 1u ? w[1] : (q == 2u ? w[2] : w[3]));
-            const uint32_t hi = q == 0u ? w[1] : (q == 1u ? w[2] : (q == 2u ? w[3] : w[4]));
-            const uint32_t code = classify1(L.t1, L.t2, utf8_cp_of(__builtin_amdgcn_alignbyte(hi, lo, r)));
-            const uint32_t ins = (rest ? code : 0u) << (8u * r);
-            out[0] |= q == 0u ? ins : 0u;
-            out[1] |= q == 1u ? ins : 0u;
-            out[2] |= q == 2u ? ins : 0u;
-            out[3] |= q == 3u ? ins : 0u;
-            rest &= rest - 1u;
+        while (__any((rest[0] | rest[1] | rest[2] | rest[3]) != 0u)) {          // wave-uniform; never taken on well-formed UTF-8
+            uint32_t r[4], cp[4];
+            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, rest[0], &r[0]));
+            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, rest[1], &r[1]));
+            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, rest[2], &r[2]));
+            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, rest[3], &r[3]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                out[q] |= (rest[q] ? classify1(L.t1, L.t2, cp[q]) : 0u) << (8u * r[q]);
+                rest[q] &= rest[q] - 1u;
+            }
         }
         *reinterpret_cast<uint4*>(L.stage + st) = make_uint4(out[0], out[1], out[2], out[3]);
-        // continuation bits of my 16 positions -> pad of row (16 i + lane / 4), 16-bit slot (lane % 4)
-        *reinterpret_cast<uint16_t*>(L.stage + 80u * (16u * i + ((uint32_t)lane >> 2)) + 64u + 2u * ((uint32_t)lane & 3u)) =
-            (uint16_t)cont16;
     }
-    // the 8 bytes after the tile: lead-only codes into halo[8..15], continuation bits into halo[3].  Lane k+1 owns byte k.
+    // the 8 bytes after the tile -> halo[8..15] as staging bytes (code at a lead, LK_CODE_CONT at a continuation byte).
+    // Lane k+1 owns byte k.
     {
         const int k = lane - 1;
-        const int64_t q0 = t0 + kTile + k;
-        const bool in_win = lane >= 1 && lane < 9 && q0 < total;
-        const bool is_c = in_win && u8_is_cont(hb & 0xFFu);
-        const lk_u64 cm = __ballot(is_c);
-        if (lane == 1) L.halo[3] = (uint8_t)((cm >> 1) & 0xFFull);
+        const bool in_win = lane >= 1 && lane < 9 && t0 + kTile + k < total;
         // the 3 bytes after mine (lanes 2..11 hold them; 0 = "no such byte", which is not a continuation byte)
         const uint32_t b1 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)hb) & 0xFFu;
         const uint32_t b2 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)b1) & 0xFFu;
@@ -507,7 +498,7 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         const uint32_t W = (hb & 0xFFu) | (b1 << 8) | (b2 << 16) | (b3 << 24);
         const uint32_t b0 = W & 0xFFu;
         const uint32_t my_code = classify1(L.t1, L.t2, b0 < 0x80u ? b0 : utf8_cp_of(W));
-        if (in_win) L.halo[8 + k] = (uint8_t)(is_c ? 0u : my_code);
+        if (in_win) L.halo[8 + k] = (uint8_t)(u8_is_cont(b0) ? LK_CODE_CONT : my_code);
     }
     return false;
 }
@@ -608,15 +599,20 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             loc = lk_rules(lk_decode(plane), ha, B, Bn);
             space_plane = loc.S;
         } else if (MODE == kModeBytes) {
-            // byte space: continuation bits of my row / of the 8 bytes after it, smeared codes of those 8 bytes
-            const lk_u64 C = *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 64u);
+            // byte space: the continuation bytes carry LK_CODE_CONT -> continuation plane of my word; the staging bytes of the
+            // 8 bytes after my row
+            const lk_u64 C = lk_take_cont_plane(plane);
             lk_halo_bytes hb;
             hb.prev = h.prev;
             hb.next_codes = lane < 63 ? *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 80u)
                                       : *reinterpret_cast<const lk_u64*>(L.halo + 8);
-            hb.next_cont = lane < 63 ? (uint32_t)L.stage[80u * lane + 80u + 64u] : (uint32_t)L.halo[3];
             hb.next_B = (uint32_t)(L.bw[lane + 1] & 0xFFFFull);
-            no_patch = __ballot(C != 0ull || hb.next_cont != 0u) != 0ull;
+            bool next_has_cont;
+            {   // a byte of next_codes equals LK_CODE_CONT
+                const lk_u64 y = hb.next_codes ^ 0x8080808080808080ull;
+                next_has_cont = (~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y) & 0x8080808080808080ull) != 0ull;
+            }
+            no_patch = __ballot(C != 0ull || next_has_cont) != 0ull;
             if (!no_patch) {
                 // no multi-byte char in or right after the tile: positions are chars, the plain rules apply
                 lk_halo ha;
@@ -628,17 +624,13 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             } else {
                 // codes sit at lead bytes only: give the continuation bytes their owner's code in the planes the PREV_*
                 // columns and the token stripping read (SPACE, SYMBOL, LOWER, ALPHA_NUM, ALPHA = bits 0, 1, 2, 4, 5).  What
-                // enters the word: the last four code bytes and continuation bits of the row before (lane 0: the halo)
+                // enters the word: the last four staging bytes of the row before (lane 0: the halo)
                 uint32_t own_code;
                 int own_left;
-                {
-                    const uint32_t codes4 = lane > 0 ? *reinterpret_cast<const uint32_t*>(L.stage + 80u * lane - 20u) : 0u;
-                    const uint32_t ctop = lane > 0 ? (uint32_t)L.stage[80u * lane - 9u] : 0u;    // bits 56..63 of the row's C word
-                    lk_owner_before(codes4, (ctop >> 7) & 1u, (ctop >> 6) & 1u, (ctop >> 5) & 1u, &own_code, &own_left);
-                    if (lane == 0) {
-                        own_code = L.halo[0];
-                        own_left = L.halo[4];
-                    }
+                lk_owner_before(lane > 0 ? *reinterpret_cast<const uint32_t*>(L.stage + 80u * lane - 20u) : 0u, &own_code, &own_left);
+                if (lane == 0) {
+                    own_code = L.halo[0];
+                    own_left = L.halo[4];
                 }
                 lk_smear_planes<0x37u>(plane, C, own_code, own_left);
                 hb.prev = own_code;

@@ -90,7 +90,7 @@ struct Model {
         return classify(cp);
     }
     // byte mode, what phase 1 of the tile kernel leaves in the staging buffer: the code at LEAD bytes, 0 at continuation bytes
-    uint32_t lead_code_at(int64_t p) const { return cont_at(p) ? 0u : byte_code_at(p); }
+    uint32_t lead_code_at(int64_t p) const { return cont_at(p) ? LK_CODE_CONT : byte_code_at(p); }
     uint32_t code_at(int64_t p) const {
         if (u8) return lead_code_at(p);
         return (cps && p >= 0 && p < total) ? classify(cps[p], rules != nullptr) : 0u;
@@ -150,17 +150,15 @@ struct Model {
                 uint32_t codes4 = 0;
                 for (int k = 1; k <= 4; ++k) codes4 |= lead_code_at(base - k) << (8 * (4 - k));
                 int cin_left = 0;
-                lk_owner_before(codes4, cont_at(base - 1), cont_at(base - 2), cont_at(base - 3), &hb.prev, &cin_left);
+                lk_owner_before(codes4, &hb.prev, &cin_left);
                 if (hb.prev != byte_code_at(base - 1)) abort();   // the owner state agrees with the per-byte definition
                 hb.next_codes = 0;
-                hb.next_cont = 0;
-                for (int k = 0; k < 8; ++k) {
-                    hb.next_codes |= (lk_u64)code_at(base + 64 + k) << (8 * k);
-                    hb.next_cont |= (uint32_t)cont_at(base + 64 + k) << k;
-                }
+                for (int k = 0; k < 8; ++k) hb.next_codes |= (lk_u64)code_at(base + 64 + k) << (8 * k);
                 hb.next_B = (uint32_t)(Bw[j + 1] & 0xFFFFull);
-                lk_u64 C = 0, Ss = 0;
-                for (int i = 0; i < 64; ++i) C |= (lk_u64)cont_at(base + i) << i;
+                lk_u64 Ss = 0;
+                const lk_u64 C = lk_take_cont_plane(plane);
+                for (int i = 0; i < 64; ++i)
+                    if (((C >> i) & 1ull) != (lk_u64)cont_at(base + i)) abort();
                 lk_smear_planes<0x37u>(plane, C, hb.prev, cin_left);
                 for (int i = 0; i < 64; ++i)   // smeared planes == per-byte definition
                     for (int b = 0; b < 8; ++b)

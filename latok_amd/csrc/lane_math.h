@@ -18,8 +18,10 @@
 
 #if defined(__HIPCC__)
 #define LATOK_HD __host__ __device__ inline
+#define LATOK_HD_COLD __host__ __device__ __attribute__((noinline))   // rare paths: a real call keeps them out of the hot loop's registers
 #else
 #define LATOK_HD static inline
+#define LATOK_HD_COLD static
 #endif
 
 typedef unsigned long long lk_u64;
@@ -276,7 +278,7 @@ LATOK_HD void lk_smear_planes(lk_u64 p[8], lk_u64 C, uint32_t cin_code, int cin_
 
 // p = bit-sliced SMEARED code planes of the word, C = its continuation bytes.  *Ss_out = smeared SPACE plane (a byte of
 // a SPACE char), which is what token stripping needs in byte space.
-LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
+LATOK_HD lk_local lk_rules_bytes_general(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
     const lk_feat fs = lk_decode(p);                 // smeared features
     const lk_u64 Lead = ~C;
     // the next 8 byte positions as a mini word (only its low bits matter)
@@ -330,6 +332,73 @@ LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, l
     r.sym = Y & nextS;
     *Ss_out = fs.S;
     return r;
+}
+
+// The same rules, cheaper on everything but stray continuation bytes.  The four C_MASK terms start at '#' '$' '^' '@' '.'
+// ':' and continue over '@' and '/': all ASCII (the reference's TWITTER / AT / COLON / SLASH / PERIOD flags are set for
+// those single code points only, latok.h:15-22), and in well-formed UTF-8 the byte after an ASCII byte is a lead byte.
+// So unless a continuation byte directly follows one of those chars ("weird": malformed input), their NEXT_* and
+// AFTER_NEXT_* columns are plain shifts by one and two positions, exactly as in char space; only NEXT_LOWER (camel case:
+// the upper-case char may be Cyrillic, Greek, ...), NEXT_SPACE (C_SYM: the symbol may be CJK punctuation, an emoji, ...)
+// and the string ends need the "next lead byte" operator.  A word with a weird byte takes lk_rules_bytes_general; the
+// CPU model checks that both agree wherever the fast form is taken.
+LATOK_HD int lk_rules_bytes_weird(const lk_u64 p[8], lk_u64 C, lk_u64 next_codes) {
+    const lk_u64 Tn = lk_transpose8(next_codes);
+    const lk_u64 Cn = (Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull;
+    // P = chars that start or continue a C_MASK term: SYMBOL with a sub-type (bits 5..7 != 0): # $ ^ @ : / .
+    const lk_u64 P = p[LK_BIT_SYMBOL] & ~C & (p[5] | p[6] | p[7]);
+    const lk_u64 Pn = (Tn >> (8 * LK_BIT_SYMBOL)) & ((Tn >> 40) | (Tn >> 48) | (Tn >> 56)) & ~Cn & 0xFFull;
+    return ((P & ((C >> 1) | (Cn << 63))) | (Pn & (Cn >> 1) & 1ull)) != 0ull;
+}
+LATOK_HD lk_local lk_rules_bytes_fast(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
+    const lk_feat fs = lk_decode(p);                 // smeared features (planes 0, 1, 2, 4, 5 are smeared)
+    const lk_u64 Lead = ~C;
+    const lk_u64 Tn = lk_transpose8(h.next_codes);
+    const lk_u64 Cn = (Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull;
+    const lk_u64 Ln = ~Cn & 0xFFull;
+#define LK_PN(b) ((Tn >> (8 * (b))) & 0xFFull)
+    const lk_u64 Sn = LK_PN(0) & Ln, Lwn = LK_PN(2) & Ln, ANn = LK_PN(4) & Ln, An = LK_PN(5) & ~LK_PN(1) & Ln,
+                 ATn = LK_PN(5) & LK_PN(6) & LK_PN(1) & Ln, SLn = LK_PN(7) & LK_PN(5) & Ln;
+#undef LK_PN
+    const lk_u64 Bn = (lk_u64)(h.next_B & 0xFFFFu);
+    const lk_u64 S = fs.S & Lead, Lw = fs.L & Lead, AN = fs.AN & Lead, A = fs.A & Lead, AT = fs.AT & Lead, SL = fs.SL & Lead;
+    const lk_u64 Y = fs.Y & Lead, U = fs.U & Lead, T = fs.T & Lead, PE = fs.PE & Lead, CO = fs.CO & Lead;
+#define LK_SH(X, Xn_, k) (((X) >> (k)) | ((Xn_) << (64 - (k))))
+    // "next lead byte" operator for lead-only planes: the value at the first lead after position i (at most 4 bytes on)
+    const lk_u64 Q1 = LK_SH(C, Cn, 1), Q2 = Q1 & LK_SH(C, Cn, 2), Q3 = Q2 & LK_SH(C, Cn, 3);
+#define LK_NEXTQ(X, Xn_) (LK_SH(X, Xn_, 1) | (Q1 & LK_SH(X, Xn_, 2)) | (Q2 & LK_SH(X, Xn_, 3)) | (Q3 & LK_SH(X, Xn_, 4)))
+    const lk_u64 E = Lead & LK_NEXTQ(B, Bn);                        // string ends: the next lead is a string start
+    const lk_u64 nextS = LK_NEXTQ(S, Sn) | E;
+    const lk_u64 nextL = LK_NEXTQ(Lw, Lwn) & ~E;
+#undef LK_NEXTQ
+    // the ASCII-started terms: the next char is the next byte, the one after it the byte after that
+    const lk_u64 nB1 = ~LK_SH(B, Bn, 1), nB2 = nB1 & ~LK_SH(B, Bn, 2);
+    const lk_u64 nextA = LK_SH(A, An, 1) & nB1, nextAN = LK_SH(AN, ANn, 1) & nB1, nextAT = LK_SH(AT, ATn, 1) & nB1,
+                 nextSL = LK_SH(SL, SLn, 1) & nB1;
+    const lk_u64 anA = LK_SH(A, An, 2) & nB2, anSL = LK_SH(SL, SLn, 2) & nB2;
+#undef LK_SH
+    const lk_u64 nB = ~B;
+    const lk_feat1 fp = lk_decode1(h.prev);
+#define LK_PREVB(X) ((((fs.X) << 1) | (lk_u64)fp.X) & nB)
+    const lk_u64 prevS = ((fs.S << 1) | (lk_u64)fp.S) | B;
+    const lk_u64 prevY = LK_PREVB(Y), prevL = LK_PREVB(L), prevAN = LK_PREVB(AN), prevA = LK_PREVB(A);
+#undef LK_PREVB
+    lk_local r;
+    r.S = S;
+    r.t_space = S;
+    r.t_sym = Y;
+    r.t_prevsym = prevY & Lead;
+    r.t_camel_next = U & nextL;
+    r.t_camel_prev = U & prevL;
+    r.raw = r.t_space | r.t_sym | r.t_prevsym | r.t_camel_next | r.t_camel_prev;
+    r.start = (T & prevS & nextA) | (PE & prevS & nextAT & anA) | (AT & prevAN & nextAN) | (CO & nextSL & anSL & prevA);
+    r.sym = Y & nextS;
+    *Ss_out = fs.S;
+    return r;
+}
+LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
+    if (lk_rules_bytes_weird(p, C, h.next_codes)) return lk_rules_bytes_general(p, C, h, B, Ss_out);
+    return lk_rules_bytes_fast(p, C, h, B, Ss_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

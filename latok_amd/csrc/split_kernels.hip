@@ -503,6 +503,48 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
     return false;
 }
 
+// byte space, phase 2: what a word needs from its surroundings -- the staging bytes of the 8 bytes after it (lane 63: the
+// halo), whether one of them is a continuation byte, the string starts after it, and the owner state in front of it (the
+// last four staging bytes of the row before; lane 0: the halo)
+__device__ __forceinline__ void bytes_word_context(const TileLds& L, int lane, lk_halo_bytes* hb, bool* next_has_cont, uint32_t* own_code,
+                                                   int* own_left) {
+    hb->next_codes = lane < 63 ? *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 80u) : *reinterpret_cast<const lk_u64*>(L.halo + 8);
+    hb->next_B = (uint32_t)(L.bw[lane + 1] & 0xFFFFull);
+    const lk_u64 y = hb->next_codes ^ 0x8080808080808080ull;          // a byte equals LK_CODE_CONT
+    *next_has_cont = (~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y) & 0x8080808080808080ull) != 0ull;
+    lk_owner_before(lane > 0 ? *reinterpret_cast<const uint32_t*>(L.stage + 80u * lane - 20u) : 0u, own_code, own_left);
+    if (lane == 0) {
+        *own_code = L.halo[0];
+        *own_left = L.halo[4];
+    }
+    hb->prev = *own_code;
+}
+// the general byte-space rules of one word, from the staging buffer (cold: tiles with a stray continuation byte behind an
+// ASCII rule char)
+__device__ __attribute__((noinline)) void bytes_rules_general_cold(const uint8_t* stage, const uint8_t* halo, const lk_u64* bw, int lane,
+                                                                   lk_local* out, lk_u64* space_out) {
+    TileLds L;
+    L.stage = const_cast<uint8_t*>(stage);
+    L.halo = const_cast<uint8_t*>(halo);
+    L.bw = const_cast<lk_u64*>(bw);
+    uint32_t d[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 q = *reinterpret_cast<const uint4*>(stage + 80u * lane + 16u * k);
+        d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+    }
+    lk_u64 plane[8];
+    lk_bitslice64(d, plane);
+    const lk_u64 C = lk_take_cont_plane(plane);
+    lk_halo_bytes hb;
+    bool next_has_cont;
+    uint32_t own_code;
+    int own_left;
+    bytes_word_context(L, lane, &hb, &next_has_cont, &own_code, &own_left);
+    lk_smear_planes<0x37u>(plane, C, own_code, own_left);
+    *out = lk_rules_bytes_general(plane, C, hb, bw[lane], space_out);
+}
+
 // Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
 // words are in the wave's LDS buffer L.  (A separate function because a producer / consumer variant of the kernel ran
 // the two phases in different waves; see DESIGN.md, negative results.)
@@ -599,19 +641,13 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             loc = lk_rules(lk_decode(plane), ha, B, Bn);
             space_plane = loc.S;
         } else if (MODE == kModeBytes) {
-            // byte space: the continuation bytes carry LK_CODE_CONT -> continuation plane of my word; the staging bytes of the
-            // 8 bytes after my row
+            // byte space: the continuation bytes carry LK_CODE_CONT -> continuation plane of my word
             const lk_u64 C = lk_take_cont_plane(plane);
             lk_halo_bytes hb;
-            hb.prev = h.prev;
-            hb.next_codes = lane < 63 ? *reinterpret_cast<const lk_u64*>(L.stage + 80u * lane + 80u)
-                                      : *reinterpret_cast<const lk_u64*>(L.halo + 8);
-            hb.next_B = (uint32_t)(L.bw[lane + 1] & 0xFFFFull);
             bool next_has_cont;
-            {   // a byte of next_codes equals LK_CODE_CONT
-                const lk_u64 y = hb.next_codes ^ 0x8080808080808080ull;
-                next_has_cont = (~(((y & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | y) & 0x8080808080808080ull) != 0ull;
-            }
+            uint32_t own_code;
+            int own_left;
+            bytes_word_context(L, lane, &hb, &next_has_cont, &own_code, &own_left);
             no_patch = __ballot(C != 0ull || next_has_cont) != 0ull;
             if (!no_patch) {
                 // no multi-byte char in or right after the tile: positions are chars, the plain rules apply
@@ -621,20 +657,20 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 ha.next1 = (uint32_t)((hb.next_codes >> 8) & 0xFFull);
                 loc = lk_rules(lk_decode(plane), ha, B, Bn);
                 space_plane = loc.S;
-            } else {
+            } else if (__ballot(lk_rules_bytes_weird(plane, C, hb.next_codes)) == 0ull) {
                 // codes sit at lead bytes only: give the continuation bytes their owner's code in the planes the PREV_*
-                // columns and the token stripping read (SPACE, SYMBOL, LOWER, ALPHA_NUM, ALPHA = bits 0, 1, 2, 4, 5).  What
-                // enters the word: the last four staging bytes of the row before (lane 0: the halo)
-                uint32_t own_code;
-                int own_left;
-                lk_owner_before(lane > 0 ? *reinterpret_cast<const uint32_t*>(L.stage + 80u * lane - 20u) : 0u, &own_code, &own_left);
-                if (lane == 0) {
-                    own_code = L.halo[0];
-                    own_left = L.halo[4];
-                }
+                // columns and the token stripping read (SPACE, SYMBOL, LOWER, ALPHA_NUM, ALPHA = bits 0, 1, 2, 4, 5)
                 lk_smear_planes<0x37u>(plane, C, own_code, own_left);
                 hb.prev = own_code;
-                loc = lk_rules_bytes(plane, C, hb, B, &space_plane);
+                loc = lk_rules_bytes_fast(plane, C, hb, B, &space_plane);
+            } else {
+                // a continuation byte right after '#' '$' '^' '@' ':' '/' '.' somewhere in the tile (malformed UTF-8): the
+                // general form, as a real call so that its registers stay out of the loop (it starts again from the staging bytes)
+                lk_local tmp;
+                lk_u64 sp;
+                bytes_rules_general_cold(L.stage, L.halo, L.bw, lane, &tmp, &sp);
+                loc = tmp;
+                space_plane = sp;
             }
         } else if (MODE == kModeRules) {
             loc = lk_rules_generic(plane, h, B, Bn, P.rules);

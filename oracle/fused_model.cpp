@@ -164,6 +164,13 @@ struct Model {
                     for (int b = 0; b < 8; ++b)
                         if (((0x37u >> b) & 1u) && ((plane[b] >> i) & 1ull) != ((byte_code_at(base + i) >> b) & 1u)) abort();
                 loc[j] = lk_rules_bytes(plane, C, hb, Bw[j], &Ss);
+                if (!lk_rules_bytes_weird(plane, C, hb.next_codes)) {   // the fast form agrees with the general one
+                    lk_u64 Sg = 0;
+                    const lk_local g = lk_rules_bytes_general(plane, C, hb, Bw[j], &Sg);
+                    if (g.raw != loc[j].raw || g.start != loc[j].start || g.sym != loc[j].sym || g.S != loc[j].S || Sg != Ss ||
+                        g.t_camel_next != loc[j].t_camel_next || g.t_prevsym != loc[j].t_prevsym)
+                        abort();
+                }
                 if (space_bits && base < total) {
                     const int64_t remain = total - base;
                     space_bits[base >> 6] = Ss & (remain >= 64 ? ~0ull : ((1ull << remain) - 1ull));

@@ -897,6 +897,60 @@ def test_utf8_byte_space(gpu, oracle):
             assert g == want, (t[:60], g[:8], want[:8])
 
 
+def test_utf8_byte_space_malformed_bytes_against_the_cpu_model(gpu):
+    """Byte space on bytes that are NOT well-formed UTF-8: stray continuation bytes (also right behind '#' '@' ':' '/' '.',
+    which sends the tile through the general rule form), runs of more than three of them, truncated sequences, lone leads,
+    0xF8..0xFF, at every word and tile phase and across tile edges.  The definition of the result is oracle/fused_model.cpp
+    (one char per lead byte, a continuation byte belongs to the nearest lead at most 3 back -- checked there against the
+    per-byte statement of that rule and, on well-formed text, against the reference-shaped oracle): the kernel must give
+    the same boundary bits and the same smeared SPACE plane (token spans), large batches and small ones."""
+    import ctypes as C
+    import os
+    from conftest import ROOT
+    from latok_amd import batch
+    model = C.CDLL(os.path.join(ROOT, "oracle", "libfused_model.so"))
+    model.fused_split_batch_utf8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(77)
+    pools = [np.arange(256, dtype=np.uint8),
+             np.array([0x20, 0x61, 0x41, 0x80, 0x80, 0xBF, 0xC3, 0xE3, 0xF0, 0xFF, 0x2E, 0x40, 0x23, 0x3A, 0x2F], np.uint8),
+             np.array([0x80, 0x81, 0xE3, 0x61, 0x20, 0x23], np.uint8),
+             np.frombuffer("a# @b .@c http://é 日本 🤓 Ünï ".encode(), np.uint8)]
+    for it in range(40):
+        big = it % 4 == 3
+        n_str = int(rng.integers(1, 400 if big else 40))
+        lens = rng.integers(0, [24, 300, 9000, 3000][it % 4], n_str)
+        boff = np.zeros(n_str + 1, np.int64)
+        np.cumsum(lens, out=boff[1:])
+        total = int(boff[-1])
+        if total == 0:
+            continue
+        u8 = np.ascontiguousarray(rng.choice(pools[(it // 4) % len(pools)], total))
+        if it % 5 == 0:   # well-formed stretches with single damaged bytes
+            good = np.frombuffer(("word #tag a@b.c http://x.y/z 日本語のテキスト、です。 🤓 Ünï Привет " * (total // 60 + 1)).encode(), np.uint8)[:total].copy()
+            hit = rng.integers(0, total, max(1, total // 97))
+            good[hit] = rng.choice(pools[1], hit.size)
+            u8 = good
+        want = np.zeros((total + 63) // 64, np.uint64)
+        want_sp = np.zeros_like(want)
+        assert model.fused_split_batch_utf8(u8.ctypes.data, boff.ctypes.data, n_str, want.ctypes.data, want_sp.ctypes.data, None) == 0
+        got = batch.split_mask_utf8_bytes_csr(u8, boff)
+        if not np.array_equal(got, want):
+            bad = int(np.nonzero(bits_to_bool(got, total) != bits_to_bool(want, total))[0][0])
+            raise AssertionError(f"case {it}: byte mask differs at byte {bad}: ...{bytes(u8[max(0, bad - 8):bad + 8])!r}")
+        # token spans read the smeared SPACE plane: same spans as the model's planes give
+        counts, spans = batch.token_spans_utf8_bytes_csr(u8, boff)
+        b, sp = bits_to_bool(want, total), bits_to_bool(want_sp, total)
+        exp = []
+        for s_ in range(n_str):
+            lo, hi = int(boff[s_]), int(boff[s_ + 1])
+            cuts = [lo + int(x) for x in np.nonzero(b[lo:hi])[0]] + [hi]
+            for a_, z_ in zip(cuts[:-1], cuts[1:]):
+                keep = np.nonzero(~sp[a_:z_])[0]
+                if keep.size:
+                    exp.append((a_ - lo + int(keep[0]), a_ - lo + int(keep[-1]) + 1))
+        assert spans.reshape(-1, 2).tolist() == [list(e) for e in exp], it
+
+
 def test_c_example_program(gpu, oracle, tmp_path):
     """examples/tokenize_utf8.c: a plain C caller of the C ABI (byte-space token ranges) prints the reference's tokens."""
     import os

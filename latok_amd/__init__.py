@@ -8,6 +8,10 @@ Layout mirrors the reference package so it can stand in for it:
     latok_amd.core.default_tokenizer   <- reference latok/core/default_tokenizer.py
     latok_amd.batch                    <- additive: whole-batch entry points over the fused kernel
 
+The repo's top-level ``latok/`` package registers these modules under the reference's own import names
+(``from latok.core.default_tokenizer import tokenize`` works with no setup call); ``install_as_latok()`` does the same on
+request for a process that must not have ``latok/`` on its path.
+
 All compute goes through ``liblatok_hip.so`` (C ABI in include/latok_hip.h).  There is no CPU fallback: importing is
 harmless, but every compute call raises ``RuntimeError`` when the library or a HIP device is missing.
 """
@@ -27,7 +31,7 @@ def install_as_latok():
     import sys
     me = sys.modules[__name__]
     other = sys.modules.get("latok")
-    if other is not None and other is not me:
+    if other is not None and other is not me and getattr(other, "_impl", None) is not me:   # (the repo's own latok/ shim is fine)
         raise RuntimeError("a different 'latok' package is already imported")
     names = {"latok": __name__, "latok.latok": __name__ + ".latok", "latok.core": __name__ + ".core",
              "latok.core.offsets": __name__ + ".core.offsets", "latok.core.latok_utils": __name__ + ".core.latok_utils",

@@ -157,6 +157,41 @@ def test_install_as_latok_aliases_reference_import_names():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
 
 
+def test_latok_import_name_is_served_without_any_setup_call():
+    """The reference's own import lines (default_tokenizer.py:33-36, scripts/timing/time_tokenizer.py:20-21) in a FRESH
+    interpreter, with nothing but the repo on sys.path and no install_as_latok(): the top-level ``latok`` package serves
+    them with the latok_amd objects themselves."""
+    import subprocess
+    import sys
+    code = ("from latok.core.default_tokenizer import tokenize, featurize, gen_split_mask, C_SPLIT, C_MASK, C_SYM\n"
+            "from latok.latok import _gen_parse_matrix, _gen_block_mask, _combine_matrix_rows\n"
+            "from latok.core.latok_utils import gen_parse_matrix, gen_block_mask, build_combo_matrix, LaToken, FEATURE_NAMES\n"
+            "import latok.core.offsets as oft\n"
+            "import latok, latok_amd, latok_amd.latok, latok_amd.core.default_tokenizer as d\n"
+            "assert tokenize is d.tokenize and _gen_parse_matrix is latok_amd.latok._gen_parse_matrix\n"
+            "assert latok.latok is latok_amd.latok and latok.core.default_tokenizer is d and oft.FEATURE_COUNT == 25\n"
+            "assert latok.__version__ == latok_amd.__version__\n"
+            "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
+
+
+def test_latok_shim_refuses_to_shadow_a_foreign_latok(tmp_path):
+    import subprocess
+    import sys
+    other = tmp_path / "elsewhere" / "latok"
+    other.mkdir(parents=True)
+    (other / "__init__.py").write_text("WHO = 'someone else'\n")
+    code = "import sys; sys.path.insert(0, %r); sys.path.append(%r); import latok" % (ROOT, str(tmp_path / "elsewhere"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert out.returncode != 0 and "would shadow another 'latok' package" in out.stderr
+    env = dict(os.environ, LATOK_AMD_ALLOW_SHADOW="1")
+    out = subprocess.run([sys.executable, "-c", code + "; print(latok.__version__)"], capture_output=True, text=True, timeout=120,
+                         cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-800:]
+
+
 def test_shard_bounds_balance_and_cover():
     """latok_amd.shard: contiguous string ranges balanced by chars; shards concatenate back to the batch."""
     import random

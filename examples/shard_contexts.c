@@ -3,7 +3,10 @@
  * other's kernels.  Strings are independent (reference tokenize() takes one str, latok/core/default_tokenizer.py:137),
  * so the batch is cut into contiguous string ranges and the shards' per-string results simply follow each other.
  *   gcc -std=c99 -pthread -Iinclude examples/shard_contexts.c -Llatok_amd -llatok_hip -Wl,-rpath,$PWD/latok_amd -o /tmp/shard_contexts
- *   /tmp/shard_contexts [device ...]      (default: two contexts on device 0)
+ *   /tmp/shard_contexts [device ...]            (default: two contexts on device 0)
+ *   /tmp/shard_contexts resident [device ...]   the shard is uploaded ONCE into its context's HBM and the call uses device
+ *                                               pointers (LATOK_DEVICE_PTRS) -- twice, to show the batch stays put; only the
+ *                                               records come back.  What a caller with data already on the GPUs does.
  * Prints, per shard, the boundary offsets of its strings (np.nonzero(gen_split_mask(...)) of the reference,
  * default_tokenizer.py:146-148) as 32-bit records. */
 #include <pthread.h>
@@ -22,6 +25,7 @@ typedef struct {
     int32_t* counts;           /* [s1 - s0] */
     int32_t* offsets;          /* capacity = my chars */
     int64_t n_offsets;
+    int resident;              /* keep the shard in HBM and call with device pointers */
     int rc;
     char err[256];
 } shard_t;
@@ -35,8 +39,26 @@ static void* run_shard(void* arg) {
         const int64_t n = sh->s1 - sh->s0, c0 = sh->row_off[sh->s0], chars = sh->row_off[sh->s1] - c0;
         int64_t* row = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
         for (int64_t i = 0; i <= n; ++i) row[i] = sh->row_off[sh->s0 + i] - c0;      /* a shard's offsets start at 0 */
-        sh->rc = latok_split_offsets_kind_batch(sh->units + c0, 1, row, n, chars, (int64_t*)sh->counts, (int64_t*)sh->offsets,
-                                                chars, &sh->n_offsets, LATOK_OUT_INT32, NULL);
+        if (!sh->resident) {
+            sh->rc = latok_split_offsets_kind_batch(sh->units + c0, 1, row, n, chars, (int64_t*)sh->counts, (int64_t*)sh->offsets,
+                                                    chars, &sh->n_offsets, LATOK_OUT_INT32, NULL);
+        } else {
+            /* device memory belongs to the device of the context that is current on this thread */
+            void* d_units = latok_dev_alloc((size_t)(chars > 0 ? chars : 1));
+            void* d_row = latok_dev_alloc((size_t)(n + 1) * sizeof(int64_t));
+            void* d_counts = latok_dev_alloc((size_t)(n + 1) * sizeof(int32_t));
+            void* d_offs = latok_dev_alloc((size_t)(chars > 0 ? chars : 1) * sizeof(int32_t));
+            sh->rc = (d_units && d_row && d_counts && d_offs) ? LATOK_OK : LATOK_ERR_NOMEM;
+            if (sh->rc == LATOK_OK) sh->rc = latok_memcpy_h2d(d_units, sh->units + c0, (size_t)chars);          /* once */
+            if (sh->rc == LATOK_OK) sh->rc = latok_memcpy_h2d(d_row, row, (size_t)(n + 1) * sizeof(int64_t));
+            for (int pass = 0; pass < 2 && sh->rc == LATOK_OK; ++pass)   /* any number of passes: nothing is uploaded again */
+                sh->rc = latok_split_offsets_kind_batch(d_units, 1, (const int64_t*)d_row, n, chars, (int64_t*)d_counts, (int64_t*)d_offs,
+                                                        chars, &sh->n_offsets, LATOK_OUT_INT32 | LATOK_DEVICE_PTRS, NULL);
+            if (sh->rc == LATOK_OK) sh->rc = latok_memcpy_d2h(sh->counts, d_counts, (size_t)n * sizeof(int32_t));
+            if (sh->rc == LATOK_OK && sh->n_offsets > 0)
+                sh->rc = latok_memcpy_d2h(sh->offsets, d_offs, (size_t)sh->n_offsets * sizeof(int32_t));
+            latok_dev_free(d_units); latok_dev_free(d_row); latok_dev_free(d_counts); latok_dev_free(d_offs);
+        }
         free(row);
     }
     if (sh->rc != LATOK_OK) snprintf(sh->err, sizeof(sh->err), "%s", latok_last_error());   /* the message is per thread */
@@ -49,6 +71,8 @@ int main(int argc, char** argv) {
     const char* texts[] = {"This is a #test! Testing, Testing, 1 2 3", "see http://a.b/c or mail me@x.org", "camelCaseXMLParser",
                            "foo@bar.com, .@user hi", "x\t\ny", "$#@^:a./"};
     const int64_t n_str = 6;
+    const int resident = argc > 1 && strcmp(argv[1], "resident") == 0;
+    if (resident) { --argc; ++argv; }
     int n_shards = argc > 1 ? argc - 1 : 2;
     if (n_shards > n_str) n_shards = (int)n_str;
     int64_t row_off[7] = {0};
@@ -62,6 +86,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < n_shards; ++r) {   /* contiguous ranges with about the same number of chars each */
         memset(&sh[r], 0, sizeof(sh[r]));
         sh[r].device = argc > 1 ? atoi(argv[1 + r]) : 0;
+        sh[r].resident = resident;
         sh[r].units = units;
         sh[r].row_off = row_off;
         sh[r].s0 = r == 0 ? 0 : sh[r - 1].s1;

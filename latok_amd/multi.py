@@ -14,6 +14,7 @@ A device may be listed more than once (two contexts on one GPU overlap one shard
 One process per GPU (bench.py, torchrun) remains the other way to use a node; this is the one for a caller that holds
 the whole batch in one process.
 """
+import ctypes as C
 import queue
 import threading
 
@@ -68,14 +69,81 @@ class _Worker(threading.Thread):
         self.join()
 
 
+_KINDS = {"utf32": (np.uint32, 4), "latin1": (np.uint8, 1), "ucs2": (np.uint16, 2), "utf8": (np.uint8, 0)}   # dtype, PEP 393 kind
+
+
+class DeviceShard:
+    """One contiguous string range of a resident batch in the HBM of ONE worker's device.  Device pointers are plain
+    ints (what latok_dev_alloc returned on that worker's context); they are only valid on that worker."""
+
+    def __init__(self, worker, s0, n_str, total, unit0):
+        self.worker, self.s0, self.n_str, self.total, self.unit0 = worker, s0, n_str, total, unit0
+        self.d_units = self.d_row = self.d_bits = None
+        self.bufs, self.cap_items, self.n_items = {}, {}, {}      # compaction records, keyed by record width
+
+    def pointers(self):
+        return [p for p in (self.d_units, self.d_row, self.d_bits) if p] + [p for p in self.bufs.values() if p]
+
+
+class ResidentBatch:
+    """A CSR batch whose shards live in the HBM of a DevicePool's devices (DevicePool.put_csr / generate)."""
+
+    def __init__(self, pool, kind, bounds, total):
+        self.pool, self.kind, self.bounds, self.total = pool, kind, np.asarray(bounds, np.int64), total
+        self.shards = []
+
+    @property
+    def n_str(self):
+        return int(self.bounds[-1])
+
+    def free(self):
+        """release every device buffer of the batch (each on the worker that owns it)"""
+        pool, shards = self.pool, self.shards
+        self.shards = []
+        if not shards or not pool._workers:
+            return
+
+        def drop(sh):
+            for p in sh.pointers():
+                pool.lib.latok_dev_free(p)
+            sh.d_units = sh.d_row = sh.d_bits = None
+            sh.bufs.clear()
+        jobs = [None] * len(pool)
+        for sh in shards:
+            if sh is not None:
+                jobs[sh.worker] = (lambda sh=sh: drop(sh))
+        pool.run(jobs)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+        return False
+
+
+def _merge_masks(parts, total):
+    """parts = [(first unit of the shard in the batch, the shard's own bitmask)]: the batch's bitmask (shift + or)"""
+    out = np.zeros((total + 63) // 64 + 1, np.uint64)
+    for lo, bits in parts:
+        if bits is None or bits.size == 0:
+            continue
+        w, sh = lo >> 6, np.uint64(lo & 63)
+        out[w:w + bits.size] |= bits << sh
+        if sh:
+            out[w + 1:w + 1 + bits.size] |= bits >> (np.uint64(64) - sh)
+    return out[:(total + 63) // 64]
+
+
 class DevicePool:
     """One context + one worker thread per entry of ``devices``."""
 
-    def __init__(self, devices, ctx_factory=_lib.Context):
+    def __init__(self, devices, ctx_factory=_lib.Context, lib=None):
         devices = list(devices)
         if not devices:
             raise ValueError("DevicePool needs at least one device")
         self.devices = devices
+        self._lib_obj = lib          # tests inject a fake of the C ABI; None = the real library, loaded on first use
         self._workers = []
         try:
             for d in devices:
@@ -124,6 +192,167 @@ class DevicePool:
         for w in self._workers:
             w.close()
         self._workers = []
+
+    # ---- device-resident shards ---------------------------------------------------------------------------------------
+    # The host-array forms above send every shard over the bus on every call (34-43 GB/s of UTF-8 per GPU).  A caller
+    # that tokenizes data which already lives in HBM -- or that runs several passes over one batch -- uploads (or
+    # generates) the shards ONCE and then calls the LATOK_DEVICE_PTRS forms of the C ABI on every context: each GPU then
+    # runs at its device-resident rate.  Strings stay independent units (reference default_tokenizer.py:137).
+    @property
+    def lib(self):
+        if self._lib_obj is None:
+            self._lib_obj = _lib.load()
+        return self._lib_obj
+
+    def _check(self, rc):
+        if rc:
+            _lib.check(rc)
+
+    def put_csr(self, units, row_off, kind="utf32"):
+        """Upload one CSR batch, cut into len(pool) contiguous string ranges balanced by unit count, each range into the
+        HBM of its worker's device.  kind: "utf32" (uint32 code points), "latin1" / "ucs2" (PEP 393 kinds 1 / 2, uint8 /
+        uint16 units; positions are chars) or "utf8" (uint8 bytes, row_off in bytes; positions are bytes).  Returns a
+        ResidentBatch; release it with .free()."""
+        dtype, _ = _KINDS[kind]
+        units = np.ascontiguousarray(units, dtype=dtype)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        if row_off.ndim != 1 or row_off.size < 1 or (row_off.size > 1 and units.size < int(row_off[-1])):
+            raise ValueError("row_off must hold n_str + 1 offsets into units")
+        bounds = shard.shard_bounds(row_off, len(self))
+        rb = ResidentBatch(self, kind, bounds, int(row_off[-1]) if row_off.size > 1 else 0)
+
+        def upload(r, s0, s1):
+            lo, hi = int(row_off[s0]), int(row_off[s1])
+            u = np.ascontiguousarray(units[lo:hi])
+            ro = np.ascontiguousarray(row_off[s0:s1 + 1] - lo)
+            sh = DeviceShard(r, s0, s1 - s0, hi - lo, lo)
+            sh.d_units = self._alloc(max(u.nbytes, 16))
+            sh.d_row = self._alloc(ro.nbytes)
+            self._check(self.lib.latok_memcpy_h2d(sh.d_units, u.ctypes.data, u.nbytes))
+            self._check(self.lib.latok_memcpy_h2d(sh.d_row, ro.ctypes.data, ro.nbytes))
+            return sh
+        rb.shards = self.run([(lambda r=r: upload(r, int(bounds[r]), int(bounds[r + 1]))) if bounds[r + 1] > bounds[r] else None
+                              for r in range(len(self))])
+        return rb
+
+    def generate(self, seed, model, n_str, len_lo, len_hi, sid0=0):
+        """A synthetic batch (SURVEY 8d corpora: bench.py's generator) of n_str strings, string ids sid0.., created
+        directly in HBM: worker r owns ids [sid0 + r n / W, sid0 + (r + 1) n / W).  Only the 8 B/string row offsets
+        cross the bus.  Returns a ResidentBatch of kind "utf32"."""
+        W = len(self)
+        bounds = np.array([r * n_str // W for r in range(W + 1)], np.int64)
+        rb = ResidentBatch(self, "utf32", bounds, 0)
+
+        def make(r, s0, n):
+            ro = np.zeros(n + 1, np.int64)
+            self._check(self.lib.latok_corpus_offsets(seed, sid0 + s0, n, len_lo, len_hi, ro.ctypes.data))
+            sh = DeviceShard(r, s0, n, int(ro[-1]), 0)
+            sh.d_units = self._alloc(max(sh.total * 4, 16))
+            sh.d_row = self._alloc(ro.nbytes)
+            self._check(self.lib.latok_memcpy_h2d(sh.d_row, ro.ctypes.data, ro.nbytes))
+            self._check(self.lib.latok_corpus_fill_device(seed, model, sid0 + s0, n, sh.d_row, sh.d_units, None))
+            self._check(self.lib.latok_sync())
+            return sh
+        rb.shards = self.run([(lambda r=r: make(r, int(bounds[r]), int(bounds[r + 1] - bounds[r]))) if bounds[r + 1] > bounds[r] else None
+                              for r in range(W)])
+        first = 0
+        for sh in rb.shards:        # unit position of each shard in the whole batch
+            if sh is not None:
+                sh.unit0 = first
+                first += sh.total
+        rb.total = first
+        return rb
+
+    def _alloc(self, nbytes):
+        p = self.lib.latok_dev_alloc(int(nbytes))
+        if not p:
+            raise MemoryError(_lib.last_error())
+        return p
+
+    def split_mask(self, rb, to_host=True):
+        """latok_split_mask_batch (or its kind / byte-space form) on every shard, on its own device, concurrently.
+        to_host=True: the batch's bitmask uint64[ceil(total/64)], merged bit-exactly from the shards' (bit i = unit i
+        of the whole batch).  to_host=False: nothing leaves the GPUs; the per-shard masks stay in sh.d_bits (bit i =
+        unit i of the SHARD) and the list of shards is returned."""
+        lib = self.lib
+
+        def one(sh):
+            words = (sh.total + 63) // 64
+            if sh.d_bits is None:
+                sh.d_bits = self._alloc(max(words * 8, 16))
+            flags = _lib.DEVICE_PTRS
+            if rb.kind == "utf32":
+                rc = lib.latok_split_mask_batch(sh.d_units, sh.d_row, sh.n_str, sh.total, sh.d_bits, flags, None)
+            elif rb.kind == "utf8":
+                rc = lib.latok_split_mask_utf8_bytes_batch(sh.d_units, sh.d_row, sh.n_str, sh.total, sh.d_bits, flags, None)
+            else:
+                rc = lib.latok_split_mask_kind_batch(sh.d_units, _KINDS[rb.kind][1], sh.d_row, sh.n_str, sh.total, sh.d_bits, flags, None)
+            self._check(rc)
+            if not to_host:
+                self._check(lib.latok_sync())
+                return None
+            bits = np.empty(words, np.uint64)
+            self._check(lib.latok_memcpy_d2h(bits.ctypes.data, sh.d_bits, bits.nbytes))    # (synchronises the stream)
+            return bits
+        res = self.run([(lambda sh=sh: one(sh)) if sh is not None and sh.total > 0 else None for sh in rb.shards])
+        if not to_host:
+            return [sh for sh in rb.shards if sh is not None]
+        return _merge_masks([(sh.unit0, bits) for sh, bits in zip(rb.shards, res) if bits is not None], rb.total)
+
+    def _compact(self, rb, fn_by_kind, width, dtype, to_host):
+        lib = self.lib
+        dt, flag32 = batch._out_dtype(dtype)
+
+        def one(sh):
+            need = None
+            for attempt in range(2):
+                cap = sh.cap_items.get(width, 0)
+                if need is not None or cap == 0:
+                    cap = max(int(need or 0), sh.total // 3, 1024)
+                    for key in ("d_counts", "d_items"):
+                        old = sh.bufs.pop((key, width), None)
+                        if old:
+                            lib.latok_dev_free(old)
+                    sh.bufs[("d_counts", width)] = self._alloc(max(sh.n_str, 1) * 8)
+                    sh.bufs[("d_items", width)] = self._alloc(cap * width * 8)
+                    sh.cap_items[width] = cap
+                n = C.c_int64(0)
+                lead = [sh.d_units, sh.d_row] if rb.kind in ("utf32", "utf8") else [sh.d_units, _KINDS[rb.kind][1], sh.d_row]
+                self._check(getattr(lib, fn_by_kind[rb.kind])(*lead, sh.n_str, sh.total, sh.bufs[("d_counts", width)], sh.bufs[("d_items", width)],
+                                                 cap, C.byref(n), _lib.DEVICE_PTRS | flag32, None))
+                if n.value <= cap:
+                    break
+                need = n.value            # the records were not written: the capacity protocol of the C ABI
+            sh.n_items[width] = int(n.value)
+            if not to_host:
+                return None
+            counts = np.empty(sh.n_str, dt)
+            items = np.empty((n.value, width) if width > 1 else n.value, dt)
+            self._check(lib.latok_memcpy_d2h(counts.ctypes.data, sh.bufs[("d_counts", width)], counts.nbytes))
+            if items.size:
+                self._check(lib.latok_memcpy_d2h(items.ctypes.data, sh.bufs[("d_items", width)], items.nbytes))
+            return counts, items
+        res = self.run([(lambda sh=sh: one(sh)) if sh is not None and sh.n_str > 0 else None for sh in rb.shards])
+        if not to_host:
+            return [sh for sh in rb.shards if sh is not None]
+        parts = [r for r in res if r is not None]
+        if not parts:
+            return np.zeros(rb.n_str, dt), np.zeros((0, width) if width > 1 else 0, dt)
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def split_offsets(self, rb, dtype=np.int32, to_host=True):
+        """Per-string boundary offsets of a resident batch: (counts[n_str], offsets[sum]) in string order (each value is
+        relative to its own string, so the shards' records simply follow each other).  to_host=False: the records stay in
+        HBM -- sh.bufs[("d_counts", 1)], sh.bufs[("d_items", 1)], sh.n_items[1] per shard."""
+        return self._compact(rb, {"utf32": "latok_split_offsets_batch", "utf8": "latok_split_offsets_utf8_bytes_batch",
+                                  "latin1": "latok_split_offsets_kind_batch", "ucs2": "latok_split_offsets_kind_batch"},
+                             1, dtype, to_host)
+
+    def token_spans(self, rb, dtype=np.int32, to_host=True):
+        """Whitespace-stripped token spans of a resident batch: (counts[n_str], spans[n_tokens, 2])."""
+        return self._compact(rb, {"utf32": "latok_token_spans_batch", "utf8": "latok_token_spans_utf8_bytes_batch",
+                                  "latin1": "latok_token_spans_kind_batch", "ucs2": "latok_token_spans_kind_batch"},
+                             2, dtype, to_host)
 
     def __enter__(self):
         return self
@@ -213,16 +442,7 @@ def split_mask_batch(cps, row_off, devices):
         row_off = np.ascontiguousarray(row_off, dtype=np.int64)
         bounds, res = map_shards(batch.split_mask_batch, np.ascontiguousarray(cps, dtype=np.uint32), row_off, pool)
         total = int(row_off[-1]) if row_off.size > 1 else 0
-        out = np.zeros((total + 63) // 64 + 1, np.uint64)
-        for r, bits in enumerate(res):
-            if bits is None or bits.size == 0:
-                continue
-            lo = int(row_off[int(bounds[r])])
-            w, sh = lo >> 6, np.uint64(lo & 63)
-            out[w:w + bits.size] |= bits << sh
-            if sh:
-                out[w + 1:w + 1 + bits.size] |= bits >> (np.uint64(64) - sh)
-        return out[:(total + 63) // 64]
+        return _merge_masks([(int(row_off[int(bounds[r])]), bits) for r, bits in enumerate(res)], total)
     finally:
         if owned:
             pool.close()

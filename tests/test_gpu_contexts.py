@@ -274,3 +274,88 @@ def test_small_calls_from_three_threads_poll_their_own_completion_words(gpu, ora
     for t in ths:
         t.join(600)
     assert not errors, errors[0]
+
+
+def test_resident_shards_on_three_contexts_equal_the_oracle(gpu, oracle):
+    """DevicePool.put_csr / generate: the shards are uploaded (or generated) ONCE into each context's HBM and every later
+    call uses the LATOK_DEVICE_PTRS forms; results against the oracle for all four input kinds, repeated calls on the same
+    resident batch, device-only results read back by hand, and the caller's HIP device untouched."""
+    from latok_amd import _lib, batch, multi
+    rng = random.Random(123)
+    texts = random_strings(rng, 4000, 0, 200, ALPHABETS["mixed"]) + random_strings(rng, 3, 20000, 50000, ALPHABETS["rare_space_at"]) + ["", "x"]
+    rng.shuffle(texts)
+    cps, row = pack(texts)
+    wc, wo, wb = _oracle_offsets(oracle, cps, row)
+    with multi.DevicePool([0, 0, 0]) as pool:
+        with pool.put_csr(cps, row) as rb:
+            assert len([sh for sh in rb.shards if sh is not None]) == 3
+            for _ in range(3):                                    # the resident batch is reusable
+                assert np.array_equal(pool.split_mask(rb), wb)
+            for dtype in (np.int32, np.int64):
+                counts, offs = pool.split_offsets(rb, dtype=dtype)
+                assert np.array_equal(counts, wc) and np.array_equal(offs, wo)
+            counts, spans = pool.token_spans(rb)
+            k = 0
+            for t, c in zip(texts, counts.tolist()):
+                assert [t[a:b] for a, b in spans[k:k + c].tolist()] == (oracle.tokenize(t) if t else [])
+                k += c
+            # device-only: read shard 1's records back on its own worker
+            shards = pool.split_offsets(rb, dtype=np.int32, to_host=False)
+            sh = shards[1]
+
+            def fetch():
+                out = np.empty(sh.n_items[1], np.int32)
+                _lib.check(pool.lib.latok_memcpy_d2h(out.ctypes.data, sh.bufs[("d_items", 1)], out.nbytes))
+                return out
+            jobs = [None] * len(pool)
+            jobs[sh.worker] = fetch
+            got = pool.run(jobs)[sh.worker]
+            lo = int(wc[:sh.s0].sum())
+            assert np.array_equal(got, wo[lo:lo + sh.n_items[1]])
+        # the narrow kinds and UTF-8 bytes
+        lat = [t for t in random_strings(rng, 3000, 0, 150, ALPHABETS["latin1"])]
+        units = np.frombuffer("".join(lat).encode("latin-1"), np.uint8)
+        lrow = np.zeros(len(lat) + 1, np.int64)
+        np.cumsum([len(t) for t in lat], out=lrow[1:])
+        lc, lo_, lb = _oracle_offsets(oracle, *pack(lat))
+        with pool.put_csr(units, lrow, kind="latin1") as rb:
+            assert np.array_equal(pool.split_mask(rb), lb)
+            c, o = pool.split_offsets(rb, dtype=np.int64)
+            assert np.array_equal(c, lc) and np.array_equal(o, lo_)
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        u8, boff = batch.pack_utf8(blobs)
+        with pool.put_csr(u8, boff, kind="utf8") as rb:
+            assert np.array_equal(pool.split_mask(rb), batch.split_mask_utf8_bytes_csr(u8, boff))
+            c, o = pool.split_offsets(rb, dtype=np.int64)
+            c1, o1 = batch.split_offsets_utf8_bytes_csr(u8, boff)
+            assert np.array_equal(c, c1) and np.array_equal(o, o1)
+        # generated on the devices: equals the host generator's corpus
+        n = 30000
+        grow = np.zeros(n + 1, np.int64)
+        gpu.latok_corpus_offsets(0x1A70C0DF, 77, n, 10, 300, grow.ctypes.data)
+        gcps = np.zeros(int(grow[-1]), np.uint32)
+        gpu.latok_corpus_fill_host(0x1A70C0DF, _lib.CORPUS_UNICODE, 77, n, grow.ctypes.data, gcps.ctypes.data)
+        with pool.generate(0x1A70C0DF, _lib.CORPUS_UNICODE, n, 10, 300, sid0=77) as rb:
+            assert rb.total == int(grow[-1])
+            assert np.array_equal(pool.split_mask(rb), oracle.split_batch(gcps, grow, want_values=False)[1])
+
+
+def test_pool_over_every_device_of_the_box(gpu, oracle):
+    """contexts on devices >= 1 (pinned buffers, events and streams created under a non-zero current device, a
+    worker thread per device).  Runs wherever the box has more than one GPU; the caller's current device stays what it was."""
+    from latok_amd import multi
+    n_dev = gpu.latok_device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU on this box")
+    rng = random.Random(5)
+    texts = random_strings(rng, 6000, 0, 300, ALPHABETS["mixed"])
+    cps, row = pack(texts)
+    wc, wo, wb = _oracle_offsets(oracle, cps, row)
+    with multi.DevicePool(list(range(n_dev))) as pool:
+        c, o = multi.split_offsets_csr(cps, row, pool)
+        assert np.array_equal(c, wc) and np.array_equal(o, wo)
+        with pool.put_csr(cps, row) as rb:
+            assert np.array_equal(pool.split_mask(rb), wb)
+            c, o = pool.split_offsets(rb, dtype=np.int64)
+            assert np.array_equal(c, wc) and np.array_equal(o, wo)
+    assert gpu.latok_ctx_device(None) == 0      # the default context is still on device 0

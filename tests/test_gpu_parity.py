@@ -977,7 +977,7 @@ def test_c_example_sharding_over_contexts(gpu, oracle, tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"), "-o", exe])
     texts = [G1, "see http://a.b/c or mail me@x.org", "camelCaseXMLParser", "foo@bar.com, .@user hi", "x\t\ny", "$#@^:a./"]
     want = [f"{i}:" + "".join(f" {o}" for o in oracle.split_offsets(t).tolist()) for i, t in enumerate(texts)]
-    for args in ([], ["0", "0", "0"]):
+    for args in ([], ["0", "0", "0"], ["resident"], ["resident", "0", "0", "0"]):
         out = subprocess.run([exe] + args, capture_output=True, timeout=120, check=True).stdout.decode().splitlines()
         assert out == want, (args, out)
 

@@ -78,3 +78,25 @@ for pin in (False, True):
         best = dt if best is None or dt < best else best
     print(json.dumps({"path": "mask, UTF-8 in (byte space)", "host_memory": "pinned" if pin else "pageable",
                       "ms_per_batch": best * 1e3, "utf8_GBps": utf8_bytes / best / 1e9}), flush=True)
+
+# device-resident shards of a DevicePool (latok_amd.multi): the batch is uploaded once per context, every call after that
+# uses device pointers -- the rate each context reaches is the device rate, not the bus's.  Contexts here: 1, 2 and 3 on
+# device 0 (what a one-GPU box can show; on a node list its devices), records stay in HBM (to_host=False).
+from latok_amd import multi  # noqa: E402
+
+for devices in ([0], [0, 0], [0, 0, 0]):
+    with multi.DevicePool(devices) as pool:
+        for kind, units in (("utf32", cps), ("latin1", u8), ("utf8", u8)):
+            with pool.put_csr(units, row, kind=kind) as rb:
+                for label, call in (("mask", lambda: pool.split_mask(rb, to_host=False)),
+                                    ("offsets int32", lambda: pool.split_offsets(rb, dtype=np.int32, to_host=False))):
+                    call()
+                    best = None
+                    for _ in range(5):
+                        t = time.perf_counter()
+                        call()
+                        dt = time.perf_counter() - t
+                        best = dt if best is None or dt < best else best
+                    print(json.dumps({"path": f"resident pool, {label}, {kind} in", "contexts": len(devices), "devices": devices,
+                                      "ms_per_batch": best * 1e3, "utf8_GBps": utf8_bytes / best / 1e9,
+                                      "note": "shards resident in HBM, device-pointer calls, results stay on the device"}), flush=True)

@@ -318,11 +318,16 @@ class DevicePool:
                     sh.cap_items[width] = cap
                 n = C.c_int64(0)
                 lead = [sh.d_units, sh.d_row] if rb.kind in ("utf32", "utf8") else [sh.d_units, _KINDS[rb.kind][1], sh.d_row]
-                self._check(getattr(lib, fn_by_kind[rb.kind])(*lead, sh.n_str, sh.total, sh.bufs[("d_counts", width)], sh.bufs[("d_items", width)],
-                                                 cap, C.byref(n), _lib.DEVICE_PTRS | flag32, None))
+                rc = getattr(lib, fn_by_kind[rb.kind])(*lead, sh.n_str, sh.total, sh.bufs[("d_counts", width)], sh.bufs[("d_items", width)],
+                                                        cap, C.byref(n), _lib.DEVICE_PTRS | flag32, None)
                 if n.value <= cap:
+                    self._check(rc)
                     break
-                need = n.value            # the records were not written: the capacity protocol of the C ABI
+                # the capacity protocol of the C ABI: the total is always returned, the records are written only if they fit
+                # (the call then fails with LATOK_ERR_INVALID "output capacity too small"): grow once and repeat
+                if attempt == 1:
+                    self._check(rc or _lib.ERR_INVALID)
+                need = n.value
             sh.n_items[width] = int(n.value)
             if not to_host:
                 return None

@@ -220,7 +220,9 @@ class FakeDeviceLib:
         n_out._obj.value = n
         self._buf(d_counts, dt)[:n_str] = [len(p) for p in per]
         self.calls.append(("spans" if spans else "offsets", threading.get_ident(), n_str, cap, n))
-        if n <= cap and n:          # the records are written only if they fit
+        if n > cap:                 # as api.cpp does: the total is reported, nothing is written, LATOK_ERR_INVALID
+            return -1
+        if n:
             flat = np.concatenate(per).ravel()
             self._buf(d_items, dt)[:flat.size] = flat
         return 0

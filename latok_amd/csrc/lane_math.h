@@ -141,6 +141,40 @@ LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
     return f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ASCII without a table: the 8 split-code planes of a word as boolean functions of the 7 bit planes of its RAW bytes
+// (r[b] bit i = bit b of byte i; every byte < 0x80).  The class of an ASCII char is a handful of range and equality
+// tests on its bits (reference flag derivation, scripts/unicode/makeunicodedata.py:167-200,256-257, swept into
+// unicode_tables.inc: SPACE = 09-0D 1C-20, digits, A-Z, a-z, SYMBOL = every other printable 21-7E, sub-types for
+// # $ ^ @ : / .), so a word costs ~120 bit operations instead of 128 table lookups through the LDS pipe.
+// tests/test_fused_model.py checks all 128 values in every position against the table.
+// ---------------------------------------------------------------------------------------------------------------
+LATOK_HD void lk_ascii_code_planes(const lk_u64 r[8], lk_u64 p[8]) {
+    const lk_u64 b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], b4 = r[4], b5 = r[5], b6 = r[6];
+    const lk_u64 nz = b3 | b2 | b1 | b0;                      // low nibble != 0
+    const lk_u64 le10 = ~(b3 & (b2 | (b1 & b0)));             // low nibble <= 10
+    const lk_u64 le9 = ~(b3 & (b2 | b1));                     // low nibble <= 9
+    const lk_u64 g2 = ~b6 & b5 & ~b4, g3 = ~b6 & b5 & b4;     // 0x2_, 0x3_
+    const lk_u64 letter = b6 & ((~b4 & nz) | (b4 & le10));    // 41-5A, 61-7A
+    const lk_u64 digit = g3 & le9;
+    const lk_u64 alnum = letter | digit;
+    const lk_u64 sp20 = g2 & ~nz;                             // 0x20
+    const lk_u64 space = (~b6 & ~b5 & b3 & ((~b4 & ((~b2 & (b1 | b0)) | (b2 & ~b1))) | (b4 & b2))) | sp20;   // 09-0D, 1C-1F, 20
+    const lk_u64 del = b6 & b5 & b4 & b3 & b2 & b1 & b0;      // 0x7F
+    const lk_u64 sym = (b6 | b5) & ~sp20 & ~del & ~alnum;
+    const lk_u64 n_e = b3 & b2 & b1 & ~b0, n_f = b3 & b2 & b1 & b0;
+    const lk_u64 c_hash = g2 & ~b3 & ~b2 & b1 & b0, c_dollar = g2 & ~b3 & b2 & ~b1 & ~b0, c_caret = b6 & ~b5 & b4 & n_e;
+    const lk_u64 c_at = b6 & ~b5 & ~b4 & ~nz, c_colon = g3 & b3 & ~b2 & b1 & ~b0, c_slash = g2 & n_f, c_dot = g2 & n_e;
+    p[LK_BIT_SPACE] = space;
+    p[LK_BIT_SYMBOL] = sym;
+    p[LK_BIT_LOWER] = letter & b5;
+    p[LK_BIT_UPPER] = letter & ~b5;
+    p[LK_BIT_ALNUM] = alnum;
+    p[5] = letter | c_hash | c_dollar | c_caret | c_at | c_slash;
+    p[6] = c_at | c_dot;
+    p[7] = c_colon | c_slash | c_dot;
+}
+
 // neighbour characters outside the word: codes of char (base-1), (base+64), (base+65); 0 when they do not exist
 struct lk_halo {
     uint32_t prev, next0, next1;

@@ -262,8 +262,9 @@ __device__ __forceinline__ uint32_t u8_high_nibble(uint32_t w) { return ((((w >>
 // 2 bytes each.  Nothing is decoded and there are no continuation bytes, so the staging buffer receives plain codes and
 // phase 2 evaluates the char-space rules (lk_rules), exactly like a UTF-32 tile; only the LDS layout is the byte-space one.
 // Halo: halo[0] = code of unit t0-1, halo[8], halo[9] = codes of units t0+4096, t0+4097 (0 where there is no such char).
+// Returns (KIND 1 only) whether every byte of the tile is ASCII (wave-uniform): phase 2 then classifies without a table.
 template <int KIND>
-__device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
+__device__ __forceinline__ bool units_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
     const int64_t total = P.total;
     if (lane < 2) *reinterpret_cast<lk_u64*>(L.halo + 8u * lane) = 0ull;
     uint32_t halo_u = 0xFFFFFFFFu;                                              // out of range -> class 0
@@ -296,6 +297,10 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(v[i].x, v[i].y, v[i].z, v[i].w);
         if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = L.ctab[halo_u & 0xFFu];
+        uint32_t hi_bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hi_bits |= (v[i].x | v[i].y | v[i].z | v[i].w) & 0x80808080u;
+        return __all(hi_bits == 0u);
     } else {
         // UCS-2: 8 units per 16-byte load, row i of the tile = units 512 i + 8 lane ..
         u32x4 v[8];
@@ -335,6 +340,7 @@ __device__ __forceinline__ void units_phase1(const SplitParams& P, const TileLds
         }
         if (lane < 3 && halo_u != 0xFFFFFFFFu) L.halo[lane == 0 ? 0 : 7 + lane] = (uint8_t)classify1(L.t1, L.t2, halo_u);
     }
+    return false;
 }
 
 // kModeBytes, phase 1 (lane = 16 consecutive bytes per 1 KiB row).  What reaches the staging buffer: the split code of
@@ -550,7 +556,7 @@ __device__ __attribute__((noinline)) void bytes_rules_general_cold(const uint8_t
 // the two phases in different waves; see DESIGN.md, negative results.)
 template <int MODE, bool DEFER = false, bool SMALL = false>
 __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLds& L, int64_t t, int q_in, int tail_zero,
-                                            bool write_summary, int4* summ_l, int lane, bool raw_stage
+                                            bool write_summary, int4* summ_l, int lane, bool raw_stage, bool ascii_tile
 #ifdef LATOK_STAMPS
                                             , unsigned long long* stamp_acc, unsigned long long& stamp_prev
 #endif
@@ -614,7 +620,17 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
 #elif defined(LATOK_AB_ARITH_SLICE)
             lk_bitslice64(d, plane);
 #else
-            slice_lut64(d, L.lut, plane);
+#ifndef LATOK_AB_LUT_ALWAYS
+            if (ascii_tile) {
+                // all 4096 bytes are ASCII: bit-slice the raw bytes and derive the code planes as boolean functions of the
+                // raw planes -- no table, nothing through the LDS pipe (128 ds_read_b32 per word otherwise, which hit a bank
+                // twice in ~90 % of the passes and kept the pipe busy for about half of a tile round)
+                lk_u64 rawp[8];
+                lk_bitslice64(d, rawp);
+                lk_ascii_code_planes(rawp, plane);
+            } else
+#endif
+                slice_lut64(d, L.lut, plane);
 #endif
             LATOK_STAMP(10);   // (share of stamp 4: LUT slicing)
             h.prev = lane > 0 ? L.ctab[h.prev] : h.prev;
@@ -819,6 +835,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     const int64_t total = P.total;
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
     bool raw_stage = MODE == kModeLatin1;   // the staging buffer holds raw bytes, not codes (Latin-1; all-ASCII tiles of byte mode)
+    bool ascii_tile = false;                // ... and every one of them is ASCII (wave-uniform)
     LATOK_STAMP(0);
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
@@ -838,11 +855,12 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
     } else if (MODE == kModeLatin1) {
-        units_phase1<1>(P, L, t0, lane);
+        ascii_tile = units_phase1<1>(P, L, t0, lane);
     } else if (MODE == kModeUcs2) {
         units_phase1<2>(P, L, t0, lane);
     } else if (MODE == kModeBytes) {
         raw_stage = bytes_phase1(P, L, t0, lane);
+        ascii_tile = raw_stage;
     } else if (FAST_TAIL) {
         // Small batches: the batch's last, partial tile takes the same road as a full one -- only the rows of 256 chars that
         // exist are requested, all of them before the first table lookup; chars that do not exist read as 0 and their
@@ -944,7 +962,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #endif
     LATOK_STAMP(3);
 
-    return tile_phase2<MODE, DEFER, SMALL>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage
+    return tile_phase2<MODE, DEFER, SMALL>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage, ascii_tile
 #ifdef LATOK_STAMPS
                                     , stamp_acc, stamp_prev
 #endif
@@ -1096,6 +1114,18 @@ constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes
 constexpr int kLdsTotalBase = kLdsSlice;
 constexpr int kLdsTotalBytes = kLdsSlice + kSliceLutBytes + 256;
 constexpr int lds_total(int mode) { return mode == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
+// Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
+// per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
+// buffers of waves 12..15 sit behind the rest of the map, so that every other offset is the same for all kernels.
+#ifndef LATOK_AB_LATIN1_WPB
+#define LATOK_AB_LATIN1_WPB 16
+#endif
+#ifndef LATOK_AB_UCS2_WPB
+#define LATOK_AB_UCS2_WPB 16
+#endif
+constexpr int tile_wpb(int mode) { return mode == kModeLatin1 ? LATOK_AB_LATIN1_WPB : (mode == kModeUcs2 ? LATOK_AB_UCS2_WPB : kWPB); }
+constexpr int lds_total_tiles(int mode) { return lds_total(mode) + (tile_wpb(mode) > kWPB ? (tile_wpb(mode) - kWPB) * kWaveLdsBytes : 0); }
+static_assert(lds_total_tiles(kModeLatin1) <= 160 * 1024 && lds_total_tiles(kModeUcs2) <= 160 * 1024, "LDS budget of one CU");
 constexpr int kLdsTotal = kLdsTotalBytes;
 static_assert(sizeof(ScanLds) <= 512, "scan scratch");
 static_assert(kSegMax == kWPB * 64, "one tile per thread in the block-wide scans");
@@ -1137,7 +1167,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     TileLds L;
     L.t1 = lds;
     L.t2 = lds + kStage1Pad;
-    uint8_t* mine = lds + kLdsWaves + wave * kWaveLdsBytes;
+    uint8_t* mine = wave < kWPB ? lds + kLdsWaves + wave * kWaveLdsBytes : lds + lds_total(MODE) + (wave - kWPB) * kWaveLdsBytes;
     L.stage = mine;
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
@@ -1164,13 +1194,13 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 #define LATOK_STAMP_NULL
 #endif
 
-template <int MODE, bool FAST_TAIL = false>
+template <int MODE, bool FAST_TAIL = false, int WPB = kWPB>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
                                             int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
     const TileLds L = wave_lds<MODE>(lds, wave);
     int4* sm = reinterpret_cast<int4*>(lds + kLdsSumm);
-    ScanLds& scan = *reinterpret_cast<ScanLds*>(lds + kLdsScan);
+    ScanLdsT<WPB>& scan = *reinterpret_cast<ScanLdsT<WPB>*>(lds + kLdsScan);
 
     const int64_t T0 = seg * S;
     const int64_t T1 = min(T0 + S, P.n_tiles);
@@ -1178,7 +1208,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     // (a) first string of each tile: P.tile_first, written by k_tile_index before this kernel.  A wave takes the tiles
     //     wave, wave + kWPB, ... of the segment -- at most 64 -- so one load per lane holds the whole segment's worth.
     int64_t tfv = 0;
-    if (wave + kWPB * lane < n_seg) tfv = P.tile_first[T0 + wave + kWPB * lane];
+    if (wave + WPB * lane < n_seg) tfv = P.tile_first[T0 + wave + WPB * lane];
     tfv = tfv < 0 ? 0 : (tfv > P.n_str ? P.n_str : tfv);   // (row offsets that are not non-decreasing leave holes in the index)
     if (tables) __syncthreads();   // the class tables (first segment of the workgroup) are in LDS
     // (b) the tiles
@@ -1192,7 +1222,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (j < slot) {
-                const int64_t w = (T0 + k_first + j * kWPB) * 64 + lane;
+                const int64_t w = (T0 + k_first + j * WPB) * 64 + lane;
 #ifdef LATOK_AB_SC1_STORES
                 if (w < n_words) __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.bits_out) + w, obuf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -1208,7 +1238,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
         if (++slot == 8) flush();
     };
-    for (int k = wave, j = 0; k < n_seg; k += kWPB, ++j) {
+    for (int k = wave, j = 0; k < n_seg; k += WPB, ++j) {
         const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
@@ -1230,7 +1260,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
             h.h = s.z; h.c = s.w & 1;
         }
         Fn64 ef, tfn; Hd64 eh, th;
-        block_scan(f, h, scan, &ef, &eh, &tfn, &th);
+        block_scan<WPB>(f, h, scan, &ef, &eh, &tfn, &th);
         if (tid == 0) { P.seg_fn[seg] = tfn; P.seg_hd[seg] = th; }
     }
     __syncthreads();
@@ -1240,21 +1270,22 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
 // batches, where that tile's latency is a visible share of the call (a 4-tile batch in pinned host memory: 31 -> 16 us);
 // the large-batch instantiation keeps the serial tail: the unified form costs its full-tile loop 16 VGPRs and 4 % on C2.
 template <int MODE, bool FAST_TAIL = false>
-__global__ __launch_bounds__(kWPB * 64) void k_tiles_main(SplitParams P) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total(MODE)];
+__global__ __launch_bounds__(tile_wpb(MODE) * 64) void k_tiles_main(SplitParams P) {
+    constexpr int WPB = tile_wpb(MODE);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total_tiles(MODE)];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> scalar tile arithmetic
     if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
 
     bool tables = MODE != kModeBlockMask;
-    if (tables) load_tables<kWPB * 64, MODE>(lds, P);   // published by the barrier at the top of the workgroup's first segment
+    if (tables) load_tables<WPB * 64, MODE>(lds, P);   // published by the barrier at the top of the workgroup's first segment
 #ifdef LATOK_STAMPS
     unsigned long long stamp_acc[16];
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
 #endif
     for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
-        run_segment<MODE, FAST_TAIL>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
+        run_segment<MODE, FAST_TAIL, WPB>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
         tables = false;
     }
 #ifdef LATOK_STAMPS
@@ -2356,8 +2387,8 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
     else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);
-    else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, block, 0, st, P);
-    else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, block, 0, st, P);
+    else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, dim3(tile_wpb(kModeLatin1) * 64), 0, st, P);
+    else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, dim3(tile_wpb(kModeUcs2) * 64), 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }

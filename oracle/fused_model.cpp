@@ -373,3 +373,21 @@ extern "C" int fused_block_mask(const int8_t* a1, const int8_t* a2, int64_t n, i
     out[0] = (any1 && !any2) ? 0 : 1;   // reference quirk: element 0 (latok.c:224 vs :211-216)
     return 0;
 }
+
+
+// test hook: 64 raw ASCII bytes -> their split codes through lk_bitslice64 + lk_ascii_code_planes (the table-free ASCII
+// classification of the narrow-input tile kernels), un-sliced again; and the same bytes through the class table
+extern "C" void fused_ascii_codes(const uint8_t* bytes64, uint8_t* planes_codes_out, uint8_t* table_codes_out) {
+    uint32_t d[16];
+    for (int k = 0; k < 16; ++k) d[k] = (uint32_t)bytes64[4 * k] | ((uint32_t)bytes64[4 * k + 1] << 8) | ((uint32_t)bytes64[4 * k + 2] << 16) |
+                                        ((uint32_t)bytes64[4 * k + 3] << 24);
+    lk_u64 raw[8], p[8];
+    lk_bitslice64(d, raw);
+    lk_ascii_code_planes(raw, p);
+    for (int i = 0; i < 64; ++i) {
+        uint32_t c = 0;
+        for (int b = 0; b < 8; ++b) c |= (uint32_t)((p[b] >> i) & 1ull) << b;
+        planes_codes_out[i] = (uint8_t)c;
+        table_codes_out[i] = (uint8_t)classify(bytes64[i]);
+    }
+}

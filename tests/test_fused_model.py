@@ -170,3 +170,22 @@ def test_model_smear_arithmetic_on_malformed_utf8(model):
         bits = np.zeros((total + 63) // 64, np.uint64)
         sp = np.zeros_like(bits)
         assert model.fused_split_batch_utf8(u8.ctypes.data, boff.ctypes.data, n_str, bits.ctypes.data, sp.ctypes.data, None) == 0
+
+
+def test_table_free_ascii_classification_is_the_table(model):
+    """lane_math.h lk_ascii_code_planes (the narrow-input tile kernels classify ASCII words AFTER bit-slicing, as boolean
+    functions of the raw bit planes, instead of 128 LDS lookups per word) against the class table for all 128 ASCII values,
+    each in every position of the 64-byte word."""
+    model.fused_ascii_codes.argtypes = [C.c_void_p] * 3
+    for rot in range(64):
+        for base in (0, 64):
+            b = np.array([base + (i + rot) % 64 for i in range(64)], np.uint8)
+            got, want = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+            model.fused_ascii_codes(b.ctypes.data, got.ctypes.data, want.ctypes.data)
+            assert np.array_equal(got, want), (rot, base)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        b = rng.integers(0, 128, 64).astype(np.uint8)
+        got, want = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+        model.fused_ascii_codes(b.ctypes.data, got.ctypes.data, want.ctypes.data)
+        assert np.array_equal(got, want)

@@ -241,13 +241,16 @@ int latok_utf8_bytes(const uint32_t* cps, int64_t n, int64_t* bytes_out, int fla
  * matrices built with build_combo_matrix (latok/core/latok_utils.py:27-56) over the 25 feature columns
  * (latok/core/offsets.py:24-49), combined as gen_split_mask does (default_tokenizer.py:113-134):
  *     splits = combine(C_SPLIT) * block_mask(combine(C_MASK), SPACE) + combine(C_SYM);  splits[0] = 1
- * with combine = _combine_matrix_rows (latok.c:275-370).  After latok_set_rules every bitmask-based entry point
- * (latok_split_mask_batch, latok_split_offsets_batch, latok_token_spans_batch, latok_token_features_batch and the
- * UTF-8 forms) evaluates the caller's tables inside the fused kernel; boundaries are bit-exact with the reference
- * recipe run on the same tables.  Each table is a row-major int8 [rows x cols] matrix of column ids, -1 padding short
- * rows; limits: <= 16 rows per table, ids 0..24, a row must not START with -1 (the reference would reuse the previous
- * row's product there).  rows = 0 gives the all-zero vector.  latok_split_values_batch refuses to run while custom
- * tables are installed (per-term values exist for the built-in tables only).  State of the current context. */
+ * with combine = _combine_matrix_rows (latok.c:275-370).  After latok_set_rules EVERY batch entry point evaluates the
+ * caller's tables inside the fused kernel, for every input form -- UTF-32, UTF-8 in byte space, UTF-8 in code-point
+ * units, PEP 393 kind 1 / 2 units (each has its own tile-kernel instantiation; nothing is widened or decoded first) --
+ * and every output: bitmask, offsets, token spans, featurize, and latok_split_values_batch, which then returns what
+ * gen_split_mask returns for those tables: (number of C_SPLIT rows that hold) * mask + (number of C_SYM rows that hold),
+ * 1 at a string start.  Boundaries and values are bit-exact with the reference recipe run on the same tables.  Each
+ * table is a row-major int8 [rows x cols] matrix of column ids, -1 padding short rows; limits: <= 32 rows per table (the
+ * rows travel in the kernel arguments; the reference's own tables have 5 / 4 / 1), ids 0..24, a row must not START
+ * with -1 (the reference would reuse the previous row's product there).  rows = 0 gives the all-zero vector.  State of
+ * the current context. */
 int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const int8_t* c_mask, int mask_rows,
                     int mask_cols, const int8_t* c_sym, int sym_rows, int sym_cols);
 int latok_reset_rules(void);   /* back to the built-in default_tokenizer.py tables */

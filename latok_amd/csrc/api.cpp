@@ -253,16 +253,12 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
-        if (g.rules_on) return fail(LATOK_ERR_INVALID, "run-time rule tables are not available in byte space; use the code-point UTF-8 entry points");
         if (((uintptr_t)d_u8 & 15) != 0)
             return fail(LATOK_ERR_INVALID, unit_kind ? "device code-unit pointer must be 16-byte aligned" : "device UTF-8 pointer must be 16-byte aligned");
         mode = unit_kind == 1 ? latok::kModeLatin1 : (unit_kind == 2 ? latok::kModeUcs2 : latok::kModeBytes);
     }
-    if (g.rules_on) {
-        if (mode == latok::kModeValues)
-            return fail(LATOK_ERR_INVALID, "split VALUES are defined for the built-in rule tables only; call latok_reset_rules()");
-        if (mode == latok::kModeBits) mode = latok::kModeRules;
-    }
+    // run-time rule tables (latok_set_rules): the same input form, rules interpreted from the kernel arguments
+    if (g.rules_on && mode != latok::kModeBlockMask) mode = latok::mode_with_rules(mode);
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     int rc = ensure_workspace(g, n_tiles);
     if (rc) return rc;
@@ -286,10 +282,10 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     if (d_codes && mode != latok::kModeBits && mode != latok::kModeRules)
         return fail(LATOK_ERR_INVALID, "internal: code bytes are written by the UTF-32 bitmask modes only");
     // rule codes (split code + NUM) when the rules are interpreted at run time or the code bytes are kept for featurize
-    const uint8_t* tables = (const uint8_t*)((mode == latok::kModeRules || d_codes) ? g.t1rule.p : g.t1.p);
+    const uint8_t* tables = (const uint8_t*)((latok::mode_rules(mode) || d_codes) ? g.t1rule.p : g.t1.p);
     P.t1 = tables;
     P.t2 = tables + latok::kStage1Pad;
-    if (mode == latok::kModeRules) P.rules = g.rules;
+    if (latok::mode_rules(mode)) P.rules = g.rules;
     else memset(&P.rules, 0, sizeof(P.rules));
     P.bits_out = d_bits;
     P.values_out = d_values;
@@ -682,7 +678,7 @@ static int decode_utf8_to_workspace(Ctx& g, const uint8_t* u8, const int64_t* by
                                          (int64_t*)g.pin_tot.d));
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t total_cps = *(volatile const int64_t*)g.pin_tot.h;
-    if (bytes_route && total_cps == total_bytes && ((uintptr_t)d_u8 & 15) == 0 && !g.rules_on) {
+    if (bytes_route && total_cps == total_bytes && ((uintptr_t)d_u8 & 15) == 0) {
         bytes_route->d_u8 = d_u8;
         bytes_route->d_boff = d_boff;
         *total_cps_out = total_cps;
@@ -756,8 +752,8 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
                                   int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st,
                                   latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr}) {
     int rc;
-    if (d_u8 && unit_kind && (feats || g.rules_on)) {
-        // featurize re-reads the code points and the rule interpreter has no narrow-unit form: widen once, on the device
+    if (d_u8 && unit_kind && feats) {
+        // featurize re-reads the code points: widen once, on the device
         if (((uintptr_t)d_u8 & (size_t)(unit_kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
         if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
         HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)g.h_cps.p, st));
@@ -902,7 +898,7 @@ static int compact_host_pipelined_body(Ctx& g, bool spans, bool feats, bool o32,
         if ((rc = g.wpref.ensure(w * 2 + 8))) return rc;
         if ((rc = g.tile_first.ensure(t * 8 + 8))) return rc;
         if (feats && (rc = g.codes.ensure((size_t)max_chars + latok::kTile + 256))) return rc;
-        if (as_u8 && unit_kind && (feats || g.rules_on) && (rc = g.h_cps.ensure((size_t)max_chars * 4 + 16))) return rc;
+        if (as_u8 && unit_kind && feats && (rc = g.h_cps.ensure((size_t)max_chars * 4 + 16))) return rc;
         if ((rc = g.chain.ensure((size_t)latok::count_blocks((int64_t)w) * 8 + 64))) return rc;
     }
     int64_t running = 0;
@@ -1444,15 +1440,8 @@ int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_
         d_row = (const int64_t*)g.u_boff.p;
         d_bits = (uint64_t*)g.h_out.p;
     }
-    if (g.rules_on) {   // the rule interpreter reads code points: widen on the device
-        if (((uintptr_t)d_units & (size_t)(kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
-        if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
-        HIP_TRY(latok::launch_widen_units(d_units, kind, total, (uint32_t*)g.h_cps.p, st));
-        rc = run_pipeline(g, (const uint32_t*)g.h_cps.p, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st);
-    } else {
-        rc = run_pipeline(g, nullptr, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, d_units, kind);
-    }
+    rc = run_pipeline(g, nullptr, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, nullptr, nullptr, d_units, kind);
     if (rc) return rc;
     if (!dev) {
         HIP_TRY(hipMemcpyAsync(mask_bits_out, d_bits, out_bytes, hipMemcpyDeviceToHost, st));

@@ -27,9 +27,26 @@ constexpr int kModeBytes = 4;            // kModeBits in BYTE space: input = UTF
 constexpr int kModeLatin1 = 5;           // kModeBits on PEP 393 kind-1 input: SplitParams::u8 = one BYTE per char (U+0000..U+00FF)
 constexpr int kModeUcs2 = 6;             // kModeBits on PEP 393 kind-2 input: SplitParams::u8 = one uint16 per char
 // modes whose input is SplitParams::u8 and whose tiles use the byte-space LDS layout (pads, 16-byte halo)
-constexpr bool mode_is_bytes(int mode) { return mode == kModeBytes || mode == kModeLatin1 || mode == kModeUcs2; }
-constexpr bool mode_is_units(int mode) { return mode == kModeLatin1 || mode == kModeUcs2; }
-constexpr bool mode_writes_bits(int mode) { return mode == kModeBits || mode == kModeRules || mode_is_bytes(mode); }
+// the same four input forms / outputs with caller-supplied C_SPLIT / C_MASK / C_SYM (SplitParams::rules; t2 = rule codes):
+// kModeRules is kModeBits + tables; these are the others
+constexpr int kModeBytesRules = 7;       // kModeBytes + run-time rule tables
+constexpr int kModeLatin1Rules = 8;      // kModeLatin1 + run-time rule tables
+constexpr int kModeUcs2Rules = 9;        // kModeUcs2 + run-time rule tables
+constexpr int kModeValuesRules = 10;     // kModeValues + run-time rule tables: what gen_split_mask returns for any tables
+                                         // (default_tokenizer.py:121-132): rows(C_SPLIT) * mask + rows(C_SYM), string start = 1
+// input / output form of a mode, and whether the rules are interpreted at run time
+constexpr int mode_base(int mode) {
+    return mode == kModeRules ? kModeBits : mode == kModeBytesRules ? kModeBytes : mode == kModeLatin1Rules ? kModeLatin1
+         : mode == kModeUcs2Rules ? kModeUcs2 : mode == kModeValuesRules ? kModeValues : mode;
+}
+constexpr bool mode_rules(int mode) { return mode != mode_base(mode); }
+constexpr int mode_with_rules(int base) {
+    return base == kModeBits ? kModeRules : base == kModeBytes ? kModeBytesRules : base == kModeLatin1 ? kModeLatin1Rules
+         : base == kModeUcs2 ? kModeUcs2Rules : base == kModeValues ? kModeValuesRules : base;
+}
+constexpr bool mode_is_bytes(int mode) { return mode_base(mode) == kModeBytes || mode_base(mode) == kModeLatin1 || mode_base(mode) == kModeUcs2; }
+constexpr bool mode_is_units(int mode) { return mode_base(mode) == kModeLatin1 || mode_base(mode) == kModeUcs2; }
+constexpr bool mode_writes_bits(int mode) { return mode_base(mode) == kModeBits || mode_is_bytes(mode); }
 
 constexpr long long kNegInf64 = -(1ll << 60);
 constexpr int kWPB = 12;                 // waves per workgroup: 768 threads -> 168 VGPRs per lane, one workgroup per CU

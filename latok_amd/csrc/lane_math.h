@@ -149,6 +149,7 @@ LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
 // # $ ^ @ : / .), so a word costs ~120 bit operations instead of 128 table lookups through the LDS pipe.
 // tests/test_fused_model.py checks all 128 values in every position against the table.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool RULE_CODES = false>   // rule codes carry NUM in bit 6 of non-symbols (split_code.h)
 LATOK_HD void lk_ascii_code_planes(const lk_u64 r[8], lk_u64 p[8]) {
     const lk_u64 b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], b4 = r[4], b5 = r[5], b6 = r[6];
     const lk_u64 nz = b3 | b2 | b1 | b0;                      // low nibble != 0
@@ -171,7 +172,7 @@ LATOK_HD void lk_ascii_code_planes(const lk_u64 r[8], lk_u64 p[8]) {
     p[LK_BIT_UPPER] = letter & ~b5;
     p[LK_BIT_ALNUM] = alnum;
     p[5] = letter | c_hash | c_dollar | c_caret | c_at | c_slash;
-    p[6] = c_at | c_dot;
+    p[6] = c_at | c_dot | (RULE_CODES ? digit : 0ull);
     p[7] = c_colon | c_slash | c_dot;
 }
 
@@ -531,7 +532,34 @@ LATOK_HD lk_u64 lk_combine_rows(const lk_planes& F, const uint32_t* rows, int n_
     return acc;
 }
 
-LATOK_HD lk_local lk_rules_generic(const lk_u64 p[8], lk_halo h, lk_u64 B, lk_u64 Bn, const lk_rule_tables& R) {
+// number of rows of a table that hold at a position, bit-sliced: cnt[b] bit i = bit b of the count at char i.  This is the
+// VALUE _combine_matrix_rows returns on a 0/1 matrix (latok.c:329-338: sum over rows of the product over the row's
+// columns; uint8 wrap needs 256 rows, LK_MAX_RULE_ROWS is far below that).
+#define LK_COUNT_BITS 6
+LATOK_HD void lk_count_rows(const lk_planes& F, const uint32_t* rows, int n_rows, lk_u64 cnt[LK_COUNT_BITS]) {
+    for (int b = 0; b < LK_COUNT_BITS; ++b) cnt[b] = 0;
+    for (int r = 0; r < n_rows; ++r) {
+        uint32_t m = rows[r];
+        lk_u64 x = ~0ull;
+        while (m) {
+            const int k = __builtin_ctz(m);
+            m &= m - 1;
+            x &= LK_PLANE_GET(F, k);
+        }
+        for (int b = 0; b < LK_COUNT_BITS; ++b) {   // ripple add of the row's plane
+            const lk_u64 c = cnt[b] & x;
+            cnt[b] ^= x;
+            x = c;
+        }
+    }
+}
+// counts of C_SPLIT and C_SYM rows per position (split VALUES under run-time tables, default_tokenizer.py:121-132)
+struct lk_rule_counts {
+    lk_u64 split[LK_COUNT_BITS], sym[LK_COUNT_BITS];
+};
+
+LATOK_HD lk_local lk_rules_generic(const lk_u64 p[8], lk_halo h, lk_u64 B, lk_u64 Bn, const lk_rule_tables& R,
+                                   lk_rule_counts* counts = nullptr) {
     lk_planes F;
     lk_feature_planes(p, h, B, Bn, F);
     lk_local r;
@@ -539,7 +567,94 @@ LATOK_HD lk_local lk_rules_generic(const lk_u64 p[8], lk_halo h, lk_u64 B, lk_u6
     r.raw = lk_combine_rows(F, R.row[0], R.n_rows[0]);
     r.start = lk_combine_rows(F, R.row[1], R.n_rows[1]);
     r.sym = lk_combine_rows(F, R.row[2], R.n_rows[2]);
-    r.t_space = r.t_sym = r.t_prevsym = r.t_camel_next = r.t_camel_prev = 0;   // per-term values exist for the default tables only
+    r.t_space = r.t_sym = r.t_prevsym = r.t_camel_next = r.t_camel_prev = 0;   // per-term planes exist for the default tables only
+    if (counts) {
+        lk_count_rows(F, R.row[0], R.n_rows[0], counts->split);
+        lk_count_rows(F, R.row[2], R.n_rows[2], counts->sym);
+    }
+    return r;
+}
+
+// Run-time rule tables in BYTE space (UTF-8 input, positions are bytes): the 25 columns of a char live at its lead byte.
+// p = rule-code planes with planes 0, 1, 2, 4, 5 smeared over the continuation bytes (lk_smear_planes), the others lead
+// only; C = continuation bytes; h as for lk_rules_bytes.  PREV_* columns read the smeared planes one byte back, NEXT_* /
+// AFTER_NEXT_* use the "next lead byte" operator -- for every column: a caller's row may put any column beside any char.
+LATOK_HD void lk_feature_planes_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_planes& F, lk_u64* E_out) {
+    const lk_u64 Lead = ~C;
+    const lk_u64 Y = p[LK_BIT_SYMBOL], nY = ~Y;
+    lk_u64 b[12];
+    b[0] = p[5] & nY & Lead;                 // ALPHA
+    b[1] = p[LK_BIT_ALNUM] & Lead;           // ALPHA_NUM
+    b[2] = p[6] & nY & Lead;                 // NUM
+    b[3] = p[LK_BIT_LOWER] & Lead;
+    b[4] = p[LK_BIT_UPPER] & Lead;
+    b[5] = p[LK_BIT_SPACE] & Lead;
+    b[6] = Y & Lead;                         // SYMBOL
+    b[7] = p[5] & Y & ~p[7] & Lead;          // TWITTER
+    b[8] = p[5] & p[6] & Y & Lead;           // CHAR_AT
+    b[9] = p[7] & ~p[6] & ~p[5] & Lead;      // CHAR_COLON
+    b[10] = p[7] & p[5] & Lead;              // CHAR_SLASH
+    b[11] = p[7] & p[6] & Lead;              // CHAR_PERIOD
+    // the next 8 byte positions as a mini word
+    const lk_u64 Tn = lk_transpose8(h.next_codes);
+    const lk_u64 Cn = (Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull;
+    const lk_u64 Ln = ~Cn & 0xFFull;
+#define LK_PN(k) ((Tn >> (8 * (k))) & 0xFFull)
+    const lk_u64 Yn = LK_PN(1);
+    const lk_u64 An = LK_PN(5) & ~Yn & Ln, ANn = LK_PN(4) & Ln, Lwn = LK_PN(2) & Ln, Sn = LK_PN(0) & Ln,
+                 ATn = LK_PN(5) & LK_PN(6) & Yn & Ln, SLn = LK_PN(7) & LK_PN(5) & Ln;
+#undef LK_PN
+    const lk_u64 Bn = (lk_u64)(h.next_B & 0xFFFFu);
+#define LK_SH(X, Xn_, k) (((X) >> (k)) | ((Xn_) << (64 - (k))))
+    const lk_u64 Q1 = LK_SH(C, Cn, 1), Q2 = Q1 & LK_SH(C, Cn, 2), Q3 = Q2 & LK_SH(C, Cn, 3);
+#define LK_NEXTQ(X, Xn_) (LK_SH(X, Xn_, 1) | (Q1 & LK_SH(X, Xn_, 2)) | (Q2 & LK_SH(X, Xn_, 3)) | (Q3 & LK_SH(X, Xn_, 4)))
+    // the same operator inside the mini word (what lies behind its 8 bytes does not reach the main word's columns)
+    const lk_u64 n1 = Cn >> 1, n2 = n1 & (Cn >> 2), n3 = n2 & (Cn >> 3);
+#define LK_NEXTQ_MINI(Xn_) (Ln & (((Xn_) >> 1) | (n1 & ((Xn_) >> 2)) | (n2 & ((Xn_) >> 3)) | (n3 & ((Xn_) >> 4))))
+    const lk_u64 E = Lead & LK_NEXTQ(B, Bn);                 // string ends: the next lead is a string start
+    const lk_u64 En = LK_NEXTQ_MINI(Bn);
+    const lk_u64 E2 = E | (Lead & LK_NEXTQ(E, En));
+    const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
+    const lk_u64 nextA_raw = LK_NEXTQ(b[0], An), nextSL_raw = LK_NEXTQ(b[10], SLn);
+    const lk_u64 anA = LK_NEXTQ(nextA_raw & Lead, LK_NEXTQ_MINI(An)) & nE2, anSL = LK_NEXTQ(nextSL_raw & Lead, LK_NEXTQ_MINI(SLn)) & nE2;
+    const uint32_t wp = lk_base_word1(h.prev);
+    const lk_u64 sA = p[5] & nY;                              // smeared ALPHA (planes 5 and 1 are smeared)
+#define LK_PREVQ(S_, i) (((((S_)) << 1) | (lk_u64)((wp >> (i)) & 1u)) & nB & Lead)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) LK_PLANE_SET(F, i, b[i]);
+    LK_PLANE_SET(F, 12, LK_PREVQ(sA, 0));                               // PREV_ALPHA
+    LK_PLANE_SET(F, 13, nextA_raw & nE & Lead);                         // NEXT_ALPHA
+    LK_PLANE_SET(F, 14, LK_PREVQ(p[LK_BIT_ALNUM], 1));                  // PREV_ALPHA_NUM
+    LK_PLANE_SET(F, 15, LK_NEXTQ(b[1], ANn) & nE & Lead);               // NEXT_ALPHA_NUM
+    LK_PLANE_SET(F, 16, LK_PREVQ(p[LK_BIT_LOWER], 3));                  // PREV_LOWER
+    LK_PLANE_SET(F, 17, LK_NEXTQ(b[3], Lwn) & nE & Lead);               // NEXT_LOWER
+    LK_PLANE_SET(F, 18, (LK_PREVQ(p[LK_BIT_SPACE], 5) | B) & Lead);     // PREV_SPACE: 1 at a string start
+    LK_PLANE_SET(F, 19, ((LK_NEXTQ(b[5], Sn) & nE) | E) & Lead);        // NEXT_SPACE: 1 at a string end
+    LK_PLANE_SET(F, 20, LK_PREVQ(Y, 6));                                // PREV_SYMBOL
+    LK_PLANE_SET(F, 21, LK_NEXTQ(b[8], ATn) & nE & Lead);               // NEXT_AT
+    LK_PLANE_SET(F, 22, nextSL_raw & nE & Lead);                        // NEXT_SLASH
+    LK_PLANE_SET(F, 23, anA & Lead);                                    // AFTER_NEXT_ALPHA
+    LK_PLANE_SET(F, 24, anSL & Lead);                                   // AFTER_NEXT_SLASH
+#undef LK_PREVQ
+#undef LK_NEXTQ_MINI
+#undef LK_NEXTQ
+#undef LK_SH
+    *E_out = E;
+}
+LATOK_HD lk_local lk_rules_generic_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, const lk_rule_tables& R,
+                                         lk_u64* Ss_out) {
+    lk_planes F;
+    lk_u64 E;
+    lk_feature_planes_bytes(p, C, h, B, F, &E);
+    const lk_u64 Lead = ~C;
+    lk_local r;
+    r.S = p[LK_BIT_SPACE] & Lead;
+    // an empty row set is "all ones" per row, and a table may have rows that no lead byte... keep everything at lead bytes
+    r.raw = lk_combine_rows(F, R.row[0], R.n_rows[0]) & Lead;
+    r.start = lk_combine_rows(F, R.row[1], R.n_rows[1]) & Lead;
+    r.sym = lk_combine_rows(F, R.row[2], R.n_rows[2]) & Lead;
+    r.t_space = r.t_sym = r.t_prevsym = r.t_camel_next = r.t_camel_prev = 0;
+    *Ss_out = p[LK_BIT_SPACE];
     return r;
 }
 

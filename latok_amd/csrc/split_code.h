@@ -30,7 +30,7 @@
 // Runtime rule tables: each row of C_SPLIT / C_MASK / C_SYM is the SET of feature columns it multiplies
 // (bit k = column k of reference latok/core/offsets.py:24-49).
 #define LK_N_FEATURES 25
-#define LK_MAX_RULE_ROWS 16
+#define LK_MAX_RULE_ROWS 32    /* rows per table (the reference's own tables have 5 / 4 / 1); sets the size of the kernel argument only */
 struct lk_rule_tables {
     uint32_t row[3][LK_MAX_RULE_ROWS];   // [0] C_SPLIT, [1] C_MASK, [2] C_SYM
     int32_t n_rows[3];

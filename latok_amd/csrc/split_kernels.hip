@@ -567,6 +567,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     const lk_u64 B = L.bw[lane];
     const int64_t base = t0 + 64 * (int64_t)lane;
     lk_local loc;
+    lk_rule_counts counts;    // kModeValuesRules only: rows of C_SPLIT / C_SYM that hold at each char
     lk_u64 space_plane = 0;   // SPACE plane for the token-span passes (byte mode: smeared over continuation bytes)
     int no_patch = 0;         // byte mode: the tile holds multi-byte chars, the resolve stage must recompute, not patch
     if (MODE == kModeBlockMask) {
@@ -611,7 +612,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         h.next1 = lane < 63 ? L.stage[80u * lane + 81u] : L.halo[2];
         const lk_u64 Bn = L.bw[lane + 1] & 3ull;
         lk_u64 plane[8];
-        if (MODE == kModeLatin1 || (MODE == kModeBytes && raw_stage)) {
+        if (mode_base(MODE) == kModeLatin1 || (mode_base(MODE) == kModeBytes && raw_stage)) {
             // d = raw bytes: classify + slice through the LUT; the neighbour bytes become codes through the code table
             LATOK_STAMP(9);    // (share of stamp 4: the four ds_read_b128 + neighbour bytes)
 #if defined(LATOK_AB_NO_SLICE)
@@ -627,7 +628,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 // twice in ~90 % of the passes and kept the pipe busy for about half of a tile round)
                 lk_u64 rawp[8];
                 lk_bitslice64(d, rawp);
-                lk_ascii_code_planes(rawp, plane);
+                lk_ascii_code_planes<mode_rules(MODE)>(rawp, plane);
             } else
 #endif
                 slice_lut64(d, L.lut, plane);
@@ -646,17 +647,19 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             ha.prev = h.prev;
             ha.next0 = lane < 63 ? h.next0 : L.halo[8];
             ha.next1 = lane < 63 ? h.next1 : L.halo[9];
-            loc = lk_rules(lk_decode(plane), ha, B, Bn);
+            if (mode_rules(MODE)) loc = lk_rules_generic(plane, ha, B, Bn, P.rules);   // (the staging bytes are rule codes then)
+            else loc = lk_rules(lk_decode(plane), ha, B, Bn);
             space_plane = loc.S;
-        } else if (MODE == kModeBytes && raw_stage) {
+        } else if (mode_base(MODE) == kModeBytes && raw_stage) {
             // all-ASCII tile: byte positions are char positions, the plain rules apply (codes of the neighbours: above)
             lk_halo ha;
             ha.prev = h.prev;
             ha.next0 = lane < 63 ? h.next0 : L.halo[8];
             ha.next1 = lane < 63 ? h.next1 : L.halo[9];
-            loc = lk_rules(lk_decode(plane), ha, B, Bn);
+            if (mode_rules(MODE)) loc = lk_rules_generic(plane, ha, B, Bn, P.rules);
+            else loc = lk_rules(lk_decode(plane), ha, B, Bn);
             space_plane = loc.S;
-        } else if (MODE == kModeBytes) {
+        } else if (mode_base(MODE) == kModeBytes) {
             // byte space: the continuation bytes carry LK_CODE_CONT -> continuation plane of my word
             const lk_u64 C = lk_take_cont_plane(plane);
             lk_halo_bytes hb;
@@ -671,8 +674,14 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 ha.prev = h.prev;
                 ha.next0 = (uint32_t)(hb.next_codes & 0xFFull);
                 ha.next1 = (uint32_t)((hb.next_codes >> 8) & 0xFFull);
-                loc = lk_rules(lk_decode(plane), ha, B, Bn);
+                if (mode_rules(MODE)) loc = lk_rules_generic(plane, ha, B, Bn, P.rules);
+                else loc = lk_rules(lk_decode(plane), ha, B, Bn);
                 space_plane = loc.S;
+            } else if (mode_rules(MODE)) {
+                // run-time rule tables in byte space: every NEXT_* / AFTER_NEXT_* column through the next-lead operator
+                lk_smear_planes<0x37u>(plane, C, own_code, own_left);
+                hb.prev = own_code;
+                loc = lk_rules_generic_bytes(plane, C, hb, B, P.rules, &space_plane);
             } else if (__ballot(lk_rules_bytes_weird(plane, C, hb.next_codes)) == 0ull) {
                 // codes sit at lead bytes only: give the continuation bytes their owner's code in the planes the PREV_*
                 // columns and the token stripping read (SPACE, SYMBOL, LOWER, ALPHA_NUM, ALPHA = bits 0, 1, 2, 4, 5)
@@ -688,8 +697,8 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 loc = tmp;
                 space_plane = sp;
             }
-        } else if (MODE == kModeRules) {
-            loc = lk_rules_generic(plane, h, B, Bn, P.rules);
+        } else if (mode_rules(MODE)) {
+            loc = lk_rules_generic(plane, h, B, Bn, P.rules, MODE == kModeValuesRules ? &counts : nullptr);
         } else {
             const lk_feat f = lk_decode(plane);
             loc = lk_rules(f, h, B, Bn);
@@ -798,11 +807,23 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const int i = 4 * w + b;
-                        int v = (int)((loc.t_space >> i) & 1) + (int)((loc.t_sym >> i) & 1) +
-                                (int)((loc.t_prevsym >> i) & 1) + (int)((loc.t_camel_next >> i) & 1) +
-                                (int)((loc.t_camel_prev >> i) & 1);
+                        int v, vy;
+                        if (MODE == kModeValuesRules) {
+                            // what the reference returns for ANY tables: (number of C_SPLIT rows that hold) * mask + (number
+                            // of C_SYM rows that hold), default_tokenizer.py:121-132 over latok.c:329-338
+                            v = vy = 0;
+#pragma unroll
+                            for (int c = 0; c < LK_COUNT_BITS; ++c) {
+                                v |= (int)((counts.split[c] >> i) & 1) << c;
+                                vy |= (int)((counts.sym[c] >> i) & 1) << c;
+                            }
+                        } else {
+                            v = (int)((loc.t_space >> i) & 1) + (int)((loc.t_sym >> i) & 1) + (int)((loc.t_prevsym >> i) & 1) +
+                                (int)((loc.t_camel_next >> i) & 1) + (int)((loc.t_camel_prev >> i) & 1);
+                            vy = (int)((loc.sym >> i) & 1);
+                        }
                         v = ((keep >> i) & 1) ? v : 0;
-                        v += (int)((loc.sym >> i) & 1);
+                        v += vy;
                         if ((B >> i) & 1) v = 1;
                         packed |= (uint32_t)v << (8 * b);
                     }
@@ -834,7 +855,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     const int64_t t0 = t * kTile;
     const int64_t total = P.total;
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
-    bool raw_stage = MODE == kModeLatin1;   // the staging buffer holds raw bytes, not codes (Latin-1; all-ASCII tiles of byte mode)
+    bool raw_stage = mode_base(MODE) == kModeLatin1;   // the staging buffer holds raw bytes, not codes (Latin-1; all-ASCII tiles of byte mode)
     bool ascii_tile = false;                // ... and every one of them is ASCII (wave-uniform)
     LATOK_STAMP(0);
 
@@ -854,11 +875,11 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     // ---- phase 1: classify 4096 chars, 4 per lane per step, into the staging buffer --------------------------
     if (MODE == kModeBlockMask) {
         // planes come straight from the caller's byte arrays (compat _gen_block_mask): nothing to classify
-    } else if (MODE == kModeLatin1) {
+    } else if (mode_base(MODE) == kModeLatin1) {
         ascii_tile = units_phase1<1>(P, L, t0, lane);
-    } else if (MODE == kModeUcs2) {
+    } else if (mode_base(MODE) == kModeUcs2) {
         units_phase1<2>(P, L, t0, lane);
-    } else if (MODE == kModeBytes) {
+    } else if (mode_base(MODE) == kModeBytes) {
         raw_stage = bytes_phase1(P, L, t0, lane);
         ascii_tile = raw_stage;
     } else if (FAST_TAIL) {
@@ -1113,7 +1134,7 @@ constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of
 constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: [slice LUT | code table] (ASCII tiles); Latin-1 has it at 0
 constexpr int kLdsTotalBase = kLdsSlice;
 constexpr int kLdsTotalBytes = kLdsSlice + kSliceLutBytes + 256;
-constexpr int lds_total(int mode) { return mode == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
+constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
 // Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
 // per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
 // buffers of waves 12..15 sit behind the rest of the map, so that every other offset is the same for all kernels.
@@ -1123,7 +1144,10 @@ constexpr int lds_total(int mode) { return mode == kModeBytes ? kLdsTotalBytes :
 #ifndef LATOK_AB_UCS2_WPB
 #define LATOK_AB_UCS2_WPB 16
 #endif
-constexpr int tile_wpb(int mode) { return mode == kModeLatin1 ? LATOK_AB_LATIN1_WPB : (mode == kModeUcs2 ? LATOK_AB_UCS2_WPB : kWPB); }
+constexpr int tile_wpb(int mode) {
+    return mode_base(mode) == kModeLatin1 && !mode_rules(mode) ? LATOK_AB_LATIN1_WPB
+         : (mode_base(mode) == kModeUcs2 && !mode_rules(mode) ? LATOK_AB_UCS2_WPB : kWPB);   // (the rule interpreter needs > 128 VGPRs)
+}
 constexpr int lds_total_tiles(int mode) { return lds_total(mode) + (tile_wpb(mode) > kWPB ? (tile_wpb(mode) - kWPB) * kWaveLdsBytes : 0); }
 static_assert(lds_total_tiles(kModeLatin1) <= 160 * 1024 && lds_total_tiles(kModeUcs2) <= 160 * 1024, "LDS budget of one CU");
 constexpr int kLdsTotal = kLdsTotalBytes;
@@ -1136,11 +1160,11 @@ static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0 && kLdsSlice % 16 == 0, "
 // copy is one stream of kTablesLdsBytes / 16 vectors; all of a thread's loads are issued before its first LDS write.
 template <int NT = kWPB * 64, int MODE = kModeBits>
 __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) {
-    if (MODE == kModeLatin1) {
+    if (mode_base(MODE) == kModeLatin1) {
         build_latin1_tables<NT>(lds, P);
         return;
     }
-    if (MODE == kModeBytes) build_latin1_tables<NT>(lds + kLdsSlice, P);   // for its all-ASCII tiles
+    if (mode_base(MODE) == kModeBytes) build_latin1_tables<NT>(lds + kLdsSlice, P);   // for its all-ASCII tiles
     constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
     constexpr int kPer = (kVec + NT - 1) / NT;                    // 4 with 768 threads
     const uint4* src = reinterpret_cast<const uint4*>(P.t1);
@@ -1171,7 +1195,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.stage = mine;
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
-    L.lut = lds + (MODE == kModeBytes ? kLdsSlice : 0);   // build_latin1_tables: kModeLatin1 at 0, kModeBytes behind the rest
+    L.lut = lds + (mode_base(MODE) == kModeBytes ? kLdsSlice : 0);   // build_latin1_tables: kModeLatin1 at 0, kModeBytes behind the rest
     L.ctab = L.lut + kSliceLutBytes;
     L.small_bits = L.small_space = nullptr;
     return L;
@@ -1359,7 +1383,7 @@ __device__ __forceinline__ void resolve_segments(const SplitParams& P, uint8_t* 
             if (q_in != 0 || tz != tz0) {
                 const int geom = s.w;
                 // (byte mode: only tiles without multi-byte chars, where "last char of a block" = "last position")
-                if ((MODE == kModeBits || mode_is_bytes(MODE)) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
+                if (!mode_rules(MODE) && (MODE == kModeBits || mode_is_bytes(MODE)) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
                     (q_in == 0 || s.z == 0)) {
                     // Patch in place: one pending start entering a tile whose head block has no start of its own
                     // zeroes that head block; a tail block that turns out to be zeroed is cleared.  What stays in a
@@ -2389,6 +2413,10 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);
     else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, dim3(tile_wpb(kModeLatin1) * 64), 0, st, P);
     else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, dim3(tile_wpb(kModeUcs2) * 64), 0, st, P);
+    else if (mode == kModeBytesRules) hipLaunchKernelGGL((k_tiles_main<kModeBytesRules>), grid, block, 0, st, P);
+    else if (mode == kModeLatin1Rules) hipLaunchKernelGGL((k_tiles_main<kModeLatin1Rules>), grid, block, 0, st, P);
+    else if (mode == kModeUcs2Rules) hipLaunchKernelGGL((k_tiles_main<kModeUcs2Rules>), grid, block, 0, st, P);
+    else if (mode == kModeValuesRules) hipLaunchKernelGGL((k_tiles_main<kModeValuesRules>), grid, block, 0, st, P);
     else hipLaunchKernelGGL((k_tiles_main<kModeBlockMask>), grid, block, 0, st, P);
     return hipGetLastError();
 }
@@ -2411,6 +2439,10 @@ hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStrea
         else hipLaunchKernelGGL((k_resolve_fix<kModeBits, kWPB>), grid, block, 0, st, P);
     } else if (mode == kModeValues) hipLaunchKernelGGL((k_resolve_fix<kModeValues, kWPB>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_resolve_fix<kModeRules, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeBytesRules) hipLaunchKernelGGL((k_resolve_fix<kModeBytesRules, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeLatin1Rules) hipLaunchKernelGGL((k_resolve_fix<kModeLatin1Rules, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeUcs2Rules) hipLaunchKernelGGL((k_resolve_fix<kModeUcs2Rules, kWPB>), grid, block, 0, st, P);
+    else if (mode == kModeValuesRules) hipLaunchKernelGGL((k_resolve_fix<kModeValuesRules, kWPB>), grid, block, 0, st, P);
     else if (mode == kModeBytes) {   // (ASCII tiles are repaired in place here too; measured better with few waves on C2 and C3)
         if (P.seg_tiles <= 128) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 2>), grid, dim3(128), 0, st, P);
         else if (P.seg_tiles <= 256) hipLaunchKernelGGL((k_resolve_fix<kModeBytes, 4>), grid, dim3(256), 0, st, P);

@@ -87,7 +87,7 @@ struct Model {
             if (cont_at(q + j)) cp = (cp << 6) | (u8[q + j] & 0x3Fu);
             else { cp = 0xFFFDu; break; }
         }
-        return classify(cp);
+        return classify(cp, rules != nullptr);
     }
     // byte mode, what phase 1 of the tile kernel leaves in the staging buffer: the code at LEAD bytes, 0 at continuation bytes
     uint32_t lead_code_at(int64_t p) const { return cont_at(p) ? LK_CODE_CONT : byte_code_at(p); }
@@ -163,8 +163,9 @@ struct Model {
                 for (int i = 0; i < 64; ++i)   // smeared planes == per-byte definition
                     for (int b = 0; b < 8; ++b)
                         if (((0x37u >> b) & 1u) && ((plane[b] >> i) & 1ull) != ((byte_code_at(base + i) >> b) & 1u)) abort();
-                loc[j] = lk_rules_bytes(plane, C, hb, Bw[j], &Ss);
-                if (!lk_rules_bytes_weird(plane, C, hb.next_codes)) {   // the fast form agrees with the general one
+                if (rules) loc[j] = lk_rules_generic_bytes(plane, C, hb, Bw[j], *rules, &Ss);
+                else loc[j] = lk_rules_bytes(plane, C, hb, Bw[j], &Ss);
+                if (!rules && !lk_rules_bytes_weird(plane, C, hb.next_codes)) {   // the fast form agrees with the general one
                     lk_u64 Sg = 0;
                     const lk_local g = lk_rules_bytes_general(plane, C, hb, Bw[j], &Sg);
                     if (g.raw != loc[j].raw || g.start != loc[j].start || g.sym != loc[j].sym || g.S != loc[j].S || Sg != Ss ||
@@ -352,6 +353,32 @@ extern "C" int fused_split_batch_rules(const uint32_t* cps, const int64_t* row_o
     m.rules = &R;
     m.run();
     if (n_fix_out) *n_fix_out = m.n_fix + m.n_patch;
+    return 0;
+}
+
+// byte space with run-time rule tables (kModeBytesRules of the HIP kernel)
+extern "C" int fused_split_batch_utf8_rules(const uint8_t* u8, const int64_t* byte_off, int64_t n_str, const uint32_t* rows,
+                                            const int32_t* n_rows, uint64_t* bits_out, uint64_t* space_out) {
+    if (n_str < 0) return -1;
+    lk_rule_tables R;
+    memset(&R, 0, sizeof(R));
+    for (int t = 0; t < 3; ++t) {
+        if (n_rows[t] < 0 || n_rows[t] > LK_MAX_RULE_ROWS) return -1;
+        R.n_rows[t] = n_rows[t];
+        for (int r = 0; r < n_rows[t]; ++r) R.row[t][r] = rows[t * LK_MAX_RULE_ROWS + r];
+    }
+    Model m;
+    m.cps = nullptr;
+    m.u8 = u8;
+    m.row_off = byte_off;
+    m.n_str = n_str;
+    m.total = n_str > 0 ? byte_off[n_str] : 0;
+    m.n_tiles = (m.total + kTile - 1) / kTile;
+    m.values = nullptr;
+    m.bits = bits_out;
+    m.space_bits = space_out;
+    m.rules = &R;
+    m.run();
     return 0;
 }
 

@@ -115,9 +115,12 @@ def random_rule_tables(rng: random.Random):
     return table(8, 3, False), table(5, 4, True), table(3, 3, True)
 
 
+MAX_RULE_ROWS = 32     # LK_MAX_RULE_ROWS (latok_amd/csrc/split_code.h)
+
+
 def rule_row_sets(tables):
-    """(C_SPLIT, C_MASK, C_SYM) -> (uint32[3*16] column sets, int32[3] row counts): the packing the kernel interprets."""
-    rows = np.zeros(3 * 16, np.uint32)
+    """(C_SPLIT, C_MASK, C_SYM) -> (uint32[3 * MAX_RULE_ROWS] column sets, int32[3] row counts): the packing the kernel interprets."""
+    rows = np.zeros(3 * MAX_RULE_ROWS, np.uint32)
     n_rows = np.zeros(3, np.int32)
     for t, tab in enumerate(tables):
         a = np.asarray(tab, np.int8)
@@ -127,7 +130,7 @@ def rule_row_sets(tables):
         for r in range(a.shape[0]):
             for v in a[r]:
                 if v != -1:
-                    rows[t * 16 + r] |= np.uint32(1) << np.uint32(v)
+                    rows[t * MAX_RULE_ROWS + r] |= np.uint32(1) << np.uint32(v)
     return rows, n_rows
 
 

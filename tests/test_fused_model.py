@@ -189,3 +189,37 @@ def test_table_free_ascii_classification_is_the_table(model):
         got, want = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
         model.fused_ascii_codes(b.ctypes.data, got.ctypes.data, want.ctypes.data)
         assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["default", "sym_everywhere", "no_mask", "all_starts", "all_columns", "random"])
+def test_model_runtime_rule_tables_in_byte_space(model, oracle, name):
+    """Run-time rule tables on UTF-8 input in byte space (lane_math.h: lk_feature_planes_bytes / lk_rules_generic_bytes --
+    PREV_* columns from the smeared planes, NEXT_* / AFTER_NEXT_* through the next-lead operator): boundary bits at the
+    lead bytes against the reference recipe run on the same tables, string by string, in char space."""
+    from conftest import RULE_SETS, random_rule_tables, rule_row_sets
+    model.fused_split_batch_utf8_rules.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = random.Random(hash(name) & 0xFFF)
+    alpha = ALPHABETS["mixed"] + list("é日🤓ü　Жδ") + ["http://é", "a@日", ".@ü", "#日", "Ünï", "９"]
+    for rep in range(6 if name == "random" else 3):
+        tables = random_rule_tables(rng) if name == "random" else RULE_SETS[name]
+        rows, n_rows = rule_row_sets(tables)
+        for n, lo, hi in [(120, 0, 60), (20, 0, 400), (2, 4000, 9000)]:
+            texts = random_strings(rng, rng.randint(1, n), lo, hi, alpha)
+            blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+            boff = np.zeros(len(texts) + 1, np.int64)
+            np.cumsum([len(b) for b in blobs], out=boff[1:])
+            total = int(boff[-1])
+            if total == 0:
+                continue
+            want = np.zeros(total, bool)
+            for t, b0 in zip(texts, boff[:-1]):
+                if t:
+                    v = oracle.split_values_rules(t, *tables)
+                    pos = np.cumsum([0] + [len(ch.encode("utf-8", "surrogatepass")) for ch in t])[:-1]
+                    want[b0 + pos] = v != 0
+            u8 = np.frombuffer(b"".join(blobs), np.uint8)
+            bits = np.zeros((total + 63) // 64, np.uint64)
+            assert model.fused_split_batch_utf8_rules(u8.ctypes.data, boff.ctypes.data, len(texts), rows.ctypes.data, n_rows.ctypes.data,
+                                                      bits.ctypes.data, None) == 0
+            got = np.unpackbits(bits.view(np.uint8), bitorder="little")[:total].astype(bool)
+            assert np.array_equal(got, want), (name, rep, int(np.nonzero(got != want)[0][0]))

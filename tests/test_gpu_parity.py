@@ -232,15 +232,45 @@ def test_golden_fixtures_on_gpu(gpu):
 
 def test_golden_rule_tables_on_gpu(gpu):
     """rules_strings.json: the REAL reference's gen_split_mask with other combo matrices installed; the fused kernel's
-    rule-table interpreter must reproduce its boundaries (no oracle involved)."""
+    rule-table interpreter must reproduce its boundaries AND its values (no oracle involved) -- through every input form:
+    UTF-32, UTF-8 in byte space, PEP 393 kind 1 / kind 2 units, each as a small batch (pinned path) and as a batch large
+    enough for the tile kernels of that form (k_tiles_main<kModeRules / BytesRules / Latin1Rules / Ucs2Rules / ValuesRules>)."""
     from latok_amd import batch
     try:
         for rs in _golden("rules_strings.json")["sets"]:
             batch.set_rules(np.array(rs["c_split"], np.int8), np.array(rs["c_mask"], np.int8), np.array(rs["c_sym"], np.int8))
             texts = [_text_of(it["cps"]) for it in rs["items"]]
+            splits = [np.array(it["splits"], np.uint8) for it in rs["items"]]
+            nz = [np.nonzero(v)[0] for v in splits]
             offs = batch.split_offsets_batch(texts)
-            for o, it in zip(offs, rs["items"]):
-                assert o.tolist() == np.nonzero(np.array(it["splits"]))[0].tolist(), rs["name"]
+            for o, e in zip(offs, nz):
+                assert o.tolist() == e.tolist(), rs["name"]
+            reps = max(1, 300_000 // max(1, sum(len(t) for t in texts))) + 1
+            for k in (1, reps):          # small (pinned path) and large (tile kernels)
+                tx, sp, zz = texts * k, splits * k, nz * k
+                cps, row = pack(tx)
+                # the VALUES gen_split_mask returns under these tables (default_tokenizer.py:121-132)
+                assert np.array_equal(batch.split_values_batch(cps, row), np.concatenate(sp)), (rs["name"], k, "values")
+                c, o = batch.split_offsets_csr(cps, row)
+                assert np.array_equal(o, np.concatenate(zz)) and c.tolist() == [len(z) for z in zz], (rs["name"], k, "utf32")
+                # UTF-8 in byte space: the same boundaries at the byte positions of their chars
+                blobs = [t.encode("utf-8", "surrogatepass") for t in tx]
+                u8, boff = batch.pack_utf8(blobs)
+                bpos = [np.cumsum([0] + [len(ch.encode("utf-8", "surrogatepass")) for ch in t]) for t in texts] * k
+                c, o = batch.split_offsets_utf8_bytes_csr(u8, boff)
+                assert o.tolist() == [int(bp[v]) for z, bp in zip(zz, bpos) for v in z], (rs["name"], k, "utf8 bytes")
+                bits = batch.split_mask_utf8_bytes_csr(u8, boff)
+                assert int(sum(bin(int(w)).count("1") for w in bits)) == sum(len(z) for z in zz)
+                # PEP 393 units: the strings that fit the kind
+                for kind, limit, enc, dt in ((1, 0x100, "latin-1", np.uint8), (2, 0x10000, "utf-16-le", np.uint16)):
+                    sel = [i for i, t in enumerate(tx) if all(ord(ch) < limit for ch in t)]
+                    if not sel:
+                        continue
+                    units = np.frombuffer("".join(tx[i] for i in sel).encode(enc, "surrogatepass"), dt)
+                    urow = np.zeros(len(sel) + 1, np.int64)
+                    np.cumsum([len(tx[i]) for i in sel], out=urow[1:])
+                    c, o = batch.split_offsets_kind_csr(units, urow)
+                    assert o.tolist() == [int(v) for i in sel for v in zz[i]], (rs["name"], k, "kind", kind)
     finally:
         batch.reset_rules()
 
@@ -749,8 +779,29 @@ def test_runtime_rule_tables(gpu, oracle, name):
                     batch.reset_rules()
                     assert np.array_equal(batch.split_mask_batch(cps, row), want)
                     batch.set_rules(*tables)
-            with pytest.raises(ValueError):
-                batch.split_values_batch(*pack(["abc"]))   # per-term values exist for the built-in tables only
+            # the VALUES under custom tables (rows that hold, times the mask, plus C_SYM rows), small and large batches
+            for texts in (["abc", "a #b c@d.e http://x/y Z"], random_strings(rng, 400, 500, 900, ALPHABETS["mixed"])):
+                cps, row = pack(texts)
+                want_v = np.concatenate([oracle.split_values_rules(t, *tables).astype(np.uint8) for t in texts])
+                assert np.array_equal(batch.split_values_batch(cps, row), want_v), (name, rep, "values")
+            # byte space and PEP 393 units, batches beyond the small-batch path
+            texts = random_strings(rng, 500, 300, 900, ALPHABETS["mixed"] + list("éЖ日🤓"))
+            flags = [oracle.split_values_rules(t, *tables) != 0 for t in texts]
+            blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+            u8, boff = batch.pack_utf8(blobs)
+            c, o = batch.split_offsets_utf8_bytes_csr(u8, boff)
+            want_o = []
+            for t, f in zip(texts, flags):
+                bp = np.cumsum([0] + [len(ch.encode("utf-8", "surrogatepass")) for ch in t])
+                want_o += [int(bp[i]) for i in np.nonzero(f)[0]]
+            assert o.tolist() == want_o, (name, rep, "utf8 bytes")
+            for kind_alpha, enc, dt in (("latin1", "latin-1", np.uint8), ("bmp", "utf-16-le", np.uint16)):
+                texts = random_strings(rng, 500, 300, 900, ALPHABETS[kind_alpha])
+                units = np.frombuffer("".join(texts).encode(enc, "surrogatepass"), dt)
+                urow = np.zeros(len(texts) + 1, np.int64)
+                np.cumsum([len(t) for t in texts], out=urow[1:])
+                c, o = batch.split_offsets_kind_csr(units, urow)
+                assert o.tolist() == [int(i) for t in texts for i in np.nonzero(oracle.split_values_rules(t, *tables))[0]], (name, rep, kind_alpha)
     finally:
         batch.reset_rules()
     assert not batch.rules_active()
@@ -763,7 +814,7 @@ def test_runtime_rule_tables_are_validated(gpu):
     from latok_amd import batch
     s, m, y = DEFAULT_RULES
     for bad in [(np.array([[25]], np.int8), m, y), (s, np.array([[-1, 3]], np.int8), y), (s, m, np.array([[-2]], np.int8)),
-                (np.zeros((17, 1), np.int8), m, y)]:
+                (np.zeros((33, 1), np.int8), m, y)]:
         with pytest.raises(ValueError):
             batch.set_rules(*bad)
         assert not batch.rules_active()

@@ -196,6 +196,19 @@ def main():
                 assert np.array_equal(bo, np.concatenate(exp_b)), "byte offsets differ: " + tag
                 cb, crow = batch.split_mask_utf8_csr(u8, boff)
                 assert np.array_equal(crow, row) and np.array_equal(cb, bits), "code-point UTF-8 path differs: " + tag
+                if rules is not None:
+                    # run-time rule tables in byte space (k_tiles_main<kModeBytesRules>) and through the code-point UTF-8 path
+                    rflags = np.zeros(u8.size, bool)
+                    rflags[bpos[np.unpackbits(rule_bits.view(np.uint8), bitorder="little")[:cps.size].astype(bool)]] = True
+                    batch.set_rules(*rules)
+                    try:
+                        rbb = batch.split_mask_utf8_bytes_csr(u8, boff)
+                        rcb, _ = batch.split_mask_utf8_csr(u8, boff)
+                    finally:
+                        batch.reset_rules()
+                    got = np.unpackbits(rbb.view(np.uint8), bitorder="little")[:u8.size].astype(bool)
+                    assert np.array_equal(got, rflags), "byte-space rule-table bitmask differs: " + tag
+                    assert np.array_equal(rcb, rule_bits), "code-point UTF-8 rule-table bitmask differs: " + tag
                 n_u8 += 1
             n_batches += 1
             n_chars += cps.size

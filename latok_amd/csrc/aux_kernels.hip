@@ -364,6 +364,21 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t
     int tot;
     const int excl = block_exclusive_scan_int(__popc(leads), &tot, lds);
     if (p < total) chunk_pref[chunk] = (uint16_t)excl;
+    // bytes p+16 .. p+18 (what a sequence that starts in my last bytes may need): the next thread's first dword, taken
+    // while every lane is active; the last lane of a wave reads them from memory.  A byte that does not exist reads as 0xFF
+    // ("not a continuation byte": the sequence is truncated -> U+FFFD).
+    uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    if ((threadIdx.x & 63) == 63) {
+        nx = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int64_t q = p + 16 + i;
+            if (q < total) nx |= (uint32_t)u8[q] << (8 * i);
+        }
+    }
+    {
+        const int64_t have = total - (p + 16);                        // bytes that exist behind my chunk
+        nx |= have >= 3 ? 0xFF000000u : (have <= 0 ? 0xFFFFFFFFu : (0xFFFFFFFFu << (8 * (int)have)));
+    }
     if (leads) {
         uint32_t* dst = out_s + excl;
         if (((v.x | v.y | v.z | v.w) & 0x80808080u) == 0) {
@@ -377,20 +392,48 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t
                 dst[4 * j + 3] = w4[j] >> 24;
             }
         } else {
-            // bytes p .. p+18: the chunk plus the 3 bytes a sequence that starts in its last byte may need
-            uint32_t w[5] = {v.x, v.y, v.z, v.w, 0x80808080u};
-            uint32_t nx = 0;
-            for (int i = 0; i < 3; ++i) {
-                const int64_t q = p + 16 + i;
-                nx |= (uint32_t)(q < total ? u8[q] : 0xFFu) << (8 * i);   // 0xFF = "not a continuation byte"
+            // A mixed chunk.  ASCII lead bytes are their own code points; only the NON-ASCII leads are decoded -- two
+            // branch-free slots per dword (well-formed UTF-8 has at most two multi-byte leads in 4 bytes; more: the loop
+            // below), as in the byte-space tile kernel (split_kernels.hip: bytes_phase1).  A lead's place in the output is
+            // its rank among the chunk's leads.  (The old form decoded all 16 positions with the branchy utf8_decode_at:
+            // 554 us for the 471 MB of C3.)
+            // bytes p+16 .. p+18: the next thread's first dword; the last lane of a wave reads them from memory
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx};
+            uint32_t rest[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t hi = d[q] & 0x80808080u;
+                const uint32_t nl = hi & (d[q] << 1);                     // 11xxxxxx: the leads that need a decode
+                // ASCII leads of the dword
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = 4 * q + r;
+                    const uint32_t b = (d[q] >> (8 * r)) & 0xFFu;
+                    if (b < 0x80u && ((leads >> k) & 1u)) dst[__popc(leads & ((1u << k) - 1u))] = b;
+                }
+                uint32_t m = nl;
+#pragma unroll
+                for (int slot = 0; slot < 2; ++slot) {
+                    const uint32_t r = ((uint32_t)__builtin_ctz(m | 0x80000000u) >> 3) & 3u;
+                    const uint32_t cp = utf8_cp_of(__builtin_amdgcn_alignbyte(w[q + 1], w[q], r));
+                    const uint32_t k = 4u * q + r;
+                    if (m) dst[__popc(leads & ((1u << k) - 1u))] = cp;
+                    m &= m - 1u;
+                }
+                rest[q] = m;
             }
-            w[4] = nx | 0xFF000000u;
-            int k = 0;
-#define LATOK_U8_AT(I) if (leads & (1u << I)) dst[k++] = utf8_decode_at<I>(w);
-            LATOK_U8_AT(0) LATOK_U8_AT(1) LATOK_U8_AT(2) LATOK_U8_AT(3) LATOK_U8_AT(4) LATOK_U8_AT(5) LATOK_U8_AT(6)
-            LATOK_U8_AT(7) LATOK_U8_AT(8) LATOK_U8_AT(9) LATOK_U8_AT(10) LATOK_U8_AT(11) LATOK_U8_AT(12) LATOK_U8_AT(13)
-            LATOK_U8_AT(14) LATOK_U8_AT(15)
-#undef LATOK_U8_AT
+            while ((rest[0] | rest[1] | rest[2] | rest[3]) != 0u) {       // malformed input only
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (rest[q]) {
+                        const uint32_t r = ((uint32_t)__builtin_ctz(rest[q]) >> 3) & 3u;
+                        const uint32_t k = 4u * q + r;
+                        dst[__popc(leads & ((1u << k) - 1u))] = utf8_cp_of(__builtin_amdgcn_alignbyte(w[q + 1], w[q], r));
+                        rest[q] &= rest[q] - 1u;
+                    }
+                }
+            }
         }
     }
     __syncthreads();

@@ -34,6 +34,21 @@ __device__ __forceinline__ uint32_t utf8_decode_bytes(uint32_t b0, uint32_t b1, 
     return utf8_decode_at<0>(w);
 }
 
+// Code point of the multi-byte sequence whose lead byte (>= 0xC0) is the LOW byte of W (W = 4 bytes in memory order).
+// Branch-free restatement of utf8_decode_at (utf8_decode.h): a truncated sequence yields U+FFFD, "surrogatepass" and
+// overlong forms decode as they are, 0xF8..0xFF count as 4-byte leads with 3 payload bits.
+__device__ __forceinline__ uint32_t utf8_cp_of(uint32_t W) {
+    const uint32_t b0 = W & 0xFFu;
+    const uint32_t X = (((W >> 8) & 0x3Fu) << 12) | (((W >> 16) & 0x3Fu) << 6) | ((W >> 24) & 0x3Fu);   // payload of bytes 1..3
+    // pure arithmetic on the sequence length n = 2, 3, 4 (selects between three forms end up as divergent control flow,
+    // and that serialises the table lookups of the slots of a row)
+    const uint32_t n = 2u + (uint32_t)(b0 >= 0xE0u) + (uint32_t)(b0 >= 0xF0u);
+    const uint32_t sh = 24u - 6u * n;                                   // payload bits of bytes 1..3 that are not used
+    const uint32_t cp = ((b0 & (0x7Fu >> n)) << (18u - sh)) | (X >> sh);
+    const uint32_t notc = (W ^ 0x80808000u) & 0xC0C0C000u;            // byte j != 0  <=>  byte j is not 10xxxxxx
+    const uint32_t need = (0xC0C0C000u >> (32u - 8u * n)) & 0xFFFFFF00u;
+    return (notc & need) ? 0xFFFDu : cp;
+}
 // bit i of the result = byte i of the dword is a lead byte ((b & 0xC0) != 0x80)
 __device__ __forceinline__ uint32_t utf8_lead_nibble(uint32_t w) {
     const uint32_t cont = (w & 0x80808080u) & ~((w << 1) & 0x80808080u);   // top bits "10"

@@ -422,24 +422,28 @@ __device__ __forceinline__ void counts_scatter_block(
                 const uint64_t bl = o_Bw & ((2ull << b) - 1ull);      // string starts at or before the item (b = 63: all)
                 const int64_t lo = bl ? obase + 63 - __builtin_clzll(bl) : o_lo_in;
                 {
-                    // token [p, e): e = next boundary; stripped extent [a2, e2)
-                    const uint64_t above = o_xb & (~1ull << b);
+                    // token [p, e): e = next boundary; stripped extent [a2, e2).  The 64 positions from the item on, taken out
+                    // of the 128-bit pair (owner word, next word): one form whether the token ends in its own word or in the
+                    // next one (two divergent branches before, and some lane of 64 nearly always crosses a word)
+                    const uint64_t X = (o_xb >> b) | ((o_xb1 << 1) << (63 - b));     // boundaries at p, p+1, ..
+                    const uint64_t N = (o_nn >> b) | ((o_nn1 << 1) << (63 - b));     // non-SPACE chars at p, p+1, ..
+                    const uint64_t after = X & ~1ull;
                     int64_t a2, e2;
-                    if (above) {                                    // everything inside the owner word
-                        const int eb = __builtin_ctzll(above);
-                        const uint64_t seg = o_nn & (~0ull << b) & ((1ull << eb) - 1ull);   // kept => seg != 0
-                        a2 = obase + __builtin_ctzll(seg);
-                        e2 = obase + 64 - __builtin_clzll(seg);
-                    } else if (o_xb1) {                             // ends at the first boundary of the next word
-                        const int eb = __builtin_ctzll(o_xb1);
+                    if (after) {                                    // the token ends within 64 chars (kept => seg != 0)
+                        const uint64_t seg = N & (((after & (~after + 1ull)) - 1ull));
+                        const int64_t p = obase + b;
+                        a2 = p + __builtin_ctzll(seg);
+                        e2 = p + 64 - __builtin_clzll(seg);
+                    } else if (o_xb1 & ~((1ull << b) - 1ull)) {     // (rare) longer: ends at a boundary of the next word beyond p + 63
+                        const int eb = __builtin_ctzll(o_xb1 & ~((1ull << b) - 1ull));
                         const uint64_t seg0 = o_nn & (~0ull << b);
-                        const uint64_t seg1 = o_nn1 & ((1ull << eb) - 1ull);     // eb < 64: bit eb is set in xb1
+                        const uint64_t seg1 = o_nn1 & ((1ull << eb) - 1ull);
                         a2 = seg0 ? obase + __builtin_ctzll(seg0) : obase + 64 + __builtin_ctzll(seg1);
                         e2 = seg1 ? obase + 128 - __builtin_clzll(seg1) : obase + 64 - __builtin_clzll(seg0);
-                    } else {
-                        const int64_t e = next_set_bit(bits, obase + 64, total);
+                    } else {                                        // (rare) no boundary up to the end of the next word
+                        const int64_t e = next_set_bit(bits, obase + 128, total);
                         const uint64_t seg = o_nn & (~0ull << b);
-                        a2 = seg ? obase + __builtin_ctzll(seg) : next_zero_bit(space, obase + 64, e);
+                        a2 = seg ? obase + __builtin_ctzll(seg) : (o_nn1 ? obase + 64 + __builtin_ctzll(o_nn1) : next_zero_bit(space, obase + 128, e));
                         e2 = prev_zero_end(space, a2, e);
                     }
                     typedef OUT out2 __attribute__((ext_vector_type(2)));

@@ -130,12 +130,12 @@ def main():
             lambda: 4 * total + csr + 4 * n + 8 * nout.value, "4 B/char + 8 B/string read; 4 B/string counts + 8 B/token written (LATOK_OUT_INT32)")
     if "features32" in paths:
         run("features32", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D32, None),
-            lambda: 2 * 4 * total + csr + 4 * n + (16 + 25) * nout.value,
-            "4 B/char read twice + 8 B/string; 4 B/string + 41 B/token written (LATOK_OUT_INT32)")
+            lambda: 4 * total + csr + 4 * n + (16 + 25) * nout.value,
+            "SURVEY 8f-2 accounting: 4 B/char + 8 B/string read (the input ONCE); 4 B/string + 41 B/token written (LATOK_OUT_INT32)")
     if "features" in paths:
         run("features", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D, None),
-            lambda: 2 * 4 * total + csr + 8 * n + (32 + 25) * nout.value,
-            "4 B/char read twice (mask, then per-token sums) + 8 B/string; 8 B/string + 57 B/token written")
+            lambda: 4 * total + csr + 8 * n + (32 + 25) * nout.value,
+            "SURVEY 8f-2 accounting: 4 B/char + 8 B/string read (the input ONCE); 8 B/string + 57 B/token written")
     if "utf8_mask" in paths:
         nout.value = 0
         run("utf8_mask", lambda: lib.latok_split_mask_utf8_batch(d_u8, d_boff, n, n8, d_bits, words + 1, d_cprow, C.byref(tcp), D, None),

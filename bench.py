@@ -5,11 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W                        # one process per GPU (gloo carries the barriers)
 
-Without a launcher (WORLD_SIZE unset) the N ranks are N library contexts (latok_ctx_create(device)) driven by N host
-threads of this process -- the product's own way of using a node (include/latok_hip.h "contexts"): every
-string is independent, so there is no collective on the data path, RCCL is not linked and torch is not imported.
-`--devices 0,0 [--take-turns]` rehearses N ranks on fewer GPUs.  Under a launcher every process is one rank and
-torch.distributed (gloo) is used for the barriers and the gather of the per-rank records only.
+Without a launcher (WORLD_SIZE unset) bench.py starts the N ranks itself.  N > 1: one child PROCESS per GPU, spawned before
+this process has touched a GPU; each child owns one library context on its device, the children meet at a gate in shared
+memory (latok_gate_create_shared), the parent collects their records and prints the line.  Every rank then has a HIP
+runtime of its own -- exactly the N = 1 run, N times -- so nothing in one rank's launch path can wait for another's
+(3 launches per 0.1 ms step and GPU: N host threads of ONE process would share the runtime's locks; `--launch threads` runs
+that form: N contexts (latok_ctx_create(device)) + N host threads, the product's in-process way of using a node,
+include/latok_hip.h "contexts").  Every string is independent, so there is no collective on the data path,
+RCCL is not linked and torch is not imported.  `--devices 0,0 [--take-turns]` rehearses N ranks on fewer GPUs.  Under a
+launcher every process is one rank and torch.distributed (gloo) is used for the barriers and the gather of the records only.
 
 A "step" is one pass of the whole pipeline (tile index -> fused tiles kernel -> resolve/repair) over one batch of
 synthetic strings that is already resident in HBM.  Default workload at every N = BASELINE.json configs[1] per GPU
@@ -530,6 +534,14 @@ def parse_args(argv=None):
                     help="under torchrun only: what carries the barriers and the gather of the report.  The data path has no "
                          "collective and RCCL is not linked, so there is nothing for an RCCL backend to do")
     ap.add_argument("--device", type=int, default=-1, help="under torchrun only: HIP device of this rank (default LOCAL_RANK mod device count)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "procs", "threads"],
+                    help="without a launcher, how the N ranks run: procs = one child PROCESS per GPU, spawned by this script before "
+                         "it touches a GPU (every rank has a HIP runtime of its own: nothing in one rank's launch path can wait "
+                         "for another's), threads = N contexts + N host threads in this process; auto = procs for N > 1")
+    ap.add_argument("--child-rank", type=int, default=-1, help=argparse.SUPPRESS)      # set by the parent of --launch procs
+    ap.add_argument("--child-gate", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--child-lock", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--child-api", default="", help=argparse.SUPPRESS)               # tests: module:factory of a fake device layer
     ap.add_argument("--take-turns", action="store_true",
                     help="rehearsal on shared GPU(s): the ranks run their timed regions one after the other, so each rank's "
                          "time is what a GPU of its own would give; the line is marked as a rehearsal and carries no `value`")
@@ -554,13 +566,115 @@ def pick_devices(args, n_dev):
     return devices
 
 
+class _FileLock:
+    """--take-turns across processes: one flock for every GPU phase"""
+
+    def __init__(self, path):
+        self.path, self.f = path, None
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(self.path, "a+")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+def child_main(args, api):
+    """One rank of --launch procs: this process owns ONE GPU.  Rank 0 creates the shared-memory gate, the others attach; the
+    record goes to stdout as one line for the parent."""
+    rank, world = args.child_rank, args.gpus
+    devices = [int(x) for x in args.devices.split(",")]
+    lib = api.lib
+    gate = C.c_void_p()
+    name = args.child_gate.encode()
+    if rank == 0:
+        api.check(lib.latok_gate_create_shared(name, world, C.byref(gate)))
+    else:
+        t_end = time.time() + 60.0
+        while lib.latok_gate_attach_shared(name, C.byref(gate)) != 0:      # rank 0 has not created it yet
+            if time.time() > t_end:
+                raise RuntimeError("rank %d: the gate %s never appeared" % (rank, args.child_gate))
+            time.sleep(0.01)
+    try:
+        n_dev = api.device_count()
+        if devices[rank] < 0 or devices[rank] >= n_dev:
+            raise RuntimeError(f"device {devices[rank]} not present ({n_dev} HIP device(s) visible); use --devices "
+                               f"(a device may repeat) to rehearse --gpus {world} on fewer GPUs")
+        ctx = api.context(devices[rank])
+        ctx.make_current()
+        phase = (lambda: _FileLock(args.child_lock)) if args.take_turns else _NoLock
+        rec = measure_shard(Shard(api, args, rank, world), args, gate, phase)
+        lib.latok_ctx_set_current(None)
+        ctx.destroy()
+        print("LATOK_BENCH_REC " + json.dumps(rec), flush=True)
+        return 0
+    except BaseException:
+        lib.latok_gate_break(gate)     # the other ranks fail at their next wait instead of sitting out the timeout
+        raise
+    finally:
+        lib.latok_gate_detach_shared(gate)
+
+
+def run_processes(args, devices, argv, spawn=None):
+    """N > 1 without a launcher, one child process per GPU.  The parent has NOT touched a GPU (nor loaded the library) when
+    it spawns them -- a process that has initialised the GPU must not start other programs on this pool -- and never does
+    afterwards either, except for host-only calls (CPU baseline, unlinking the gate)."""
+    import subprocess
+    import tempfile
+    world = len(devices)
+    gate_name = "/latok_bench_%d_%d" % (os.getpid(), int(time.time() * 1e3) & 0xFFFFFF)
+    lock = tempfile.NamedTemporaryFile(prefix="latok_bench_lock_", delete=False)
+    lock.close()
+    base = [a for a in (argv if argv is not None else sys.argv[1:])]
+    cmd0 = [sys.executable, os.path.abspath(__file__)] + base + ["--devices", ",".join(map(str, devices)), "--child-gate", gate_name,
+                                                                   "--child-lock", lock.name, "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    spawn = spawn or (lambda cmd: subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    procs = [spawn(cmd0 + ["--child-rank", str(r)]) for r in range(world)]
+    outs = [p.communicate() for p in procs]
+    try:
+        os.unlink(lock.name)
+    except OSError:
+        pass
+    lib = _lib.load()                      # (after the children are gone)
+    lib.latok_gate_unlink_shared(gate_name.encode())
+    recs, errors = [None] * world, []
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        line = [ln for ln in so.splitlines() if ln.startswith("LATOK_BENCH_REC ")]
+        if p.returncode == 0 and line:
+            recs[r] = json.loads(line[-1][len("LATOK_BENCH_REC "):])
+        else:
+            errors.append((r, p.returncode, (se.strip().splitlines() or ["(no output)"])[-1]))
+    if errors:
+        errors.sort(key=lambda e: "gate: broken" in e[2])       # the root cause first
+        r, rc, msg = errors[0]
+        raise SystemExit(f"bench.py: rank {r} (device {devices[r]}) failed with exit code {rc}: {msg}")
+    return recs
+
+
+def load_api(spec):
+    """tests only: 'module:factory' of a fake device layer for the children of --launch procs"""
+    import importlib
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr)()
+
+
 def main(argv=None, api=None, out=None):
     args = parse_args(argv)
-    api = api or RealApi()
+    if args.child_rank >= 0:              # one rank of --launch procs
+        return child_main(args, api or (load_api(args.child_api) if args.child_api else RealApi()))
     env_world = os.environ.get("WORLD_SIZE", "")
     dist = None
+    rank = 0
     if env_world != "" and int(env_world) > 1:
         # started by a launcher, one process per GPU (python -m torch.distributed.run ... bench.py --gpus N)
+        api = api or RealApi()
         rank, world, local_rank = int(os.environ.get("RANK", "0")), int(env_world), int(os.environ.get("LOCAL_RANK", "0"))
         if world != args.gpus:
             if rank == 0:
@@ -568,9 +682,17 @@ def main(argv=None, api=None, out=None):
             sys.exit(2)
         recs, dist = run_under_launcher(api, args, rank, world, local_rank)
         mode, devices, same_start = f"one process per GPU (launcher, {args.dist_backend} for barriers only)", None, False
+    elif args.gpus > 1 and args.launch in ("auto", "procs") and api is None:
+        # no launcher, N > 1: one child process per GPU, spawned before this process touches a GPU
+        devices = [int(x) for x in args.devices.split(",") if x != ""] if args.devices else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit(f"bench.py: --devices lists {len(devices)} devices for --gpus {args.gpus}")
+        recs = run_processes(args, devices, argv)
+        mode = "one process per GPU, spawned by bench.py (no launcher, no torch, no RCCL; shared-memory gate)"
+        same_start = not args.take_turns
     else:
-        # no launcher: N contexts + N host threads in THIS process (also for N = 1)
-        rank = 0
+        # N contexts + N host threads in THIS process (N = 1; --launch threads)
+        api = api or RealApi()
         devices = pick_devices(args, api.device_count())
         recs = run_in_process(api, args, devices)
         mode, same_start = "one process, one context + host thread per GPU (no launcher, no torch, no RCCL)", not args.take_turns

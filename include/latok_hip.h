@@ -288,6 +288,13 @@ int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int 
 typedef struct latok_gate latok_gate;
 int latok_gate_create(int parties, latok_gate** gate_out);
 int latok_gate_destroy(latok_gate* gate);
+/* The same rendezvous for one PROCESS per GPU: the gate lives in POSIX shared memory under `name` ("/something").  One
+ * process creates it, the others attach; every process detaches when done and one of them unlinks the name.  The host's
+ * monotonic clock is one clock for all processes of the machine, so t0 / t1 of latok_bench_split_mask_gated compare. */
+int latok_gate_create_shared(const char* name, int parties, latok_gate** gate_out);
+int latok_gate_attach_shared(const char* name, latok_gate** gate_out);
+int latok_gate_detach_shared(latok_gate* gate);
+int latok_gate_unlink_shared(const char* name);
 int latok_gate_wait(latok_gate* gate, double timeout_s);
 int latok_gate_break(latok_gate* gate);
 int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,

@@ -78,6 +78,10 @@ SIGNATURES = {
     "latok_gate_destroy": (ci, [vp]),
     "latok_gate_wait": (ci, [vp, C.c_double]),
     "latok_gate_break": (ci, [vp]),
+    "latok_gate_create_shared": (ci, [C.c_char_p, ci, C.POINTER(vp)]),
+    "latok_gate_attach_shared": (ci, [C.c_char_p, C.POINTER(vp)]),
+    "latok_gate_detach_shared": (ci, [vp]),
+    "latok_gate_unlink_shared": (ci, [C.c_char_p]),
     "latok_bench_split_mask_gated": (ci, [vp, vp, i64, i64, vp, ci, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)]),
 }
 

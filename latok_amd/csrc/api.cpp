@@ -4,10 +4,14 @@
 // sequence of the pipeline (tile index -> tiles -> resolve/repair).  No compute happens on the
 // host and there is no CPU fallback: without a HIP device every compute entry point fails.
 #include <hip/hip_runtime.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1896,6 +1900,36 @@ int latok_gate_create(int parties, latok_gate** gate_out) {
 }
 int latok_gate_destroy(latok_gate* gate) {
     delete gate;
+    return LATOK_OK;
+}
+static int gate_map_shared(const char* name, bool create, int parties, latok_gate** gate_out) {
+    if (!name || name[0] != '/' || !gate_out) return fail(LATOK_ERR_INVALID, "gate: shared name must start with '/'");
+    const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) return fail(LATOK_ERR_INVALID, "gate: shm_open(%s) failed: %s", name, strerror(errno));
+    if (create && ftruncate(fd, (off_t)sizeof(latok_gate)) != 0) {
+        close(fd);
+        shm_unlink(name);
+        return fail(LATOK_ERR_NOMEM, "gate: ftruncate failed: %s", strerror(errno));
+    }
+    void* p = mmap(nullptr, sizeof(latok_gate), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(LATOK_ERR_NOMEM, "gate: mmap failed: %s", strerror(errno));
+    latok_gate* g = create ? new (p) latok_gate : reinterpret_cast<latok_gate*>(p);
+    if (create) g->parties = parties;
+    *gate_out = g;
+    return LATOK_OK;
+}
+int latok_gate_create_shared(const char* name, int parties, latok_gate** gate_out) {
+    if (parties < 1) return fail(LATOK_ERR_INVALID, "gate: parties must be >= 1");
+    return gate_map_shared(name, true, parties, gate_out);
+}
+int latok_gate_attach_shared(const char* name, latok_gate** gate_out) { return gate_map_shared(name, false, 0, gate_out); }
+int latok_gate_detach_shared(latok_gate* gate) {
+    if (gate) munmap(gate, sizeof(latok_gate));
+    return LATOK_OK;
+}
+int latok_gate_unlink_shared(const char* name) {
+    if (name) shm_unlink(name);
     return LATOK_OK;
 }
 int latok_gate_break(latok_gate* gate) {

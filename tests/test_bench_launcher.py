@@ -249,3 +249,44 @@ def test_without_a_gpu_the_driver_spelling_fails_loudly_not_with_a_usage_error()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "HIP device(s) visible" in p.stderr and "launch one rank per GPU" not in p.stderr
+
+
+def fake_api():
+    """factory for the children of `bench.py --launch procs --child-api test_bench_launcher:fake_api`"""
+    return FakeApi(n_dev=8, ms_per_pass=3.0)
+
+
+def _run_procs(extra, timeout=180):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, env.get("PYTHONPATH", "")])
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--child-api", "test_bench_launcher:fake_api"] + BASE + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_process_per_gpu_launch_is_the_default_for_n_gt_1():
+    """`python3 bench.py --gpus N` with no launcher: the script spawns one child process per GPU itself (before it touches a
+    GPU), the children meet at a gate in shared memory and the parent prints the ONE line.  Device layer faked in the
+    children; processes, gate, clocks and the line are real."""
+    p = _run_procs(["--gpus", "3"])
+    assert p.returncode == 0, p.stderr[-1500:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["config"]["devices"] == [0, 1, 2] and "spawned by bench.py" in line["config"]["launch"]
+    assert line["config"]["strings_total"] == 6000 and len(line["ms_per_rank"]) == 3 == len(line["roofline"]["frac_per_rank"])
+    # gated start across processes (one monotonic clock per host): the job took about one rank's time
+    assert line["start_skew_us"] is not None and line["start_skew_us"] < 50_000
+    assert line["ms_per_step"] * 5 < 1.6 * max(line["ms_per_rank_wall"]) * 5
+    assert line["value"] == pytest.approx(line["config"]["utf8_bytes_total"] * 5 / (line["ms_per_step"] * 5 / 1e3) / 1e9, rel=1e-6)
+
+
+def test_process_per_gpu_take_turns_and_failure():
+    p = _run_procs(["--gpus", "2", "--devices", "0,0", "--take-turns"])
+    assert p.returncode == 0, p.stderr[-1500:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["value"] is None and line["value_projected"] > 0 and line["config"]["devices"] == [0, 0]
+    # a rank whose device does not exist: the job fails quickly and says which rank and why
+    t = time.time()
+    p = _run_procs(["--gpus", "2", "--devices", "0,11"])
+    assert p.returncode != 0 and "rank 1 (device 11)" in p.stderr and "not present" in p.stderr
+    assert time.time() - t < 60

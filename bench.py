@@ -283,7 +283,9 @@ class Shard:
         ms, t0, t1 = C.c_float(0), C.c_int64(0), C.c_int64(0)
         self.api.check(self.lib.latok_bench_split_mask_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, steps, gate,
                                                              C.byref(ms), C.byref(t0), C.byref(t1)))
-        return {"ms_events": float(ms.value), "t0_ns": int(t0.value), "t1_ns": int(t1.value)}
+        used_graph = getattr(self.lib, "latok_debug_bench_used_graph", None)
+        return {"ms_events": float(ms.value), "t0_ns": int(t0.value), "t1_ns": int(t1.value),
+                "graph": bool(used_graph()) if used_graph is not None else False}
 
     def kernel_only(self, steps):
         """the dominant kernel alone: `steps` back-to-back launches of k_tiles_main between one HIP event pair"""
@@ -364,6 +366,8 @@ def run_in_process(api, args, devices):
     gate inside the library, so the timed regions start within microseconds of each other whatever the interpreter does.
     No torch, no RCCL: the shards are independent."""
     world = len(devices)
+    if world > 1 and not args.take_turns:
+        os.environ.setdefault("LATOK_BENCH_GRAPH", "1")   # N launching threads in one process: replay the K passes as one hipGraph
     gate = C.c_void_p()
     api.check(api.lib.latok_gate_create(world, C.byref(gate)))
     turn_lock = threading.Lock()
@@ -495,6 +499,7 @@ def build_line(args, recs, mode, devices, same_start):
         "ms_per_rank": [r["ms_events"] / K for r in recs],
         "ms_per_rank_wall": [w / K * 1e3 for w in walls],
         "start_skew_us": (max(r["t0_ns"] for r in recs) - min(r["t0_ns"] for r in recs)) / 1e3 if same_start else None,
+        "timed_region_launches": "one hipGraph replay of the K passes per rank" if all(r.get("graph") for r in recs) else "3 kernel launches per pass",
         "sustained": r0["sustained"],
         "fix_tiles_rank0": r0["n_fix"], "tiles_rank0": (r0["total"] + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
         "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,

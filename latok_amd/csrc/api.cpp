@@ -1962,10 +1962,16 @@ static inline int64_t mono_ns() {
     return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static thread_local int tl_bench_used_graph = 0;
+/* measurement aid (not part of the ABI in include/latok_hip.h): 1 when this thread's last latok_bench_split_mask_gated replayed
+ * a captured hipGraph (LATOK_BENCH_GRAPH=1 and the capture succeeded), 0 when it launched the passes one by one */
+int latok_debug_bench_used_graph(void) { return tl_bench_used_graph; }
+
 int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total,
                                  uint64_t* mask_dev, int iters, latok_gate* gate, float* ms_events_out, int64_t* t0_ns_out,
                                  int64_t* t1_ns_out) {
     LATOK_ENTER();
+    tl_bench_used_graph = 0;
     int rc = need_init(g);
     if (rc) return rc;
     if (iters < 1) return fail(LATOK_ERR_INVALID, "iters must be >= 1");
@@ -1973,12 +1979,49 @@ int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off
     StreamTurn turn(g, nullptr);
     hipStream_t st = turn.st;
     if ((rc = resolve_total_device(row_off_dev, n_str, &total, st))) return rc;
+    // LATOK_BENCH_GRAPH=1 (bench.py --launch threads, N > 1): the K passes are captured into ONE hipGraph outside the
+    // timed region and replayed by one call inside it -- with N host threads of one process launching 3 kernels per 0.1 ms
+    // step each, the threads would otherwise meet in the runtime's launch path.  Same kernels, same order, same stream.
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    {
+        const char* e = getenv("LATOK_BENCH_GRAPH");
+        if (e && e[0] == '1') {
+            // (the workspaces are sized by the caller's warm-up passes; one eager pass here makes sure of it: nothing may
+            // allocate during a capture)
+            if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                for (int i = 0; i < iters && !rc; ++i)
+                    rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st);
+                hipError_t ce = hipStreamEndCapture(st, &graph);
+                if (!rc && ce == hipSuccess && graph) ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+                if (rc || ce != hipSuccess || !gexec) {      // no graph on this runtime: the eager form below
+                    if (gexec) (void)hipGraphExecDestroy(gexec);
+                    if (graph) (void)hipGraphDestroy(graph);
+                    graph = nullptr;
+                    gexec = nullptr;
+                    rc = LATOK_OK;
+                    (void)hipGetLastError();
+                }
+            }
+        }
+    }
     HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = latok_gate_wait(gate, 120.0))) return rc;
+    if ((rc = latok_gate_wait(gate, 120.0))) {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
     const int64_t t0 = mono_ns();
     HIP_TRY(hipEventRecord(g.ev[0], st));
-    for (int i = 0; i < iters; ++i)
-        if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) break;
+    if (gexec) {
+        tl_bench_used_graph = 1;
+        if (hipGraphLaunch(gexec, st) != hipSuccess) rc = fail(LATOK_ERR_HIP, "hipGraphLaunch failed");
+    } else {
+        for (int i = 0; i < iters; ++i)
+            if ((rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, mask_dev, nullptr, latok::kModeBits, st))) break;
+    }
     if (!rc) {
         hipError_t e = hipEventRecord(g.ev[1], st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1986,6 +2029,8 @@ int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off
     }
     const int64_t t1 = mono_ns();
     const int rc_gate = latok_gate_wait(gate, 120.0);   // also on failure: the other threads must not wait for this one
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
     if (rc) return rc;
     if (rc_gate) return rc_gate;
     float ms = 0.f;

@@ -55,6 +55,7 @@ sys.path.insert(0, ROOT)
 from latok_amd import _lib  # noqa: E402
 
 GATE_TIMEOUT_S = 900.0
+CHILD_TIMEOUT_S = 1500.0   # --launch procs: a rank that has not finished by then is killed (its own process handle)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 WORKLOADS = {
@@ -642,7 +643,14 @@ def run_processes(args, devices, argv, spawn=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     spawn = spawn or (lambda cmd: subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     procs = [spawn(cmd0 + ["--child-rank", str(r)]) for r in range(world)]
-    outs = [p.communicate() for p in procs]
+    outs, deadline = [], time.time() + CHILD_TIMEOUT_S
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                       # (this child, by its own handle: never by pattern)
+            so, se = p.communicate()
+            outs.append((so, (se or "") + f"\nbench.py: rank killed after {CHILD_TIMEOUT_S:.0f} s"))
     try:
         os.unlink(lock.name)
     except OSError:

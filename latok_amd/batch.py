@@ -458,6 +458,53 @@ def tokenize_batch(texts, devices=None):
     return out
 
 
+class TokenSpans:
+    """The tokens of a batch WITHOUT the per-token Python objects: ``spans[k] = (start, end)`` of token k inside its own
+    string (whitespace stripped, empties dropped -- what the reference's loop keeps, default_tokenizer.py:149-160),
+    ``counts[i]`` tokens for string i, strings in order.  Building ``list[list[str]]`` costs one slice per token (1.5 ms per
+    1000 short strings, five orders of magnitude below the device path); a caller that filters, counts, hashes or looks only
+    at some strings slices lazily:
+
+        ts = batch.token_spans_batch(texts)
+        ts.counts, ts.spans                     # numpy: int32 / int64 [n_str], [n_tokens, 2]
+        ts.tokens(i)                            # list[str] of string i, sliced on demand
+        for toks in ts: ...                     # == batch.tokenize_batch(texts), one string at a time
+    """
+
+    def __init__(self, texts, counts, spans):
+        self.texts, self.counts, self.spans = texts, counts, spans
+        self.first = np.zeros(len(texts) + 1, np.int64)       # index of each string's first token
+        np.cumsum(counts, out=self.first[1:])
+
+    def __len__(self):
+        return len(self.texts)
+
+    def row(self, i):
+        """(start, end) pairs of string i: a view into ``spans``"""
+        return self.spans[int(self.first[i]):int(self.first[i + 1])]
+
+    def tokens(self, i):
+        t = self.texts[i]
+        return [t[a:b] for a, b in self.row(i).tolist()]
+
+    def __iter__(self):
+        return (self.tokens(i) for i in range(len(self.texts)))
+
+
+def token_spans_batch(texts):
+    """list[str] -> TokenSpans: the same device work as tokenize_batch, none of its per-token Python."""
+    texts = list(texts)
+    if len(texts) == 0:
+        return TokenSpans(texts, np.zeros(0, np.int64), np.zeros((0, 2), np.int64))
+    if _narrow_pays(texts):
+        units, row_off = pack_kind(texts)
+        counts, spans = token_spans_kind_csr(units, row_off, dtype=_record_dtype(row_off))
+    else:
+        cps, row_off = pack(texts)
+        counts, spans = token_spans_csr(cps, row_off, dtype=_record_dtype(row_off))
+    return TokenSpans(texts, counts, spans.reshape(-1, 2))
+
+
 # ---- runtime rule tables (the reference's extension point, default_tokenizer.py:9-30,108-110) ------------------------
 def _rule_table(name, idx):
     """A combo matrix as build_combo_matrix returns it -> C-contiguous int8 [rows, cols].  A 1-D index vector means

@@ -133,6 +133,13 @@ def tokenize(text: str):
         yield ''
 
 
+def tokenize_spans(texts):
+    """Additive: the tokens of a whole list of strings as spans (``latok_amd.batch.TokenSpans``: counts, (start, end) pairs,
+    lazy ``tokens(i)``) -- the same result as ``[list(tokenize(t)) for t in texts]`` without one Python object per token."""
+    _sync_rules()
+    return _batch.token_spans_batch(texts)
+
+
 def featurize(text: str):
     """Yield the tokens of ``text`` as ``LaToken`` with their summed feature vectors
     (reference default_tokenizer.py:163-191), computed on the device without building the n x 25 matrix.

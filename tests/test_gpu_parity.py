@@ -390,6 +390,11 @@ def test_token_spans_on_device(gpu, oracle):
         random_strings(rng, 300, 0, 120, ALPHABETS["mixed"]) + random_strings(rng, 50, 0, 400, ALPHABETS["words"]) + \
         random_strings(rng, 3, 5000, 20000, ALPHABETS["mixed"]) + random_strings(rng, 100, 0, 30, list("ab \t\n"))
     got = batch.tokenize_batch(texts)
+    # the span form of the same call (no per-token Python objects): identical tokens, lazily sliced
+    ts = batch.token_spans_batch(texts)
+    assert len(ts) == len(texts) and int(ts.counts.sum()) == len(ts.spans) and list(ts) == got
+    from latok_amd.core import default_tokenizer as dtk
+    assert list(dtk.tokenize_spans(texts[:20])) == got[:20]
     for t, g in zip(texts, got):
         want = oracle.tokenize(t) if t else []
         assert g == want, (t[:80], g[:10], want[:10])

@@ -20,6 +20,7 @@ m = dt._gen_parse_matrix(text)
 timeit("gen_split_mask(m) [compat kernels]", lambda: dt.gen_split_mask(m), 100)
 texts = [text] * 1000
 timeit("tokenize_batch(1000 strings)", lambda: batch.tokenize_batch(texts), 20)
+timeit("token_spans_batch(1000 strings): spans, no per-token str", lambda: batch.token_spans_batch(texts), 20)
 # the C call alone (arrays prebuilt): what a C / Cython caller of the ABI pays per string
 import ctypes as C
 from latok_amd import _lib

@@ -62,10 +62,12 @@ __device__ __forceinline__ uint32_t classify1(const uint8_t* t1, const uint8_t* 
     return t2[(blk << kTblShift) | (cp & ((1u << kTblShift) - 1u))];
 }
 
-__device__ __forceinline__ uint32_t classify4(const uint8_t* t1, const uint8_t* t2, u32x4 v) {
+__device__ __forceinline__ uint32_t classify4(const uint8_t* t1, const uint8_t* t2, u32x4 v, bool* not_ascii = nullptr) {
     uint32_t c;
     // wave-uniform fast path: all 256 chars of this wave instruction are ASCII -> stage-2 block 0, no stage-1 lookup
-    if (__all((v.x | v.y | v.z | v.w) < 128u)) {
+    const bool ascii = __all((v.x | v.y | v.z | v.w) < 128u);
+    if (not_ascii && !ascii) *not_ascii = true;
+    if (ascii) {
         c = (uint32_t)t2[v.x] | ((uint32_t)t2[v.y] << 8) | ((uint32_t)t2[v.z] << 16) | ((uint32_t)t2[v.w] << 24);
     } else {
         c = classify1(t1, t2, v.x) | (classify1(t1, t2, v.y) << 8) | (classify1(t1, t2, v.z) << 16) |
@@ -826,12 +828,27 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     return out_word;
 }
 
+// UTF-32 bitmask mode: the first R rows (1 KiB each) of the wave's NEXT tile are requested into registers right
+// before phase 2 of the current one, so that the wave has loads in flight while it computes.  The wait counts are explicit
+// (a vmcnt(0) on every path in front of the requests; the pass that inserts waits otherwise drains the queue at the first
+// register it loses track of, and the prefetch silently does nothing).  Measured on C2, same box, twice: kernel 96.1-96.3 ->
+// 94.4-94.5 us with R = 2 (R = 1: 93.9-94.1, R = 4: 95-99), step 106.6-107.3 -> 105.0-105.1; C3 / C4 / C5 within their noise
+// (profiles/r03_ab_headline_prefetch.txt).  -DLATOK_AB_CPS_PREFETCH=0: off.
+#ifndef LATOK_AB_CPS_PREFETCH
+#define LATOK_AB_CPS_PREFETCH 2
+#endif
+struct CpsPrefetch {
+    u32x4 v[LATOK_AB_CPS_PREFETCH > 0 ? LATOK_AB_CPS_PREFETCH : 1];
+    bool valid;
+};
+
 template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
                                              int tail_zero, bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
                                              , unsigned long long* stamp_acc = nullptr
 #endif
+                                             , CpsPrefetch* pf = nullptr, int64_t t_next = -1
                                              ) {
 #ifdef LATOK_STAMPS
     unsigned long long stamp_prev = 0, stamp_dummy[16];
@@ -842,6 +859,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     const uint32_t st_lane = 4u * lane + 16u * ((uint32_t)lane >> 4);   // stage_addr(4 lane); row i adds 320 i
     bool raw_stage = mode_base(MODE) == kModeLatin1;   // the staging buffer holds raw bytes, not codes (Latin-1; all-ASCII tiles of byte mode)
     bool ascii_tile = false;                // ... and every one of them is ASCII (wave-uniform)
+    bool tile_not_ascii = false;            // UTF-32: some row of the tile took the two-stage lookup (wave-uniform)
     LATOK_STAMP(0);
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
@@ -921,14 +939,19 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = src[64 * i];
 #else
+        constexpr int R = LATOK_AB_CPS_PREFETCH;
+        const bool pre = R > 0 && pf && pf->valid;      // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = __builtin_nontemporal_load(src + 64 * i);
+        for (int i = 0; i < 16; ++i) {
+            if (i < R && pre) v[i] = pf->v[i < R ? i : 0];
+            else v[i] = __builtin_nontemporal_load(src + 64 * i);
+        }
 #endif
         LATOK_STAMP(1);
         uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;   // wave-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const uint32_t c = classify4(L.t1, L.t2, v[i]);
+            const uint32_t c = classify4(L.t1, L.t2, v[i], &tile_not_ascii);
             *reinterpret_cast<uint32_t*>(L.stage + st_lane + 320u * i) = c;   // == stage_addr(256 i + 4 lane)
             if (codes) codes[64 * i] = c;                                     // 256 contiguous bytes per wave instruction
         }
@@ -967,6 +990,23 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     wave_lds_sync();
 #endif
     LATOK_STAMP(3);
+#if LATOK_AB_CPS_PREFETCH > 0
+    if (MODE == kModeBits && pf) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load of this tile has been consumed -- said on every path
+        pf->valid = false;
+#ifdef LATOK_AB_CPS_PREFETCH_ASCII_ONLY
+        const bool want = !tile_not_ascii;    // non-ASCII tiles (two LDS lookups per char in phase 1) measured slower with it
+#else
+        const bool want = true;
+#endif
+        if (want && t_next >= 0 && (t_next + 1) * kTile <= total) {
+            const u32x4* nsrc = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
+#pragma unroll
+            for (int i = 0; i < LATOK_AB_CPS_PREFETCH; ++i) pf->v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
+            pf->valid = true;
+        }
+    }
+#endif
 
     return tile_phase2<MODE, DEFER, SMALL>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage, ascii_tile
 #ifdef LATOK_STAMPS
@@ -1247,8 +1287,16 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
         if (++slot == 8) flush();
     };
+#if LATOK_AB_CPS_PREFETCH > 0
+    CpsPrefetch pf;
+    pf.valid = false;
+#endif
     for (int k = wave, j = 0; k < n_seg; k += WPB, ++j) {
-        const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG);
+        const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG
+#if LATOK_AB_CPS_PREFETCH > 0
+                                                                      , MODE == kModeBits && !FAST_TAIL ? &pf : nullptr, k + WPB < n_seg ? T0 + k + WPB : (int64_t)-1
+#endif
+                                                                      );
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
         stamp_acc[0] += 1;

@@ -24,8 +24,13 @@ same corpus (string ids rank*1M ...) -> "scaling": "weak".  The other workloads:
     C5   configs[4]  10 K documents x 1 M chars, split over the N ranks (strong; 40 GB resident at N = 1)
 
 Timing: W untimed warm-up steps, then EXACTLY K steps.  The timed region of a rank is ONE library call
-(latok_bench_split_mask_gated): rendezvous of all ranks -> host monotonic clock -> HIP event -> K passes -> HIP event ->
-stream synchronise -> host clock -> rendezvous.  `value` = UTF-8 bytes of all ranks x K / whole-job WALL time (in
+(latok_bench_split_mask_flow_gated / latok_bench_split_mask_gated): rendezvous of all ranks -> host monotonic clock -> HIP
+event -> K passes -> HIP event -> stream(s) synchronise -> host clock -> rendezvous.  By default the K passes go through the
+product's batch flow (include/latok_hip.h "batch flow", `--in-flight 2`): consecutive batches alternate between two streams,
+two workspaces and two output bitmasks, so the string-index and resolve launches of one batch run in the shadow of the other
+batch's tile kernel; every pass still runs all three kernels and every result is complete when the clock stops.  The same K
+steps one batch at a time (`--in-flight 1`, what earlier rounds reported as `value`) are timed right after and ride along as
+`serial`.  `value` = UTF-8 bytes of all ranks x K / whole-job WALL time (in
 process: last rank out - first rank in, one clock; under a launcher: max over ranks of the rank's wall time).  The
 HIP-event time of the same K steps rides along (`ms_per_step_events`, `value_events`, `ms_per_rank`); round 2 reported
 that one as `value` (0.7-2 % higher), round 1 and this round the wall time, as the contract reads.
@@ -251,7 +256,8 @@ class Shard:
         else:
             self.sid0, self.n_str = split_string_ids(args.strings or n_default, rank, world)
         self.total = self.utf8 = 0
-        self.d_row = self.d_cps = self.d_bits = None
+        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = None
+        self.flow = args.in_flight >= 2
 
     def build(self):
         """the shard directly in HBM: offsets on the host (8 B/string), code points generated on the device"""
@@ -263,7 +269,9 @@ class Shard:
         self.d_row = lib.latok_dev_alloc(row.nbytes)
         self.d_cps = lib.latok_dev_alloc(self.total * 4)
         self.d_bits = lib.latok_dev_alloc(((self.total + 63) // 64) * 8)
-        if not (self.d_row and self.d_cps and self.d_bits):
+        # two batches in flight write two bitmasks (consecutive steps alternate between them)
+        self.d_bits2 = lib.latok_dev_alloc(((self.total + 63) // 64) * 8) if self.flow else None
+        if not (self.d_row and self.d_cps and self.d_bits and (self.d_bits2 or not self.flow)):
             raise RuntimeError(self.api.last_error())
         chk(lib.latok_memcpy_h2d(self.d_row, row.ctypes.data, row.nbytes))
         chk(lib.latok_corpus_fill_device(seed, model, self.sid0, self.n_str, self.d_row, self.d_cps, None))
@@ -278,10 +286,23 @@ class Shard:
                                                            None, None, None))
         self.api.check(self.lib.latok_sync())
 
-    def timed(self, steps, gate):
+    def warmup_flow(self, n):
+        if self.flow and n > 0:
+            ms, t0, t1 = C.c_float(0), C.c_int64(0), C.c_int64(0)
+            self.api.check(self.lib.latok_bench_split_mask_flow_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits,
+                                                                      self.d_bits2, n, None, C.byref(ms), C.byref(t0), C.byref(t1)))
+
+    def timed(self, steps, gate, flow=None):
         """EXACTLY `steps` pipeline passes: gate -> host clock -> HIP event -> passes -> HIP event -> stream sync -> host
-        clock -> gate, all inside one library call (no interpreter between the clocks)"""
+        clock -> gate, all inside one library call (no interpreter between the clocks).  flow: the passes go through the
+        batch flow (latok_flow_split_mask: two batches in flight, alternating between two output bitmasks), every pass
+        still launches all three kernels and completes inside the region."""
+        flow = self.flow if flow is None else flow
         ms, t0, t1 = C.c_float(0), C.c_int64(0), C.c_int64(0)
+        if flow:
+            self.api.check(self.lib.latok_bench_split_mask_flow_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits,
+                                                                      self.d_bits2, steps, gate, C.byref(ms), C.byref(t0), C.byref(t1)))
+            return {"ms_events": float(ms.value), "t0_ns": int(t0.value), "t1_ns": int(t1.value), "graph": False}
         self.api.check(self.lib.latok_bench_split_mask_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, steps, gate,
                                                              C.byref(ms), C.byref(t0), C.byref(t1)))
         used_graph = getattr(self.lib, "latok_debug_bench_used_graph", None)
@@ -302,12 +323,18 @@ class Shard:
         while done < want:
             k = min(2000, want - done)
             ms = C.c_float(0)
-            self.api.check(self.lib.latok_bench_split_mask(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, 0, k,
-                                                           C.byref(ms), None, None))
+            if self.flow:
+                t0, t1 = C.c_int64(0), C.c_int64(0)
+                self.api.check(self.lib.latok_bench_split_mask_flow_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits,
+                                                                          self.d_bits2, k, None, C.byref(ms), C.byref(t0), C.byref(t1)))
+                ms = C.c_float((t1.value - t0.value) / 1e6)   # wall: the event pair sits on two streams
+            else:
+                self.api.check(self.lib.latok_bench_split_mask(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, 0, k,
+                                                               C.byref(ms), None, None))
             chunks.append(ms.value / k)
             t_ms += ms.value
             done += k
-        return {"steps": done, "seconds": t_ms / 1e3, "ms_per_step": t_ms / done,
+        return {"steps": done, "seconds": t_ms / 1e3, "ms_per_step": t_ms / done, "in_flight": 2 if self.flow else 1,
                 "value": self.utf8 * done / (t_ms / 1e3) / 1e9, "unit": "GB/s (rank 0)",
                 "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1]}
 
@@ -321,10 +348,10 @@ class Shard:
         return nbytes / (ms.value / 20 / 1e3) / 1e9 if ms.value > 0 else None
 
     def free(self):
-        for p in (self.d_row, self.d_cps, self.d_bits):
+        for p in (self.d_row, self.d_cps, self.d_bits, self.d_bits2):
             if p:
                 self.lib.latok_dev_free(p)
-        self.d_row = self.d_cps = self.d_bits = None
+        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = None
 
     def alg_read(self):
         return 4 * self.total + 8 * (self.n_str + 1)   # 4 B/code point + 8 B/string row offset
@@ -337,12 +364,19 @@ def measure_shard(sh, args, gate, phase):
     lib, chk = sh.lib, sh.api.check
     sh.build()
     sh.warmup(args.warmup)
+    sh.warmup_flow(args.warmup)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
     with phase():
         rec = sh.timed(args.steps, None if args.take_turns else gate)
+    serial = None
+    if sh.flow:   # the same K steps one batch at a time (what `value` was before the batch flow), beside the headline
+        chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
+        with phase():
+            serial = sh.timed(args.steps, None if args.take_turns else gate, flow=False)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
     with phase():
         k_ms, n_fix = sh.kernel_only(args.steps)
+    rec["serial"] = serial
     rec.update(rank=sh.rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                sustained=None, measured_read=None)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
@@ -435,12 +469,19 @@ def run_under_launcher(api, args, rank, world, local_rank):
         sh = Shard(api, args, rank, world)
         sh.build()
         sh.warmup(args.warmup)
+        sh.warmup_flow(args.warmup)
         dist.barrier()
         with _Barrier("timed"):
             rec = sh.timed(args.steps, None)
+        serial = None
+        if sh.flow:
+            dist.barrier()
+            with _Barrier("timed-serial"):
+                serial = sh.timed(args.steps, None, flow=False)
         dist.barrier()
         with _Barrier("kernel"):
             k_ms, n_fix = sh.kernel_only(args.steps)
+        rec["serial"] = serial
         rec.update(rank=rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                    sustained=None, measured_read=None)
         dist.barrier()
@@ -474,6 +515,16 @@ def build_line(args, recs, mode, devices, same_start):
     else:
         job_s = max(walls)
     ev_max = max(r["ms_events"] for r in recs) / 1e3
+    flow = all(r.get("serial") for r in recs)
+    serial = None
+    if flow:   # the same K steps, one batch at a time on one stream
+        sr = [r["serial"] for r in recs]
+        s_job = ((max(x["t1_ns"] for x in sr) - min(x["t0_ns"] for x in sr)) / 1e9 if same_start
+                 else max((x["t1_ns"] - x["t0_ns"]) / 1e9 for x in sr))
+        serial = {"ms_per_step": s_job / K * 1e3, "value": utf8_all * K / s_job / 1e9,
+                  "ms_per_rank": [x["ms_events"] / K for x in sr],
+                  "what": "the same K steps with ONE batch in flight (index -> tiles -> resolve back to back on one stream): "
+                          "`value` of rounds 1-3 before the batch flow"}
     fracs = [r["alg_read"] / (r["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs]
     worst = min(range(world), key=lambda i: fracs[i])
     r0 = recs[0]
@@ -491,8 +542,13 @@ def build_line(args, recs, mode, devices, same_start):
                    "chars_total": sum(r["total"] for r in recs), "utf8_bytes_total": utf8_all,
                    "sharding": f"{world} x independent contiguous string-id shards, no collective on the data path",
                    "launch": mode, "devices": devices},
+        "in_flight": 2 if flow else 1,
+        "in_flight_note": ("batch flow (latok_flow_split_mask): step i+1 is submitted while step i runs, on a second stream with its own "
+                           "workspace and its own output bitmask; every step launches all three kernels and is complete when the "
+                           "clock stops; `serial` = the same K steps one at a time") if flow else "one batch at a time",
+        "serial": serial,
         "timing": ("host monotonic clock, inputs resident in HBM: every rank's region = [gate ->] clock -> K pipeline passes -> "
-                   "stream synchronise -> clock inside one library call; value = bytes of all ranks x K / "
+                   "stream(s) synchronise -> clock inside one library call; value = bytes of all ranks x K / "
                    + ("(last rank out - first rank in)" if same_start else "max over ranks of the rank's own wall time")
                    + "; the HIP-event time of the same K steps rides along as ms_per_step_events / value_events"),
         "ms_per_step_events": ev_max / K * 1e3,
@@ -500,7 +556,8 @@ def build_line(args, recs, mode, devices, same_start):
         "ms_per_rank": [r["ms_events"] / K for r in recs],
         "ms_per_rank_wall": [w / K * 1e3 for w in walls],
         "start_skew_us": (max(r["t0_ns"] for r in recs) - min(r["t0_ns"] for r in recs)) / 1e3 if same_start else None,
-        "timed_region_launches": "one hipGraph replay of the K passes per rank" if all(r.get("graph") for r in recs) else "3 kernel launches per pass",
+        "timed_region_launches": ("one hipGraph replay of the K passes per rank" if all(r.get("graph") for r in recs)
+                                  else "3 kernel launches per pass" + (", passes alternating between two streams" if flow else "")),
         "sustained": r0["sustained"],
         "fix_tiles_rank0": r0["n_fix"], "tiles_rank0": (r0["total"] + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
         "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -521,6 +578,9 @@ def build_line(args, recs, mode, devices, same_start):
         line["ms_per_step_projected"] = proj / K * 1e3
         line["value"] = None
         line["ms_per_step"] = None
+        if serial:
+            serial["value"] = serial["ms_per_step"] = None
+            serial["ms_per_step_projected"] = max((x["t1_ns"] - x["t0_ns"]) / 1e9 for x in sr) / K * 1e3
     return line
 
 
@@ -548,12 +608,18 @@ def parse_args(argv=None):
     ap.add_argument("--child-gate", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-lock", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-api", default="", help=argparse.SUPPRESS)               # tests: module:factory of a fake device layer
+    ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
+                    help="batches in flight per GPU in the timed region: 2 = the batch flow (latok_flow_split_mask; default), "
+                         "1 = one batch at a time; 0 = 2, except 1 for N > 1 host threads in one process (--launch threads)")
     ap.add_argument("--take-turns", action="store_true",
                     help="rehearsal on shared GPU(s): the ranks run their timed regions one after the other, so each rank's "
                          "time is what a GPU of its own would give; the line is marked as a rehearsal and carries no `value`")
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus and --steps must be >= 1, --warmup >= 0")
+    if args.in_flight == 0:
+        threads_n = args.gpus > 1 and args.launch == "threads" and args.child_rank < 0 and not args.take_turns
+        args.in_flight = 1 if threads_n else 2
     return args
 
 

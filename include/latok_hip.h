@@ -256,6 +256,22 @@ int latok_set_rules(const int8_t* c_split, int split_rows, int split_cols, const
 int latok_reset_rules(void);   /* back to the built-in default_tokenizer.py tables */
 int latok_rules_active(void);  /* 1 while custom tables are installed */
 
+/* ---- batch flow: many device-resident batches through one context, overlapped -------------------------------------------
+ * The reference tokenizes one string after another (default_tokenizer.py:137-160: every call is independent of the one
+ * before).  Here a batch costs three dependent launches (per-tile string index, tiles, resolve); only the tile kernel needs
+ * the whole GPU.  A flow keeps up to TWO batches in flight on the current context -- every stage on its own stream, every
+ * batch in flight with its own workspace -- so that the string index of batch i+1 runs beside the tile kernel of batch i
+ * and the resolve stage of batch i beside the tile kernel of batch i+1 (C2: 0.108 -> ~0.097 ms per batch).
+ *   latok_flow_split_mask: enqueue latok_split_mask_batch(LATOK_DEVICE_PTRS) of one batch and return.  The inputs must be
+ *     complete in device memory when the call is made (they are NOT ordered behind work on any caller stream), and must stay
+ *     untouched until latok_flow_wait.  total_chars < 0: read from row_off (one small synchronous copy).  Consecutive
+ *     batches should write different mask buffers; a batch that writes the buffer of a batch still in flight simply waits
+ *     for it (correct, not overlapped).  Results are bit-identical to latok_split_mask_batch.
+ *   latok_flow_wait: block until every batch submitted on the current context is complete (latok_sync does the same). */
+int latok_flow_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                          uint64_t* mask_dev);
+int latok_flow_wait(void);
+
 /* ---- measurement ----------------------------------------------------------------------------------------------- */
 /* Run latok_split_mask_batch on device-resident data: `warmup` untimed passes, then
  *   ms_total_out  = elapsed ms of `iters` whole-pipeline passes (tile index, tiles, resolve) between ONE pair of HIP events
@@ -300,6 +316,13 @@ int latok_gate_break(latok_gate* gate);
 int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                                  uint64_t* mask_dev, int iters, latok_gate* gate, float* ms_events_out,
                                  int64_t* t0_ns_out, int64_t* t1_ns_out);
+/* The same timed region through the batch flow: `iters` latok_flow_split_mask submissions of the batch, writing mask_a_dev
+ * and mask_b_dev alternately (two buffers of ceil(total_chars / 64) words), then latok_flow_wait -- every pass does all
+ * three launches and completes inside the region.  ms_events_out: from an event in front of the first string-index launch
+ * to one behind the last resolve launch. */
+int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                                      uint64_t* mask_a_dev, uint64_t* mask_b_dev, int iters, latok_gate* gate,
+                                      float* ms_events_out, int64_t* t0_ns_out, int64_t* t1_ns_out);
 
 #ifdef __cplusplus
 }

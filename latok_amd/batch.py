@@ -506,6 +506,22 @@ def token_spans_batch(texts):
 
 
 # ---- runtime rule tables (the reference's extension point, default_tokenizer.py:9-30,108-110) ------------------------
+# ---- batch flow: many device-resident batches through the current context, two in flight ------------------------------
+def flow_split_mask(d_cps, d_row_off, n_str, total_chars, d_mask):
+    """include/latok_hip.h "batch flow": enqueue the split mask of one DEVICE-RESIDENT batch (device addresses as ints /
+    c_void_p: UTF-32 code points, int64 row offsets, uint64 mask words out) and return at once; up to two batches run
+    overlapped (the string-index and resolve launches of one in the shadow of the other's tile kernel).  The inputs must
+    be complete in device memory; results are complete after ``flow_wait()``.  The reference's unit of independence is
+    the single ``tokenize`` call (default_tokenizer.py:137-160)."""
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_flow_split_mask(d_cps, d_row_off, int(n_str), int(total_chars), d_mask))
+
+
+def flow_wait():
+    """Block until every batch submitted with ``flow_split_mask`` on the current context is complete."""
+    _lib.check(_lib.ensure_init().latok_flow_wait())
+
+
 def _rule_table(name, idx):
     """A combo matrix as build_combo_matrix returns it -> C-contiguous int8 [rows, cols].  A 1-D index vector means
     "sum of those feature rows" to _combine_matrix_rows (latok.c:340-353): one single-column row per entry."""

@@ -179,6 +179,18 @@ struct Ctx {
     bool chain_ready = false;
     unsigned chain_seen = 0, chain_ctl_seen = 0;   // DevBuf::gen of the allocations the state was last cleared in
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // batch flow (latok_flow_*): up to kFlowSlots device-resident batches in flight, each with its own stream and workspace
+    struct FlowSlot {
+        DevBuf summ, seg_agg, fix_count, tile_first;
+        hipStream_t st = nullptr;
+        bool used = false;
+        const void* out = nullptr;       // the mask buffer the slot's last batch writes
+    };
+    static constexpr int kFlowSlots = 4;
+    FlowSlot flow[kFlowSlots];
+    int flow_slots = 2;                  // slots in use (LATOK_FLOW_SLOTS, A/B)
+    bool flow_ready = false;
+    unsigned long long flow_seq = 0;     // batches submitted so far
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
     bool turn_stream_valid = false;
@@ -204,15 +216,19 @@ struct DeviceGuard {
     std::lock_guard<std::mutex> lk(g.mu);    \
     DeviceGuard device_guard_(g)
 
+static size_t ws_summ_bytes(int64_t n_tiles) { return (size_t)(n_tiles > 0 ? n_tiles : 1) * 16; }
+// one Fn64 + Hd64 pair per segment; plan_segments never makes a segment shorter than kWPB tiles (unless it is the
+// only one), so n_segs <= t / kWPB + 1
+static size_t ws_seg_bytes(int64_t n_tiles) {
+    return ((size_t)(n_tiles > 0 ? n_tiles : 1) / latok::kWPB + 2) * (sizeof(latok::Fn64) + sizeof(latok::Hd64));
+}
+static size_t ws_first_bytes(int64_t n_tiles) { return (size_t)(n_tiles > 0 ? n_tiles : 1) * 8 + 8; }   // per-tile string index (stage 0)
 int ensure_workspace(Ctx& g, int64_t n_tiles) {
-    const size_t t = (size_t)(n_tiles > 0 ? n_tiles : 1);
     int rc;
-    if ((rc = g.summ.ensure(t * 16))) return rc;
-    // one Fn64 + Hd64 pair per segment; plan_segments never makes a segment shorter than kWPB tiles (unless it is the
-    // only one), so n_segs <= t / kWPB + 1
-    if ((rc = g.seg_agg.ensure((t / latok::kWPB + 2) * (sizeof(latok::Fn64) + sizeof(latok::Hd64))))) return rc;
+    if ((rc = g.summ.ensure(ws_summ_bytes(n_tiles)))) return rc;
+    if ((rc = g.seg_agg.ensure(ws_seg_bytes(n_tiles)))) return rc;
     if ((rc = g.fix_count.ensure(8))) return rc;
-    if ((rc = g.tile_first.ensure(t * 8 + 8))) return rc;   // per-tile string index (stage 0)
+    if ((rc = g.tile_first.ensure(ws_first_bytes(n_tiles)))) return rc;
     return LATOK_OK;
 }
 
@@ -253,7 +269,8 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
                  const int* bm_flags = nullptr, uint64_t* d_space = nullptr, int64_t* d_tile_first = nullptr,
                  const uint8_t* d_u8 = nullptr, int unit_kind = 0, int stages = 7,   // stages: 1 = tile index, 2 = tiles, 4 = resolve
                  uint8_t* d_codes = nullptr,     // d_codes: also leave the rule code of every char (featurize)
-                 latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr}) {   // completion word stored by the last launch
+                 latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr},   // completion word stored by the last launch
+                 Ctx::FlowSlot* slot = nullptr) {   // the workspace of a batch-flow slot instead of the context's own
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
@@ -264,7 +281,11 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     // run-time rule tables (latok_set_rules): the same input form, rules interpreted from the kernel arguments
     if (g.rules_on && mode != latok::kModeBlockMask) mode = latok::mode_with_rules(mode);
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
-    int rc = ensure_workspace(g, n_tiles);
+    DevBuf& w_summ = slot ? slot->summ : g.summ;
+    DevBuf& w_seg = slot ? slot->seg_agg : g.seg_agg;
+    DevBuf& w_fix = slot ? slot->fix_count : g.fix_count;
+    DevBuf& w_first = slot ? slot->tile_first : g.tile_first;
+    int rc = slot ? LATOK_OK : ensure_workspace(g, n_tiles);   // (a flow slot is sized by flow_submit before anything is enqueued)
     if (rc) return rc;
     latok::SplitParams P;
     P.cps = d_cps;
@@ -281,7 +302,7 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
         P.seg_tiles = (int)(n_tiles < latok::kOneSegTiles ? latok::kOneSegTiles : n_tiles);
         P.n_segs = 1;
     }
-    if ((size_t)P.n_segs * (sizeof(latok::Fn64) + sizeof(latok::Hd64)) > g.seg_agg.cap || (size_t)n_tiles * 16 > g.summ.cap)
+    if ((size_t)P.n_segs * (sizeof(latok::Fn64) + sizeof(latok::Hd64)) > w_seg.cap || (size_t)n_tiles * 16 > w_summ.cap)
         return fail(LATOK_ERR_INVALID, "internal: workspace too small for %lld segments / %lld tiles", (long long)P.n_segs, (long long)n_tiles);
     if (d_codes && mode != latok::kModeBits && mode != latok::kModeRules)
         return fail(LATOK_ERR_INVALID, "internal: code bytes are written by the UTF-32 bitmask modes only");
@@ -295,12 +316,12 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.values_out = d_values;
     P.space_out = d_space;
     P.codes_out = d_codes;
-    if (!d_tile_first) d_tile_first = (int64_t*)g.tile_first.p;   // the per-tile string index lives in the workspace
+    if (!d_tile_first) d_tile_first = (int64_t*)w_first.p;   // the per-tile string index lives in the workspace
     P.tile_first = d_tile_first;
-    P.summ = (int4*)g.summ.p;
-    P.seg_fn = (latok::Fn64*)g.seg_agg.p;
-    P.seg_hd = (latok::Hd64*)((char*)g.seg_agg.p + (size_t)P.n_segs * sizeof(latok::Fn64));
-    P.fix_count = (int64_t*)g.fix_count.p;
+    P.summ = (int4*)w_summ.p;
+    P.seg_fn = (latok::Fn64*)w_seg.p;
+    P.seg_hd = (latok::Hd64*)((char*)w_seg.p + (size_t)P.n_segs * sizeof(latok::Fn64));
+    P.fix_count = (int64_t*)w_fix.p;
     P.bm_a1 = bm_a1;
     P.bm_a2 = bm_a2;
     P.bm_flags = bm_flags;
@@ -441,6 +462,18 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
         }
     }
     g.pipe_tot.release();
+    for (auto& f : g.flow) {
+        if (f.st) {
+            (void)hipStreamSynchronize(f.st);
+            (void)hipStreamDestroy(f.st);
+        }
+        f.st = nullptr;
+        for (DevBuf* b : {&f.summ, &f.seg_agg, &f.fix_count, &f.tile_first}) b->release();
+        f.used = false;
+        f.out = nullptr;
+    }
+    g.flow_ready = false;
+    g.flow_seq = 0;
     if (g.s_h2d) (void)hipStreamDestroy(g.s_h2d);
     if (g.s_d2h) (void)hipStreamDestroy(g.s_d2h);
     g.s_h2d = g.s_d2h = nullptr;
@@ -1719,12 +1752,13 @@ int latok_memset_dev(void* d, int v, size_t n) {
     HIP_TRY(hipMemsetAsync(d, v, n, g.stream));
     return LATOK_OK;
 }
+static int flow_drain(Ctx& g);   // batch flow (below): its three streams
 int latok_sync(void) {
     LATOK_ENTER();
     int rc = need_init(g);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(g.stream));
-    return LATOK_OK;
+    return flow_drain(g);
 }
 int latok_device_props(int* n_cu, int64_t* hbm_bytes, char* name_out, int name_cap) {
     LATOK_ENTER();
@@ -1807,6 +1841,82 @@ extern "C" int latok_debug_host_decode_utf8(const uint8_t* utf8, const int64_t* 
     memcpy(bytepos_out, pos.data(), pos.size() * 8);
     *n_cps_out = (int64_t)cps.size();
     return 1;
+}
+
+
+// ---- batch flow: several device-resident batches in flight on one context --------------------------------------------
+// A batch is three dependent launches (string index, tiles, resolve) and only the tile kernel fills the chip; back to back on
+// one stream the two latency-bound launches and the three kernel boundaries cost 11-14 us of a 108 us step on C2.  A flow
+// gives every batch in flight its own stream and workspace (two slots, used in turn) and NO dependency between the streams:
+// the tile kernel of batch i+1 takes over the CUs as the workgroups of batch i retire, and the small launches of one stream
+// run in the shadow of the other stream's tile kernel.  (Measured first: one stream per STAGE with events between them, so that
+// the tile kernels stay strictly back to back -- 115-120 us per step, slower than serial: an inter-queue event wait costs more
+// than the launch it hides.)
+static int flow_setup(Ctx& g) {
+    if (g.flow_ready) return LATOK_OK;
+    const char* e = getenv("LATOK_FLOW_SLOTS");
+    g.flow_slots = e ? atoi(e) : 2;
+    if (g.flow_slots < 1) g.flow_slots = 1;
+    if (g.flow_slots > Ctx::kFlowSlots) g.flow_slots = Ctx::kFlowSlots;
+    for (int i = 0; i < g.flow_slots; ++i) {
+        Ctx::FlowSlot& f = g.flow[i];
+        if (!f.st) HIP_TRY(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
+    }
+    g.flow_ready = true;
+    return LATOK_OK;
+}
+static int flow_drain(Ctx& g) {
+    if (!g.flow_ready) return LATOK_OK;
+    for (int i = 0; i < g.flow_slots; ++i) HIP_TRY(hipStreamSynchronize(g.flow[i].st));
+    for (int i = 0; i < g.flow_slots; ++i) g.flow[i].used = false;   // nothing in flight: no mask buffer is being written
+    return LATOK_OK;
+}
+static int flow_submit(Ctx& g, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask) {
+    int rc = flow_setup(g);
+    if (rc) return rc;
+    if (n_str <= 0 || total <= 0) return LATOK_OK;
+    if (!cps || !row_off || !mask) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    if (((uintptr_t)cps & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
+    // slots are used in turn -- except that a batch which writes the mask buffer of a batch still in flight goes to THAT
+    // batch's slot, whose stream orders the two (callers that alternate buffers never hit this; an event per batch to order
+    // such pairs across streams would cost every batch ~3 us)
+    Ctx::FlowSlot* fp = &g.flow[g.flow_seq % (unsigned)g.flow_slots];
+    for (int i = 0; i < g.flow_slots; ++i)
+        if (g.flow[i].used && g.flow[i].out == (const void*)mask) fp = &g.flow[i];
+    Ctx::FlowSlot& f = *fp;
+    // a slot that has to grow is reallocated only once nothing in flight can still use it
+    if (f.summ.cap < ws_summ_bytes(n_tiles) || f.seg_agg.cap < ws_seg_bytes(n_tiles) || f.tile_first.cap < ws_first_bytes(n_tiles) ||
+        f.fix_count.cap < 8) {
+        if ((rc = flow_drain(g))) return rc;
+        if ((rc = f.summ.ensure(ws_summ_bytes(n_tiles))) || (rc = f.seg_agg.ensure(ws_seg_bytes(n_tiles))) ||
+            (rc = f.tile_first.ensure(ws_first_bytes(n_tiles))) || (rc = f.fix_count.ensure(8)))
+            return rc;
+    }
+    if ((rc = run_pipeline(g, cps, row_off, n_str, total, mask, nullptr, latok::kModeBits, f.st, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, 0, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
+        return rc;
+    f.used = true;
+    f.out = mask;
+    ++g.flow_seq;
+    return LATOK_OK;
+}
+
+int latok_flow_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                          uint64_t* mask_dev) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (total_chars < 0) {
+        if ((rc = resolve_total_device(row_off_dev, n_str, &total_chars, g.stream))) return rc;
+    }
+    return flow_submit(g, cps_dev, row_off_dev, n_str, total_chars, mask_dev);
+}
+int latok_flow_wait(void) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    return flow_drain(g);
 }
 
 int latok_bench_stream_read(const void* buf_dev, int64_t bytes, int warmup, int iters, float* ms_out) {
@@ -2032,6 +2142,40 @@ int latok_bench_split_mask_gated(const uint32_t* cps_dev, const int64_t* row_off
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
     if (rc) return rc;
+    if (rc_gate) return rc_gate;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));
+    if (ms_events_out) *ms_events_out = ms;
+    if (t0_ns_out) *t0_ns_out = t0;
+    if (t1_ns_out) *t1_ns_out = t1;
+    return LATOK_OK;
+}
+
+int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total,
+                                      uint64_t* mask_a_dev, uint64_t* mask_b_dev, int iters, latok_gate* gate,
+                                      float* ms_events_out, int64_t* t0_ns_out, int64_t* t1_ns_out) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (iters < 1) return fail(LATOK_ERR_INVALID, "iters must be >= 1");
+    if (!mask_a_dev || !mask_b_dev) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    if ((rc = resolve_total_device(row_off_dev, n_str, &total, g.stream))) return rc;
+    if ((rc = flow_setup(g)) || (rc = flow_drain(g))) return rc;
+    HIP_TRY(hipStreamSynchronize(g.stream));
+    if ((rc = latok_gate_wait(gate, 120.0))) return rc;
+    const int64_t t0 = mono_ns();
+    HIP_TRY(hipEventRecord(g.ev[0], g.flow[g.flow_seq % (unsigned)g.flow_slots].st));   // the stream of the first submission
+    for (int i = 0; i < iters; ++i)
+        if ((rc = flow_submit(g, cps_dev, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev))) break;
+    if (!rc) {
+        hipError_t e = hipEventRecord(g.ev[1], g.flow[(g.flow_seq + (unsigned)g.flow_slots - 1) % (unsigned)g.flow_slots].st);   // ... of the last one
+        if (e != hipSuccess) rc = fail(LATOK_ERR_HIP, "timed region failed: %s", hipGetErrorString(e));
+    }
+    const int rc_drain = flow_drain(g);
+    const int64_t t1 = mono_ns();
+    const int rc_gate = latok_gate_wait(gate, 120.0);   // also on failure: the other ranks must not wait for this one
+    if (rc) return rc;
+    if (rc_drain) return rc_drain;
     if (rc_gate) return rc_gate;
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, g.ev[0], g.ev[1]));

@@ -33,7 +33,9 @@ class FakeLib:
         self.next_ptr = 0x1000
         self.live = {}                       # ptr -> (device, bytes)
         self.fills = []                      # (device, sid0, n_str)
-        self.timed = []                      # (device, thread, t0, t1)
+        self.timed = []                      # (device, thread, t0, t1) of the headline region of every rank
+        self.timed_serial = []               # ... of the `serial` region behind it (batch flow on)
+        self.flow_calls = 0
 
     def __getattr__(self, name):            # gate functions, corpus offsets: the real thing
         return getattr(self.real, name)
@@ -87,7 +89,7 @@ class FakeLib:
             n_fix._obj.value = 7
         return 0
 
-    def latok_bench_split_mask_gated(self, cps, row, n_str, total, bits, iters, gate, ms, t0, t1):
+    def _region(self, iters, gate, ms, t0, t1, sink):
         rc = self.real.latok_gate_wait(gate, C.c_double(20.0))
         if rc:
             return rc
@@ -98,8 +100,21 @@ class FakeLib:
         ms._obj.value = (b - a) / 1e6
         t0._obj.value, t1._obj.value = a, b
         with self.lock:
-            self.timed.append((self._dev(), threading.get_ident(), a, b))
+            sink.append((self._dev(), threading.get_ident(), a, b))
         return rc
+
+    def latok_bench_split_mask_gated(self, cps, row, n_str, total, bits, iters, gate, ms, t0, t1):
+        # with the batch flow on (the default) this is the `serial` region that follows the headline one
+        return self._region(iters, gate, ms, t0, t1, self.timed_serial if self.flow_calls else self.timed)
+
+    def latok_bench_split_mask_flow_gated(self, cps, row, n_str, total, bits_a, bits_b, iters, gate, ms, t0, t1):
+        assert bits_a and bits_b and bits_a != bits_b, "the flow alternates between two output bitmasks"
+        if iters <= 1:      # the flow's warm-up pass (BASE: --warmup 1, --steps 5)
+            ms._obj.value = 0.0
+            return 0
+        with self.lock:
+            self.flow_calls += 1
+        return self._region(iters, gate, ms, t0, t1, self.timed)
 
     def latok_bench_stream_read(self, buf, nbytes, warmup, iters, ms):
         ms._obj.value = 1.0
@@ -176,6 +191,16 @@ def test_in_process_launch_runs_every_rank_on_its_own_context(n, monkeypatch):
     assert line["value"] == pytest.approx(line["config"]["utf8_bytes_total"] * 5 / (job_ms / 1e3) / 1e9, rel=1e-6)
     assert line["roofline"]["frac"] == min(line["roofline"]["frac_per_rank"]) and line["fix_tiles_rank0"] == 7
     assert line["vs_baseline"] is None and line["higher_is_better"] is True and line["data"] == "synthetic"
+    # the headline region went through the batch flow (two batches in flight), the same K steps one at a time ride along
+    assert line["in_flight"] == 2 and api.lib.flow_calls == n and len(api.lib.timed_serial) == n
+    assert line["serial"]["value"] > 0 and len(line["serial"]["ms_per_rank"]) == n
+
+
+def test_in_flight_1_times_one_batch_at_a_time(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    api = FakeApi(n_dev=2)
+    line = _run(["--gpus", "2", "--in-flight", "1"] + BASE, api)
+    assert line["in_flight"] == 1 and line["serial"] is None and api.lib.flow_calls == 0 and len(api.lib.timed) == 2
 
 
 def test_devices_may_repeat_and_take_turns_serialises(monkeypatch):

@@ -1,0 +1,165 @@
+"""The batch flow of the C ABI (include/latok_hip.h "batch flow": latok_flow_split_mask / latok_flow_wait): many
+device-resident batches through one context with two in flight.  Every result must be what latok_split_mask_batch and the
+oracle give for the same batch -- whatever the sizes of the neighbours in the flow, also when a workspace slot has to grow,
+when two batches in flight name the same output buffer, under run-time rule tables, and from two contexts at once."""
+import random
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ALPHABETS, RULE_SETS, oracle_rule_bits, pack, random_strings
+
+pytestmark = pytest.mark.gpu
+
+
+class _Resident:
+    """one batch in device memory + a poisoned output bitmask"""
+
+    def __init__(self, lib, cps, row):
+        from latok_amd import _lib
+        self.lib, self.n_str, self.total = lib, len(row) - 1, int(row[-1])
+        self.words = (self.total + 63) // 64
+        self.d_cps = lib.latok_dev_alloc(max(cps.nbytes, 16))
+        self.d_row = lib.latok_dev_alloc(row.nbytes)
+        self.d_mask = lib.latok_dev_alloc(max(self.words * 8, 16))
+        assert self.d_cps and self.d_row and self.d_mask
+        _lib.check(lib.latok_memcpy_h2d(self.d_cps, cps.ctypes.data, cps.nbytes))
+        _lib.check(lib.latok_memcpy_h2d(self.d_row, row.ctypes.data, row.nbytes))
+        _lib.check(lib.latok_memset_dev(self.d_mask, 0xA5, max(self.words * 8, 16)))
+
+    def mask(self, d_mask=None):
+        from latok_amd import _lib
+        out = np.empty(self.words, np.uint64)
+        _lib.check(self.lib.latok_memcpy_d2h(out.ctypes.data, d_mask or self.d_mask, out.nbytes))
+        return out
+
+    def free(self):
+        for p in (self.d_cps, self.d_row, self.d_mask):
+            self.lib.latok_dev_free(p)
+
+
+def _batches(rng):
+    """sizes from one char to several segments, incl. documents whose pending-start queue crosses tiles and segments"""
+    out = [["x"], ["", "a b", ""], random_strings(rng, 50, 0, 40, ALPHABETS["mixed"]),
+           random_strings(rng, 3000, 0, 200, ALPHABETS["mixed"]),
+           random_strings(rng, 4, 30000, 90000, ALPHABETS["rare_space_at"]) + random_strings(rng, 200, 0, 100, ALPHABETS["starts"]),
+           random_strings(rng, 2, 200000, 400000, ALPHABETS["nospace_at"]) + ["@a b"],
+           random_strings(rng, 20000, 0, 300, ALPHABETS["words"]),
+           random_strings(rng, 700, 0, 64, ALPHABETS["mixed"])]
+    rng.shuffle(out)
+    return out
+
+
+def test_flow_results_equal_the_serial_call_and_the_oracle(gpu, oracle):
+    from latok_amd import _lib, batch
+    rng = random.Random(2024)
+    work = []
+    for texts in _batches(rng) + _batches(rng):
+        cps, row = pack(texts)
+        work.append((_Resident(gpu, cps, row), oracle.split_batch(cps, row, want_values=False)[1], cps, row))
+    try:
+        for rb, _, _, _ in work:                       # sixteen batches of very different sizes, back to back
+            batch.flow_split_mask(rb.d_cps, rb.d_row, rb.n_str, rb.total, rb.d_mask)
+        batch.flow_wait()
+        for rb, want, cps, row in work:
+            got = rb.mask()
+            assert np.array_equal(got, want)
+            assert np.array_equal(batch.split_mask_batch(cps, row), want)
+        # again, now with total_chars left to the library (-1) and latok_sync as the barrier
+        for rb, _, _, _ in work:
+            _lib.check(gpu.latok_memset_dev(rb.d_mask, 0x5A, max(rb.words * 8, 16)))
+        for rb, _, _, _ in work:
+            batch.flow_split_mask(rb.d_cps, rb.d_row, rb.n_str, -1, rb.d_mask)
+        _lib.check(gpu.latok_sync())
+        for rb, want, _, _ in work:
+            assert np.array_equal(rb.mask(), want)
+    finally:
+        for rb, _, _, _ in work:
+            rb.free()
+
+
+def test_two_batches_in_flight_may_name_the_same_output_buffer(gpu, oracle):
+    """the second one is ordered behind the first (same slot stream): the buffer ends up holding the LAST batch's mask"""
+    from latok_amd import batch
+    rng = random.Random(7)
+    a = pack(random_strings(rng, 6000, 0, 300, ALPHABETS["mixed"]))
+    b = pack(random_strings(rng, 5, 40000, 60000, ALPHABETS["rare_space_at"]) + random_strings(rng, 4000, 0, 200, ALPHABETS["mixed"]))
+    c = pack(random_strings(rng, 3000, 0, 100, ALPHABETS["starts"]))
+    ra, rb_, rc = _Resident(gpu, *a), _Resident(gpu, *b), _Resident(gpu, *c)
+    try:
+        words = max(ra.words, rb_.words, rc.words)
+        shared = gpu.latok_dev_alloc(words * 8)
+        for _ in range(3):
+            batch.flow_split_mask(ra.d_cps, ra.d_row, ra.n_str, ra.total, shared)
+            batch.flow_split_mask(rc.d_cps, rc.d_row, rc.n_str, rc.total, rc.d_mask)     # an unrelated batch in between
+            batch.flow_split_mask(rb_.d_cps, rb_.d_row, rb_.n_str, rb_.total, shared)
+            batch.flow_wait()
+            assert np.array_equal(rb_.mask(shared), oracle.split_batch(*b, want_values=False)[1])
+            assert np.array_equal(rc.mask(), oracle.split_batch(*c, want_values=False)[1])
+        gpu.latok_dev_free(shared)
+    finally:
+        for r in (ra, rb_, rc):
+            r.free()
+
+
+@pytest.mark.parametrize("name", ["sym_everywhere", "all_starts"])
+def test_flow_under_run_time_rule_tables(gpu, oracle, name):
+    from latok_amd import batch
+    rng = random.Random(31)
+    tables = RULE_SETS[name]
+    sets = [random_strings(rng, 1500, 0, 200, ALPHABETS["mixed"]) + random_strings(rng, 2, 9000, 20000, ALPHABETS["rare_space_at"])
+            for _ in range(3)]
+    res = [_Resident(gpu, *pack(t)) for t in sets]
+    batch.set_rules(*tables)
+    try:
+        for r in res:
+            batch.flow_split_mask(r.d_cps, r.d_row, r.n_str, r.total, r.d_mask)
+        batch.flow_wait()
+        for r, t in zip(res, sets):
+            assert np.array_equal(r.mask(), oracle_rule_bits(oracle, t, tables))
+    finally:
+        batch.reset_rules()
+        for r in res:
+            r.free()
+
+
+def test_flows_of_two_contexts_run_side_by_side(gpu, oracle):
+    from latok_amd import _lib, batch
+    rng = random.Random(5)
+    work = [[pack(random_strings(rng, 4000 + 500 * k, 0, 250, ALPHABETS["mixed"])) for k in range(4)] for _ in range(2)]
+    want = [[oracle.split_batch(c, r, want_values=False)[1] for c, r in w] for w in work]
+    errors = []
+
+    def run(k):
+        try:
+            with _lib.Context(0) as ctx:
+                res = [_Resident(gpu, c, r) for c, r in work[k]]
+                for _ in range(5):
+                    for r in res:
+                        batch.flow_split_mask(r.d_cps, r.d_row, r.n_str, r.total, r.d_mask)
+                    batch.flow_wait()
+                    for r, w in zip(res, want[k]):
+                        assert np.array_equal(r.mask(), w)
+                for r in res:
+                    r.free()
+            ctx.destroy()
+        except BaseException as exc:   # noqa: BLE001 - reported to the main thread
+            errors.append(exc)
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errors, errors[0]
+
+
+def test_flow_refuses_what_the_serial_call_refuses(gpu):
+    from latok_amd import batch
+    with pytest.raises(ValueError):
+        batch.flow_split_mask(0x1000, 0x2000, 3, 10, None)        # NULL output
+    with pytest.raises(ValueError):
+        batch.flow_split_mask(0x1004, 0x2000, 3, 10, 0x3000)      # misaligned code points
+    batch.flow_split_mask(None, None, 0, 0, None)                  # an empty batch is nothing to do
+    batch.flow_wait()

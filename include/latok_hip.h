@@ -270,6 +270,13 @@ int latok_rules_active(void);  /* 1 while custom tables are installed */
  *   latok_flow_wait: block until every batch submitted on the current context is complete (latok_sync does the same). */
 int latok_flow_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                           uint64_t* mask_dev);
+/* The same for the other input forms of the path: PEP 393 units (kind 1 / 2 / 4 as latok_split_mask_kind_batch; positions are
+ * chars) and UTF-8 in byte space (as latok_split_mask_utf8_bytes_batch; positions are bytes).  Batches of different forms may
+ * follow each other in one flow. */
+int latok_flow_split_mask_kind(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                               uint64_t* mask_dev);
+int latok_flow_split_mask_utf8_bytes(const uint8_t* utf8_dev, const int64_t* byte_off_dev, int64_t n_str, int64_t total_bytes,
+                                     uint64_t* mask_dev);
 int latok_flow_wait(void);
 
 /* ---- measurement ----------------------------------------------------------------------------------------------- */

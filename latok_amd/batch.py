@@ -517,6 +517,18 @@ def flow_split_mask(d_cps, d_row_off, n_str, total_chars, d_mask):
     _lib.check(lib.latok_flow_split_mask(d_cps, d_row_off, int(n_str), int(total_chars), d_mask))
 
 
+def flow_split_mask_kind(d_units, kind, d_row_off, n_str, total_chars, d_mask):
+    """``flow_split_mask`` for PEP 393 units in device memory (kind 1 = Latin-1 bytes, 2 = UCS-2 uint16, 4 = UTF-32)."""
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_flow_split_mask_kind(d_units, int(kind), d_row_off, int(n_str), int(total_chars), d_mask))
+
+
+def flow_split_mask_utf8_bytes(d_utf8, d_byte_off, n_str, total_bytes, d_mask):
+    """``flow_split_mask`` in byte space: UTF-8 bytes + byte offsets in device memory, bit i of the mask = byte i."""
+    lib = _lib.ensure_init()
+    _lib.check(lib.latok_flow_split_mask_utf8_bytes(d_utf8, d_byte_off, int(n_str), int(total_bytes), d_mask))
+
+
 def flow_wait():
     """Block until every batch submitted with ``flow_split_mask`` on the current context is complete."""
     _lib.check(_lib.ensure_init().latok_flow_wait())

@@ -1871,12 +1871,15 @@ static int flow_drain(Ctx& g) {
     for (int i = 0; i < g.flow_slots; ++i) g.flow[i].used = false;   // nothing in flight: no mask buffer is being written
     return LATOK_OK;
 }
-static int flow_submit(Ctx& g, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask) {
+// units: UTF-32 code points (unit_kind 4), PEP 393 units (1 / 2; positions are chars) or UTF-8 bytes (0; byte space)
+static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask) {
     int rc = flow_setup(g);
     if (rc) return rc;
     if (n_str <= 0 || total <= 0) return LATOK_OK;
-    if (!cps || !row_off || !mask) return fail(LATOK_ERR_INVALID, "NULL buffer");
-    if (((uintptr_t)cps & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    if (!units || !row_off || !mask) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    if (((uintptr_t)units & 15) != 0) return fail(LATOK_ERR_INVALID, "device input pointer must be 16-byte aligned");
+    const uint32_t* cps = unit_kind == 4 ? (const uint32_t*)units : nullptr;
+    const uint8_t* u8 = unit_kind == 4 ? nullptr : (const uint8_t*)units;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     // slots are used in turn -- except that a batch which writes the mask buffer of a batch still in flight goes to THAT
     // batch's slot, whose stream orders the two (callers that alternate buffers never hit this; an event per batch to order
@@ -1894,7 +1897,7 @@ static int flow_submit(Ctx& g, const uint32_t* cps, const int64_t* row_off, int6
             return rc;
     }
     if ((rc = run_pipeline(g, cps, row_off, n_str, total, mask, nullptr, latok::kModeBits, f.st, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, 0, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
+                           nullptr, nullptr, nullptr, u8, unit_kind == 4 ? 0 : unit_kind, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
         return rc;
     f.used = true;
     f.out = mask;
@@ -1910,7 +1913,28 @@ int latok_flow_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, i
     if (total_chars < 0) {
         if ((rc = resolve_total_device(row_off_dev, n_str, &total_chars, g.stream))) return rc;
     }
-    return flow_submit(g, cps_dev, row_off_dev, n_str, total_chars, mask_dev);
+    return flow_submit(g, cps_dev, 4, row_off_dev, n_str, total_chars, mask_dev);
+}
+int latok_flow_split_mask_kind(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                               uint64_t* mask_dev) {
+    LATOK_ENTER();
+    int rc = check_kind(kind);
+    if (rc) return rc;
+    if ((rc = need_init(g))) return rc;
+    if (total_chars < 0) {
+        if ((rc = resolve_total_device(row_off_dev, n_str, &total_chars, g.stream))) return rc;
+    }
+    return flow_submit(g, units_dev, kind, row_off_dev, n_str, total_chars, mask_dev);
+}
+int latok_flow_split_mask_utf8_bytes(const uint8_t* utf8_dev, const int64_t* byte_off_dev, int64_t n_str, int64_t total_bytes,
+                                     uint64_t* mask_dev) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (total_bytes < 0) {
+        if ((rc = resolve_total_device(byte_off_dev, n_str, &total_bytes, g.stream))) return rc;
+    }
+    return flow_submit(g, utf8_dev, 0, byte_off_dev, n_str, total_bytes, mask_dev);
 }
 int latok_flow_wait(void) {
     LATOK_ENTER();
@@ -2166,7 +2190,7 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
     const int64_t t0 = mono_ns();
     HIP_TRY(hipEventRecord(g.ev[0], g.flow[g.flow_seq % (unsigned)g.flow_slots].st));   // the stream of the first submission
     for (int i = 0; i < iters; ++i)
-        if ((rc = flow_submit(g, cps_dev, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev))) break;
+        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev))) break;
     if (!rc) {
         hipError_t e = hipEventRecord(g.ev[1], g.flow[(g.flow_seq + (unsigned)g.flow_slots - 1) % (unsigned)g.flow_slots].st);   // ... of the last one
         if (e != hipSuccess) rc = fail(LATOK_ERR_HIP, "timed region failed: %s", hipGetErrorString(e));

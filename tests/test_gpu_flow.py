@@ -155,6 +155,51 @@ def test_flows_of_two_contexts_run_side_by_side(gpu, oracle):
     assert not errors, errors[0]
 
 
+def test_flow_of_mixed_input_forms(gpu, oracle):
+    """UTF-32, Latin-1 / UCS-2 units and UTF-8 in byte space follow each other in one flow; each equals its serial call"""
+    from latok_amd import _lib, batch
+    rng = random.Random(77)
+    lat = random_strings(rng, 5000, 0, 200, ALPHABETS["latin1"])
+    bmp = random_strings(rng, 4000, 0, 200, ALPHABETS["bmp"]) + random_strings(rng, 2, 30000, 50000, ALPHABETS["rare_space_at"])
+    mixed = random_strings(rng, 5000, 0, 150, ALPHABETS["mixed"])
+
+    def dev(a):
+        p = gpu.latok_dev_alloc(max(a.nbytes, 16) + 64)
+        _lib.check(gpu.latok_memcpy_h2d(p, a.ctypes.data, a.nbytes))
+        return p
+    jobs = []   # (submit, want, words, d_mask)
+    u1, r1 = batch.pack_kind(lat)
+    assert u1.dtype == np.uint8
+    u2, r2 = batch.pack_kind(bmp)
+    assert u2.dtype == np.uint16
+    for units, row, kind in ((u1, r1, 1), (u2, r2, 2)):
+        want = batch.split_mask_kind_csr(units, row)
+        d_u, d_r, d_m = dev(units), dev(row), gpu.latok_dev_alloc(want.nbytes + 16)
+        jobs.append((lambda d_u=d_u, d_r=d_r, d_m=d_m, k=kind, row=row: batch.flow_split_mask_kind(d_u, k, d_r, len(row) - 1, int(row[-1]), d_m),
+                     want, d_m))
+    u8, boff = batch.pack_utf8([t.encode("utf-8", "surrogatepass") for t in mixed])
+    want = batch.split_mask_utf8_bytes_csr(u8, boff)
+    d_u, d_r, d_m = dev(u8), dev(boff), gpu.latok_dev_alloc(want.nbytes + 16)
+    jobs.append((lambda d_u=d_u, d_r=d_r, d_m=d_m: batch.flow_split_mask_utf8_bytes(d_u, d_r, len(boff) - 1, int(boff[-1]), d_m), want, d_m))
+    cps, row = pack(mixed)
+    want32 = oracle.split_batch(cps, row, want_values=False)[1]
+    d_c, d_r4, d_m4 = dev(cps), dev(row), gpu.latok_dev_alloc(want32.nbytes + 16)
+    n32, t32 = len(row) - 1, int(row[-1])
+    jobs.append((lambda: batch.flow_split_mask_kind(d_c, 4, d_r4, n32, t32, d_m4), want32, d_m4))
+    for _ in range(3):
+        for _, w_, m_ in jobs:
+            _lib.check(gpu.latok_memset_dev(m_, 0x3C, w_.nbytes))
+        for submit, _, _ in jobs + jobs[::-1]:
+            submit()
+        batch.flow_wait()
+        for _, w_, m_ in jobs:
+            got = np.empty_like(w_)
+            _lib.check(gpu.latok_memcpy_d2h(got.ctypes.data, m_, got.nbytes))
+            assert np.array_equal(got, w_)
+    with pytest.raises(ValueError):
+        batch.flow_split_mask_kind(d_c, 3, d_r4, 1, 1, d_m4)      # no such PEP 393 kind
+
+
 def test_flow_refuses_what_the_serial_call_refuses(gpu):
     from latok_amd import batch
     with pytest.raises(ValueError):

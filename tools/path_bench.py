@@ -11,6 +11,8 @@
   bytes_mask / bytes_offsets / bytes_spans   latok_*_utf8_bytes_batch (8f-3 fused: the tile kernel reads the bytes)
   rules_mask      latok_split_mask_batch after latok_set_rules(built-in tables)   (8f-4)
   offsets32 / spans32 / features32 / kind_offsets32 / kind_spans32   the same entry points with LATOK_OUT_INT32 records
+  mask_flow / bytes_mask_flow / kind_mask_flow   the same mask paths through the batch flow (latok_flow_split_mask*: two
+                  batches in flight, the small launches of one in the shadow of the other's tile kernel)
   kind_mask / kind_offsets / kind_spans      latok_*_kind_batch on PEP 393 code units: kind 1 (uint8) when every char
                   of the corpus is <= U+00FF (C2), else kind 2 (uint16) with the corpus' astral chars folded into the BMP
                   (cp & 0xFFFF; timing only -- C3 as CPython would store it without its emoji)
@@ -61,7 +63,7 @@ def main():
     ap.add_argument("--strings", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
-    ap.add_argument("--paths", default="mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
+    ap.add_argument("--paths", default="mask,mask_flow,bytes_mask_flow,kind_mask_flow,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
                                        "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,"
                                        "kind_spans,kind_spans32")
     args = ap.parse_args()
@@ -112,6 +114,41 @@ def main():
                           "alg_bytes_are": note}), flush=True)
 
     paths = args.paths.split(",")
+    flow_buf = {}
+
+    def flow_pair(n_words):   # two output bitmasks: consecutive submissions of a flow alternate between them
+        if n_words not in flow_buf:
+            flow_buf[n_words] = (lib.latok_dev_alloc(n_words * 8 + 8), lib.latok_dev_alloc(n_words * 8 + 8))
+        return flow_buf[n_words]
+
+    def run_flow(name, submit, alg, note):
+        """the same measurement through the batch flow (include/latok_hip.h): `--iters` submissions, then one latok_flow_wait"""
+        a_, b_ = None, None
+        for i in range(4):
+            _lib.check(submit(i))
+        _lib.check(lib.latok_flow_wait())
+        k = max(args.iters, 20)
+        t = time.perf_counter()
+        for i in range(k):
+            _lib.check(submit(i))
+        _lib.check(lib.latok_flow_wait())
+        dt = (time.perf_counter() - t) / k
+        a = alg()
+        print(json.dumps({"path": name, "workload": args.workload, "strings": n, "chars": total, "utf8_bytes": n8,
+                          "items": 0, "ms_per_call": dt * 1e3, "utf8_GBps": n8 / dt / 1e9,
+                          "alg_bytes": a, "alg_GBps": a / dt / 1e9, "frac_of_hbm_peak": a / dt / 1e9 / HBM_PEAK,
+                          "alg_bytes_are": note + "; batch flow: two batches in flight, per-batch time of " + str(k) + " submissions + one wait"}),
+              flush=True)
+
+    if "mask_flow" in paths:
+        fa, fb = flow_pair(words)
+        run_flow("mask_flow", lambda i: lib.latok_flow_split_mask(d_cps, d_row, n, total, fb if i & 1 else fa),
+                 lambda: 4 * total + csr + words * 8, "4 B/char + 8 B/string read, 1 bit/char written")
+    if "bytes_mask_flow" in paths:
+        bw_ = (n8 + 63) // 64
+        fa, fb = flow_pair(bw_)
+        run_flow("bytes_mask_flow", lambda i: lib.latok_flow_split_mask_utf8_bytes(d_u8, d_boff, n, n8, fb if i & 1 else fa),
+                 lambda: n8 + csr + bw_ * 8, "UTF-8 bytes + 8 B/string read; 1 bit/byte written (byte space, fused ingest)")
     if "mask" in paths:
         run("mask", lambda: lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None),
             lambda: 4 * total + csr + words * 8, "4 B/char + 8 B/string read, 1 bit/char written")
@@ -176,6 +213,10 @@ def main():
         d_units = lib.latok_dev_alloc(units.nbytes + 64)
         _lib.check(lib.latok_memcpy_h2d(d_units, units.ctypes.data, units.nbytes))
         note = f"{kind} B/char + 8 B/string read"
+        if "kind_mask_flow" in paths:
+            fa, fb = flow_pair(words)
+            run_flow("kind_mask_flow", lambda i: lib.latok_flow_split_mask_kind(d_units, kind, d_row, n, total, fb if i & 1 else fa),
+                     lambda: kind * total + csr + words * 8, note + "; 1 bit/char written")
         if "kind_mask" in paths:
             nout.value = 0
             run("kind_mask", lambda: lib.latok_split_mask_kind_batch(d_units, kind, d_row, n, total, d_bits, D, None),

@@ -277,6 +277,21 @@ int latok_flow_split_mask_kind(const void* units_dev, int kind, const int64_t* r
                                uint64_t* mask_dev);
 int latok_flow_split_mask_utf8_bytes(const uint8_t* utf8_dev, const int64_t* byte_off_dev, int64_t n_str, int64_t total_bytes,
                                      uint64_t* mask_dev);
+/* Boundary offsets / token spans of a batch through the flow: what latok_split_offsets_batch / latok_token_spans_batch (and
+ * their _kind / _utf8_bytes forms) compute, enqueued without waiting for the item total.  kind: 4 = UTF-32 code points, 1 / 2 =
+ * PEP 393 units, 0 = UTF-8 bytes in byte space (row_off = byte offsets, positions are bytes).  Every pointer is a device
+ * address (LATOK_DEVICE_PTRS is implied); flags: LATOK_OUT_INT32 for int32 counts / records.
+ *   counts_dev[n_str], offsets_dev[offsets_cap] (spans_dev[2 * spans_cap]): as in the blocking calls.
+ *   result_dev: int64[2] in memory the DEVICE can write and the caller can read after latok_flow_wait (latok_dev_alloc +
+ *     latok_memcpy_d2h, or latok_host_alloc for a direct read): result[0] = number of items of the batch, result[1] = 0, or
+ *     nonzero when the batch could not be reported (low half: a string of >= 2^31 chars under LATOK_OUT_INT32; high half:
+ *     internal scan error, the call is safe to repeat).  When result[0] exceeds the capacity nothing was written to the
+ *     records (counts are valid): resubmit with a larger buffer -- the capacity protocol of the blocking calls, read late.
+ * Batches whose records go to the buffer of a batch still in flight are ordered behind it. */
+int latok_flow_split_offsets(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
+                             void* counts_dev, void* offsets_dev, int64_t offsets_cap, int64_t* result_dev, int flags);
+int latok_flow_token_spans(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
+                           void* counts_dev, void* spans_dev, int64_t spans_cap, int64_t* result_dev, int flags);
 int latok_flow_wait(void);
 
 /* ---- measurement ----------------------------------------------------------------------------------------------- */

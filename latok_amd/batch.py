@@ -529,6 +529,24 @@ def flow_split_mask_utf8_bytes(d_utf8, d_byte_off, n_str, total_bytes, d_mask):
     _lib.check(lib.latok_flow_split_mask_utf8_bytes(d_utf8, d_byte_off, int(n_str), int(total_bytes), d_mask))
 
 
+def flow_split_offsets(d_units, kind, d_row_off, n_str, total_units, d_counts, d_offsets, cap, d_result, dtype=np.int64):
+    """Boundary offsets of one device-resident batch through the flow (``latok_flow_split_offsets``): kind 4 / 1 / 2 =
+    UTF-32 / Latin-1 / UCS-2 units, 0 = UTF-8 bytes in byte space.  ``d_result`` = int64[2] the device can write: item
+    total and error word, valid after ``flow_wait()``; nothing is written to ``d_offsets`` when the total exceeds ``cap``."""
+    lib = _lib.ensure_init()
+    _, flag32 = _out_dtype(dtype)
+    _lib.check(lib.latok_flow_split_offsets(d_units, int(kind), d_row_off, int(n_str), int(total_units), d_counts, d_offsets, int(cap),
+                                            d_result, flag32))
+
+
+def flow_token_spans(d_units, kind, d_row_off, n_str, total_units, d_counts, d_spans, cap, d_result, dtype=np.int64):
+    """Token spans (start, end per kept token) of one device-resident batch through the flow (``latok_flow_token_spans``)."""
+    lib = _lib.ensure_init()
+    _, flag32 = _out_dtype(dtype)
+    _lib.check(lib.latok_flow_token_spans(d_units, int(kind), d_row_off, int(n_str), int(total_units), d_counts, d_spans, int(cap),
+                                          d_result, flag32))
+
+
 def flow_wait():
     """Block until every batch submitted with ``flow_split_mask`` on the current context is complete."""
     _lib.check(_lib.ensure_init().latok_flow_wait())

@@ -182,6 +182,11 @@ struct Ctx {
     // batch flow (latok_flow_*): up to kFlowSlots device-resident batches in flight, each with its own stream and workspace
     struct FlowSlot {
         DevBuf summ, seg_agg, fix_count, tile_first;
+        // compaction passes of the slot's batch (latok_flow_split_offsets / _token_spans): what the context's own calls keep
+        // in bits / space / kept / wcnt / wpref / bases / chain / chain_ctl / scalar
+        DevBuf bits, space, kept, wcnt, wpref, bases, chain, chain_ctl, scalar;
+        unsigned scan_epoch = 0, chain_seen = 0, chain_ctl_seen = 0;
+        bool chain_ready = false;
         hipStream_t st = nullptr;
         bool used = false;
         const void* out = nullptr;       // the mask buffer the slot's last batch writes
@@ -468,7 +473,11 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
             (void)hipStreamDestroy(f.st);
         }
         f.st = nullptr;
-        for (DevBuf* b : {&f.summ, &f.seg_agg, &f.fix_count, &f.tile_first}) b->release();
+        for (DevBuf* b : {&f.summ, &f.seg_agg, &f.fix_count, &f.tile_first, &f.bits, &f.space, &f.kept, &f.wcnt, &f.wpref, &f.bases,
+                          &f.chain, &f.chain_ctl, &f.scalar})
+            b->release();
+        f.scan_epoch = f.chain_seen = f.chain_ctl_seen = 0;
+        f.chain_ready = false;
         f.used = false;
         f.out = nullptr;
     }
@@ -758,21 +767,33 @@ static int enqueue_features(Ctx& g, const uint8_t* d_codes, const int64_t* d_row
 
 // the single-pass scan of k_word_counts_scan keeps its state between launches: entries carry an epoch, so the array is
 // cleared only when it is (re)allocated or when the 18-bit epoch wraps
-static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* epoch_out) {
+struct ScanState {   // the chained scan's look-back words + epoch of one workspace set (the context's own, or a flow slot's)
+    DevBuf& chain;
+    DevBuf& chain_ctl;
+    unsigned& scan_epoch;
+    unsigned& chain_seen;
+    unsigned& chain_ctl_seen;
+    bool& chain_ready;
+};
+static ScanState scan_state(Ctx& g, Ctx::FlowSlot* slot) {
+    if (slot) return ScanState{slot->chain, slot->chain_ctl, slot->scan_epoch, slot->chain_seen, slot->chain_ctl_seen, slot->chain_ready};
+    return ScanState{g.chain, g.chain_ctl, g.scan_epoch, g.chain_seen, g.chain_ctl_seen, g.chain_ready};
+}
+static int next_scan_epoch(ScanState c, int64_t n_blocks, hipStream_t st, unsigned* epoch_out) {
     int rc;
-    if ((rc = g.chain.ensure((size_t)n_blocks * 8 + 64))) return rc;
-    if ((rc = g.chain_ctl.ensure(64))) return rc;
-    g.scan_epoch = (g.scan_epoch + 1) & 0x3FFFFu;
+    if ((rc = c.chain.ensure((size_t)n_blocks * 8 + 64))) return rc;
+    if ((rc = c.chain_ctl.ensure(64))) return rc;
+    c.scan_epoch = (c.scan_epoch + 1) & 0x3FFFFu;
     // (the state array may have been re-allocated by this call or by an earlier reserve: fresh memory holds anything)
-    if (g.chain.gen != g.chain_seen || g.chain_ctl.gen != g.chain_ctl_seen || g.scan_epoch == 0 || !g.chain_ready) {
-        g.chain_seen = g.chain.gen;
-        g.chain_ctl_seen = g.chain_ctl.gen;
-        HIP_TRY(hipMemsetAsync(g.chain.p, 0, g.chain.cap, st));
-        HIP_TRY(hipMemsetAsync(g.chain_ctl.p, 0, 64, st));
-        g.scan_epoch = 1;
-        g.chain_ready = true;
+    if (c.chain.gen != c.chain_seen || c.chain_ctl.gen != c.chain_ctl_seen || c.scan_epoch == 0 || !c.chain_ready) {
+        c.chain_seen = c.chain.gen;
+        c.chain_ctl_seen = c.chain_ctl.gen;
+        HIP_TRY(hipMemsetAsync(c.chain.p, 0, c.chain.cap, st));
+        HIP_TRY(hipMemsetAsync(c.chain_ctl.p, 0, 64, st));
+        c.scan_epoch = 1;
+        c.chain_ready = true;
     }
-    *epoch_out = g.scan_epoch;
+    *epoch_out = c.scan_epoch;
     return LATOK_OK;
 }
 
@@ -787,8 +808,19 @@ static int next_scan_epoch(Ctx& g, int64_t n_blocks, hipStream_t st, unsigned* e
 static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, const uint32_t* d_cps, const uint8_t* d_u8, int unit_kind,
                                   const int64_t* d_row, int64_t n_str, int64_t total, void* d_counts, void* d_items, int8_t* d_feat,
                                   int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st,
-                                  latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr}) {
+                                  latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr},
+                                  Ctx::FlowSlot* slot = nullptr) {   // slot: the workspaces of a batch-flow slot (offsets / spans only)
     int rc;
+    if (slot && feats) return fail(LATOK_ERR_INVALID, "internal: no featurize in a batch flow");
+    DevBuf& w_bits = slot ? slot->bits : g.bits;
+    DevBuf& w_space = slot ? slot->space : g.space;
+    DevBuf& w_kept = slot ? slot->kept : g.kept;
+    DevBuf& w_wcnt = slot ? slot->wcnt : g.wcnt;
+    DevBuf& w_bases = slot ? slot->bases : g.bases;
+    DevBuf& w_wpref = slot ? slot->wpref : g.wpref;
+    DevBuf& w_first = slot ? slot->tile_first : g.tile_first;
+    DevBuf& w_scalar = slot ? slot->scalar : g.scalar;
+    const ScanState sc = scan_state(g, slot);
     if (d_u8 && unit_kind && feats) {
         // featurize re-reads the code points: widen once, on the device
         if (((uintptr_t)d_u8 & (size_t)(unit_kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
@@ -798,24 +830,25 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
         d_u8 = nullptr;
     }
     const int64_t words = (total + 63) / 64;
-    if ((rc = g.bits.ensure((size_t)words * 8 + 8))) return rc;
-    if (spans && (rc = g.space.ensure((size_t)words * 8 + 8))) return rc;
-    if (spans && (rc = g.kept.ensure((size_t)words * 8 + 8))) return rc;
+    if ((rc = w_bits.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = w_space.ensure((size_t)words * 8 + 8))) return rc;
+    if (spans && (rc = w_kept.ensure((size_t)words * 8 + 8))) return rc;
     const int64_t c_tiles = (words + 63) / 64;
-    if ((rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
-    if ((rc = g.bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
-    if ((rc = g.wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
+    if ((rc = w_wcnt.ensure((size_t)c_tiles * 8 + 8))) return rc;       // items per tile
+    if ((rc = w_bases.ensure((size_t)c_tiles * 8 + 8))) return rc;      // rank of each tile's first item
+    if ((rc = w_wpref.ensure((size_t)words * 2 + 8))) return rc;        // items of the tile before each word
+    if ((rc = w_scalar.ensure(64))) return rc;
     unsigned epoch = 0;
-    if ((rc = next_scan_epoch(g, latok::count_blocks(words), st, &epoch))) return rc;
-    uint64_t* d_bits = (uint64_t*)g.bits.p;
-    uint64_t* d_space = spans ? (uint64_t*)g.space.p : nullptr;
-    uint64_t* d_kept = spans ? (uint64_t*)g.kept.p : nullptr;
+    if ((rc = next_scan_epoch(sc, latok::count_blocks(words), st, &epoch))) return rc;
+    uint64_t* d_bits = (uint64_t*)w_bits.p;
+    uint64_t* d_space = spans ? (uint64_t*)w_space.p : nullptr;
+    uint64_t* d_kept = spans ? (uint64_t*)w_kept.p : nullptr;
     const uint64_t* d_item_mask = spans ? d_kept : d_bits;
-    int64_t* d_rank = (int64_t*)g.bases.p;
-    int64_t* d_tcnt = (int64_t*)g.wcnt.p;
-    uint16_t* d_pref = (uint16_t*)g.wpref.p;
-    if ((rc = g.tile_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
-    int64_t* d_tile_first = (int64_t*)g.tile_first.p;
+    int64_t* d_rank = (int64_t*)w_bases.p;
+    int64_t* d_tcnt = (int64_t*)w_wcnt.p;
+    uint16_t* d_pref = (uint16_t*)w_wpref.p;
+    if ((rc = w_first.ensure((size_t)((total + latok::kTile - 1) / latok::kTile) * 8 + 8))) return rc;
+    int64_t* d_tile_first = (int64_t*)w_first.p;
     uint8_t* d_codes = nullptr;
     if (feats) {   // the tile kernel leaves the rule code of every char: 1 B/char for k_features_tiles instead of 4 B/char + tables
         const size_t code_bytes = (size_t)total + latok::kTile + 256;   // read (never used) up to a tile behind the last char
@@ -825,14 +858,18 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
         HIP_TRY(hipMemsetAsync(d_codes + tail0, 0, code_bytes - tail0, st));
     }
     if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes)))
+                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes, latok::DoneSignal{nullptr, 0, nullptr}, slot)))
         return rc;
-    h_tot[0] = 0;
-    h_tot[1] = 0;
-    int64_t* d_total = (int64_t*)g.scalar.p;
+    if (h_tot) {   // pinned pair of the context's own calls: cleared by the host
+        h_tot[0] = 0;
+        h_tot[1] = 0;
+    } else {       // a flow's result words live wherever the caller put them: cleared on the stream
+        HIP_TRY(hipMemsetAsync(p_tot, 0, 16, st));
+    }
+    int64_t* d_total = (int64_t*)w_scalar.p;
     int* d_err = (int*)(p_tot + 1);
     HIP_TRY(latok::launch_word_counts_scan(spans, d_bits, d_space, words, total, d_kept, d_tcnt, d_pref, d_rank,
-                                           (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p, epoch, d_total, p_tot, d_err + 1, st));   // (the scan's own flag: the upper half of the pinned word)
+                                           (unsigned long long*)sc.chain.p, (unsigned*)sc.chain_ctl.p, epoch, d_total, p_tot, d_err + 1, st));   // (the scan's own flag: the upper half of the pinned word)
     if (feats) {   // spans and sums come from one kernel
         HIP_TRY(latok::launch_string_counts(o32, d_item_mask, d_rank, d_pref, d_row, n_str, total, d_total, d_counts, d_err, st));
         return enqueue_features(g, d_codes, d_row, n_str, total, d_bits, d_space, d_kept, d_rank, d_tcnt, d_pref, d_tile_first, d_items,
@@ -1871,6 +1908,29 @@ static int flow_drain(Ctx& g) {
     for (int i = 0; i < g.flow_slots; ++i) g.flow[i].used = false;   // nothing in flight: no mask buffer is being written
     return LATOK_OK;
 }
+// Reserve what a batch needs in a slot.  A buffer that has to grow is reallocated only once nothing in flight can still use it.
+struct SlotNeed {
+    DevBuf* buf;
+    size_t bytes;
+};
+static int flow_reserve(Ctx& g, std::initializer_list<SlotNeed> needs) {
+    bool grow = false;
+    for (const SlotNeed& n : needs) grow = grow || n.buf->cap < n.bytes;
+    if (!grow) return LATOK_OK;
+    int rc = flow_drain(g);
+    for (const SlotNeed& n : needs)
+        if (!rc) rc = n.buf->ensure(n.bytes);
+    return rc;
+}
+// Slots are used in turn -- except that a batch which writes an output buffer of a batch still in flight goes to THAT batch's
+// slot, whose stream orders the two (callers that alternate buffers never hit this; an event per batch to order such pairs
+// across streams would cost every batch ~3 us).
+static Ctx::FlowSlot& flow_pick(Ctx& g, const void* out) {
+    Ctx::FlowSlot* fp = &g.flow[g.flow_seq % (unsigned)g.flow_slots];
+    for (int i = 0; i < g.flow_slots; ++i)
+        if (g.flow[i].used && g.flow[i].out == out) fp = &g.flow[i];
+    return *fp;
+}
 // units: UTF-32 code points (unit_kind 4), PEP 393 units (1 / 2; positions are chars) or UTF-8 bytes (0; byte space)
 static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask) {
     int rc = flow_setup(g);
@@ -1881,26 +1941,53 @@ static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* 
     const uint32_t* cps = unit_kind == 4 ? (const uint32_t*)units : nullptr;
     const uint8_t* u8 = unit_kind == 4 ? nullptr : (const uint8_t*)units;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
-    // slots are used in turn -- except that a batch which writes the mask buffer of a batch still in flight goes to THAT
-    // batch's slot, whose stream orders the two (callers that alternate buffers never hit this; an event per batch to order
-    // such pairs across streams would cost every batch ~3 us)
-    Ctx::FlowSlot* fp = &g.flow[g.flow_seq % (unsigned)g.flow_slots];
-    for (int i = 0; i < g.flow_slots; ++i)
-        if (g.flow[i].used && g.flow[i].out == (const void*)mask) fp = &g.flow[i];
-    Ctx::FlowSlot& f = *fp;
-    // a slot that has to grow is reallocated only once nothing in flight can still use it
-    if (f.summ.cap < ws_summ_bytes(n_tiles) || f.seg_agg.cap < ws_seg_bytes(n_tiles) || f.tile_first.cap < ws_first_bytes(n_tiles) ||
-        f.fix_count.cap < 8) {
-        if ((rc = flow_drain(g))) return rc;
-        if ((rc = f.summ.ensure(ws_summ_bytes(n_tiles))) || (rc = f.seg_agg.ensure(ws_seg_bytes(n_tiles))) ||
-            (rc = f.tile_first.ensure(ws_first_bytes(n_tiles))) || (rc = f.fix_count.ensure(8)))
-            return rc;
-    }
+    Ctx::FlowSlot& f = flow_pick(g, mask);
+    if ((rc = flow_reserve(g, {{&f.summ, ws_summ_bytes(n_tiles)}, {&f.seg_agg, ws_seg_bytes(n_tiles)}, {&f.tile_first, ws_first_bytes(n_tiles)},
+                               {&f.fix_count, 8}})))
+        return rc;
     if ((rc = run_pipeline(g, cps, row_off, n_str, total, mask, nullptr, latok::kModeBits, f.st, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr, u8, unit_kind == 4 ? 0 : unit_kind, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
         return rc;
     f.used = true;
     f.out = mask;
+    ++g.flow_seq;
+    return LATOK_OK;
+}
+// offsets (spans = false) or token spans of one batch: everything latok_split_offsets_batch / latok_token_spans_batch launch,
+// on the slot's stream and workspaces; the item total and the error flags land in result[0..1] when the stream gets there
+static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total,
+                               void* counts, void* items, int64_t cap, int64_t* result, int flags) {
+    int rc = flow_setup(g);
+    if (rc) return rc;
+    if (!result) return fail(LATOK_ERR_INVALID, "NULL result pointer");
+    if (((uintptr_t)result & 7) != 0) return fail(LATOK_ERR_INVALID, "result pointer must be 8-byte aligned");
+    if (n_str <= 0 || total <= 0) {   // nothing to launch: counts of empty strings are zero, no items
+        Ctx::FlowSlot& f0 = flow_pick(g, items);
+        HIP_TRY(hipMemsetAsync(result, 0, 16, f0.st));
+        if (n_str > 0 && counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_str * ((flags & LATOK_OUT_INT32) ? 4 : 8), f0.st));
+        return LATOK_OK;
+    }
+    if (!units || !row_off || !counts || (!items && cap > 0)) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    if (cap < 0) return fail(LATOK_ERR_INVALID, "capacity must be >= 0");
+    if (((uintptr_t)units & 15) != 0) return fail(LATOK_ERR_INVALID, "device input pointer must be 16-byte aligned");
+    const bool o32 = (flags & LATOK_OUT_INT32) != 0;
+    if (((uintptr_t)items & 15) != 0 || ((uintptr_t)counts & (o32 ? 3 : 7)) != 0) return fail(LATOK_ERR_INVALID, "misaligned output buffer");
+    const uint32_t* cps = unit_kind == 4 ? (const uint32_t*)units : nullptr;
+    const uint8_t* u8 = unit_kind == 4 ? nullptr : (const uint8_t*)units;
+    const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
+    const int64_t words = (total + 63) / 64, c_tiles = (words + 63) / 64;
+    Ctx::FlowSlot& f = flow_pick(g, items);
+    if ((rc = flow_reserve(g, {{&f.summ, ws_summ_bytes(n_tiles)}, {&f.seg_agg, ws_seg_bytes(n_tiles)}, {&f.tile_first, ws_first_bytes(n_tiles)},
+                               {&f.fix_count, 8}, {&f.bits, (size_t)words * 8 + 8}, {&f.space, spans ? (size_t)words * 8 + 8 : 0},
+                               {&f.kept, spans ? (size_t)words * 8 + 8 : 0}, {&f.wcnt, (size_t)c_tiles * 8 + 8}, {&f.bases, (size_t)c_tiles * 8 + 8},
+                               {&f.wpref, (size_t)words * 2 + 8}, {&f.scalar, 64}, {&f.chain, (size_t)latok::count_blocks(words) * 8 + 64},
+                               {&f.chain_ctl, 64}})))
+        return rc;
+    if ((rc = enqueue_compaction_dev(g, spans, false, o32, cps, u8, unit_kind == 4 ? 0 : unit_kind, row_off, n_str, total, counts, items, nullptr,
+                                     cap, result, nullptr, f.st, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
+        return rc;
+    f.used = true;
+    f.out = items;
     ++g.flow_seq;
     return LATOK_OK;
 }
@@ -1935,6 +2022,26 @@ int latok_flow_split_mask_utf8_bytes(const uint8_t* utf8_dev, const int64_t* byt
         if ((rc = resolve_total_device(byte_off_dev, n_str, &total_bytes, g.stream))) return rc;
     }
     return flow_submit(g, utf8_dev, 0, byte_off_dev, n_str, total_bytes, mask_dev);
+}
+static int flow_compact_entry(bool spans, const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
+                              void* counts_dev, void* items_dev, int64_t cap, int64_t* result_dev, int flags) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (kind != 0 && (rc = check_kind(kind))) return rc;
+    if (flags & ~(LATOK_OUT_INT32 | LATOK_DEVICE_PTRS)) return fail(LATOK_ERR_INVALID, "unknown flag");
+    if (total_units < 0) {
+        if ((rc = resolve_total_device(row_off_dev, n_str, &total_units, g.stream))) return rc;
+    }
+    return flow_submit_compact(g, spans, units_dev, kind, row_off_dev, n_str, total_units, counts_dev, items_dev, cap, result_dev, flags);
+}
+int latok_flow_split_offsets(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
+                             void* counts_dev, void* offsets_dev, int64_t offsets_cap, int64_t* result_dev, int flags) {
+    return flow_compact_entry(false, units_dev, kind, row_off_dev, n_str, total_units, counts_dev, offsets_dev, offsets_cap, result_dev, flags);
+}
+int latok_flow_token_spans(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
+                           void* counts_dev, void* spans_dev, int64_t spans_cap, int64_t* result_dev, int flags) {
+    return flow_compact_entry(true, units_dev, kind, row_off_dev, n_str, total_units, counts_dev, spans_dev, spans_cap, result_dev, flags);
 }
 int latok_flow_wait(void) {
     LATOK_ENTER();

@@ -200,6 +200,118 @@ def test_flow_of_mixed_input_forms(gpu, oracle):
         batch.flow_split_mask_kind(d_c, 3, d_r4, 1, 1, d_m4)      # no such PEP 393 kind
 
 
+class _Out:
+    """device buffers of one compaction result: counts, records, the two result words"""
+
+    def __init__(self, lib, n_str, cap, width, dt):
+        self.lib, self.n_str, self.cap, self.width, self.dt = lib, n_str, cap, width, np.dtype(dt)
+        self.d_counts = lib.latok_dev_alloc(max(n_str, 1) * self.dt.itemsize + 16)
+        self.d_items = lib.latok_dev_alloc(max(cap, 1) * width * self.dt.itemsize + 16)
+        self.d_res = lib.latok_dev_alloc(16)
+        assert self.d_counts and self.d_items and self.d_res
+
+    def fetch(self):
+        from latok_amd import _lib
+        res = np.empty(2, np.int64)
+        _lib.check(self.lib.latok_memcpy_d2h(res.ctypes.data, self.d_res, 16))
+        counts = np.empty(self.n_str, self.dt)
+        if self.n_str:
+            _lib.check(self.lib.latok_memcpy_d2h(counts.ctypes.data, self.d_counts, counts.nbytes))
+        n = int(res[0])
+        items = np.empty((min(n, self.cap), self.width) if self.width > 1 else min(n, self.cap), self.dt)
+        if items.size and n <= self.cap:
+            _lib.check(self.lib.latok_memcpy_d2h(items.ctypes.data, self.d_items, items.nbytes))
+        return res, counts, items
+
+    def free(self):
+        for p in (self.d_counts, self.d_items, self.d_res):
+            self.lib.latok_dev_free(p)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_flow_offsets_and_spans_equal_the_blocking_calls(gpu, oracle, dtype):
+    """latok_flow_split_offsets / latok_flow_token_spans on batches of very different sizes back to back, offsets and spans
+    interleaved in one flow: counts, records and totals are those of the blocking calls (which the other GPU tests pin to
+    the oracle), and the offsets are checked against the oracle directly"""
+    from latok_amd import batch
+    rng = random.Random(808)
+    work = []
+    for texts in _batches(rng):
+        cps, row = pack(texts)
+        rb = _Resident(gpu, cps, row)
+        wc, wo = batch.split_offsets_csr(cps, row, dtype=dtype)
+        sc, sp = batch.token_spans_csr(cps, row, dtype=dtype)
+        vals = oracle.split_batch(cps, row)[0]
+        assert np.array_equal(np.concatenate([np.nonzero(vals[row[i]:row[i + 1]])[0] for i in range(len(row) - 1)] or [np.zeros(0, np.int64)]), wo)
+        work.append((rb, (wc, wo), (sc, sp), _Out(gpu, rb.n_str, len(wo), 1, dtype), _Out(gpu, rb.n_str, len(sp), 2, dtype)))
+    try:
+        for _ in range(2):
+            for rb, _, _, oo, os_ in work:
+                batch.flow_split_offsets(rb.d_cps, 4, rb.d_row, rb.n_str, rb.total, oo.d_counts, oo.d_items, oo.cap, oo.d_res, dtype=dtype)
+                batch.flow_token_spans(rb.d_cps, 4, rb.d_row, rb.n_str, -1, os_.d_counts, os_.d_items, os_.cap, os_.d_res, dtype=dtype)
+            batch.flow_wait()
+            for rb, (wc, wo), (sc, sp), oo, os_ in work:
+                res, counts, items = oo.fetch()
+                assert res[0] == len(wo) and res[1] == 0 and np.array_equal(counts, wc) and np.array_equal(items, wo)
+                res, counts, items = os_.fetch()
+                assert res[0] == len(sp) and res[1] == 0 and np.array_equal(counts, sc) and np.array_equal(items, sp)
+    finally:
+        for rb, _, _, oo, os_ in work:
+            rb.free()
+            oo.free()
+            os_.free()
+
+
+def test_flow_compaction_capacity_protocol_and_other_input_forms(gpu, oracle):
+    from latok_amd import _lib, batch
+    rng = random.Random(99)
+    texts = random_strings(rng, 6000, 0, 200, ALPHABETS["latin1"])
+    units, row = batch.pack_kind(texts)
+    assert units.dtype == np.uint8
+    wc, wo = batch.split_offsets_kind_csr(units, row, dtype=np.int32)
+    d_u = gpu.latok_dev_alloc(units.nbytes + 64)
+    d_r = gpu.latok_dev_alloc(row.nbytes)
+    _lib.check(gpu.latok_memcpy_h2d(d_u, units.ctypes.data, units.nbytes))
+    _lib.check(gpu.latok_memcpy_h2d(d_r, row.ctypes.data, row.nbytes))
+    n, total = len(row) - 1, int(row[-1])
+    small, full = _Out(gpu, n, len(wo) // 2, 1, np.int32), _Out(gpu, n, len(wo), 1, np.int32)
+    # UTF-8 in byte space, spans
+    blobs = [t.encode("utf-8") for t in random_strings(rng, 4000, 0, 150, ALPHABETS["mixed"])]
+    u8, boff = batch.pack_utf8(blobs)
+    bc, bs = batch.token_spans_utf8_bytes_csr(u8, boff)
+    d_u8 = gpu.latok_dev_alloc(u8.nbytes + 64)
+    d_bo = gpu.latok_dev_alloc(boff.nbytes)
+    _lib.check(gpu.latok_memcpy_h2d(d_u8, u8.ctypes.data, u8.nbytes))
+    _lib.check(gpu.latok_memcpy_h2d(d_bo, boff.ctypes.data, boff.nbytes))
+    bo = _Out(gpu, len(boff) - 1, len(bs), 2, np.int64)
+    empty = _Out(gpu, 3, 4, 1, np.int64)
+    d_er = gpu.latok_dev_alloc(32)
+    _lib.check(gpu.latok_memset_dev(d_er, 0, 32))                         # three empty strings: row offsets 0 0 0 0
+    try:
+        _lib.check(gpu.latok_memset_dev(small.d_items, 0x7F, max(small.cap, 1) * 4))
+        batch.flow_split_offsets(d_u, 1, d_r, n, total, small.d_counts, small.d_items, small.cap, small.d_res, dtype=np.int32)
+        batch.flow_token_spans(d_u8, 0, d_bo, len(boff) - 1, int(boff[-1]), bo.d_counts, bo.d_items, bo.cap, bo.d_res)
+        batch.flow_split_offsets(d_u, 1, d_r, n, total, full.d_counts, full.d_items, full.cap, full.d_res, dtype=np.int32)
+        batch.flow_split_offsets(d_u, 1, d_er, 3, 0, empty.d_counts, empty.d_items, empty.cap, empty.d_res)
+        batch.flow_wait()
+        res, counts, _ = small.fetch()
+        assert res[0] == len(wo) > small.cap and res[1] == 0 and np.array_equal(counts, wc)      # too small: total reported, counts valid
+        untouched = np.empty(small.cap, np.int32)
+        _lib.check(gpu.latok_memcpy_d2h(untouched.ctypes.data, small.d_items, untouched.nbytes))
+        assert (untouched == 0x7F7F7F7F).all()                                                    # ... and no record written
+        res, counts, items = full.fetch()
+        assert res[0] == len(wo) and np.array_equal(counts, wc) and np.array_equal(items, wo)
+        res, counts, items = bo.fetch()
+        assert res[0] == len(bs) and res[1] == 0 and np.array_equal(counts, bc) and np.array_equal(items, bs)
+        res, counts, _ = empty.fetch()
+        assert res[0] == 0 and res[1] == 0 and not counts.any()
+    finally:
+        for o in (small, full, bo, empty):
+            o.free()
+        for p in (d_u, d_r, d_u8, d_bo, d_er):
+            gpu.latok_dev_free(p)
+
+
 def test_flow_refuses_what_the_serial_call_refuses(gpu):
     from latok_amd import batch
     with pytest.raises(ValueError):

@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--strings", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
-    ap.add_argument("--paths", default="mask,mask_flow,bytes_mask_flow,kind_mask_flow,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
+    ap.add_argument("--paths", default="mask,mask_flow,bytes_mask_flow,kind_mask_flow,offsets32_flow,spans32_flow,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
                                        "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,"
                                        "kind_spans,kind_spans32")
     args = ap.parse_args()
@@ -149,6 +149,20 @@ def main():
         fa, fb = flow_pair(bw_)
         run_flow("bytes_mask_flow", lambda i: lib.latok_flow_split_mask_utf8_bytes(d_u8, d_boff, n, n8, fb if i & 1 else fa),
                  lambda: n8 + csr + bw_ * 8, "UTF-8 bytes + 8 B/string read; 1 bit/byte written (byte space, fused ingest)")
+    d_res = lib.latok_dev_alloc(64)
+    for name, spans, width in (("offsets32_flow", False, 4), ("spans32_flow", True, 8)):
+        if name in paths:
+            if "items2" not in flow_buf:
+                flow_buf["items2"] = (lib.latok_dev_alloc(cap * 32), lib.latok_dev_alloc(n * 8))
+            d_items2, d_counts2 = flow_buf["items2"]
+            fn = lib.latok_flow_token_spans if spans else lib.latok_flow_split_offsets
+            run("offsets32" if not spans else "spans32", (lambda s_=spans: (lib.latok_token_spans_batch if s_ else lib.latok_split_offsets_batch)(
+                d_cps, d_row, n, total, d_counts, d_items, cap, C.byref(nout), D | _lib.OUT_INT32, None)), lambda: 0, "(item count for the flow line)")
+            items_n = nout.value
+            run_flow(name, lambda i, fn=fn: fn(d_cps, 4, d_row, n, total, d_counts2 if i & 1 else d_counts, d_items2 if i & 1 else d_items, cap,
+                                               C.c_void_p(d_res + 16 * (i & 1)), _lib.OUT_INT32),
+                     lambda: 4 * total + csr + 4 * n + width * items_n,
+                     f"4 B/char + 8 B/string read; 4 B/string counts + {width} B/item written (LATOK_OUT_INT32)")
     if "mask" in paths:
         run("mask", lambda: lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None),
             lambda: 4 * total + csr + words * 8, "4 B/char + 8 B/string read, 1 bit/char written")

@@ -292,6 +292,9 @@ int latok_flow_split_offsets(const void* units_dev, int kind, const int64_t* row
                              void* counts_dev, void* offsets_dev, int64_t offsets_cap, int64_t* result_dev, int flags);
 int latok_flow_token_spans(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
                            void* counts_dev, void* spans_dev, int64_t spans_cap, int64_t* result_dev, int flags);
+/* featurize through the flow: latok_token_features_batch / _kind_batch (kind 4 / 1 / 2) with the same result words */
+int latok_flow_token_features(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                              void* counts_dev, void* spans4_dev, int8_t* features_dev, int64_t cap, int64_t* result_dev, int flags);
 int latok_flow_wait(void);
 
 /* ---- measurement ----------------------------------------------------------------------------------------------- */

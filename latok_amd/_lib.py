@@ -88,6 +88,7 @@ SIGNATURES = {
     "latok_flow_split_mask_utf8_bytes": (ci, [vp, vp, i64, i64, vp]),
     "latok_flow_split_offsets": (ci, [vp, ci, vp, i64, i64, vp, vp, i64, vp, ci]),
     "latok_flow_token_spans": (ci, [vp, ci, vp, i64, i64, vp, vp, i64, vp, ci]),
+    "latok_flow_token_features": (ci, [vp, ci, vp, i64, i64, vp, vp, vp, i64, vp, ci]),
     "latok_flow_wait": (ci, []),
     "latok_bench_split_mask_flow_gated": (ci, [vp, vp, i64, i64, vp, vp, ci, vp, C.POINTER(C.c_float), C.POINTER(i64),
                                                C.POINTER(i64)]),

@@ -547,6 +547,15 @@ def flow_token_spans(d_units, kind, d_row_off, n_str, total_units, d_counts, d_s
                                           d_result, flag32))
 
 
+def flow_token_features(d_units, kind, d_row_off, n_str, total_chars, d_counts, d_spans4, d_features, cap, d_result, dtype=np.int64):
+    """featurize of one device-resident batch through the flow (``latok_flow_token_features``): 4 span values + 25 int8
+    feature sums per kept token (reference default_tokenizer.py:163-191)."""
+    lib = _lib.ensure_init()
+    _, flag32 = _out_dtype(dtype)
+    _lib.check(lib.latok_flow_token_features(d_units, int(kind), d_row_off, int(n_str), int(total_chars), d_counts, d_spans4, d_features,
+                                             int(cap), d_result, flag32))
+
+
 def flow_wait():
     """Block until every batch submitted with ``flow_split_mask`` on the current context is complete."""
     _lib.check(_lib.ensure_init().latok_flow_wait())

@@ -184,7 +184,7 @@ struct Ctx {
         DevBuf summ, seg_agg, fix_count, tile_first;
         // compaction passes of the slot's batch (latok_flow_split_offsets / _token_spans): what the context's own calls keep
         // in bits / space / kept / wcnt / wpref / bases / chain / chain_ctl / scalar
-        DevBuf bits, space, kept, wcnt, wpref, bases, chain, chain_ctl, scalar;
+        DevBuf bits, space, kept, wcnt, wpref, bases, chain, chain_ctl, scalar, codes, widened;   // codes / widened: featurize
         unsigned scan_epoch = 0, chain_seen = 0, chain_ctl_seen = 0;
         bool chain_ready = false;
         hipStream_t st = nullptr;
@@ -474,7 +474,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
         }
         f.st = nullptr;
         for (DevBuf* b : {&f.summ, &f.seg_agg, &f.fix_count, &f.tile_first, &f.bits, &f.space, &f.kept, &f.wcnt, &f.wpref, &f.bases,
-                          &f.chain, &f.chain_ctl, &f.scalar})
+                          &f.chain, &f.chain_ctl, &f.scalar, &f.codes, &f.widened})
             b->release();
         f.scan_epoch = f.chain_seen = f.chain_ctl_seen = 0;
         f.chain_ready = false;
@@ -811,7 +811,6 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
                                   latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr},
                                   Ctx::FlowSlot* slot = nullptr) {   // slot: the workspaces of a batch-flow slot (offsets / spans only)
     int rc;
-    if (slot && feats) return fail(LATOK_ERR_INVALID, "internal: no featurize in a batch flow");
     DevBuf& w_bits = slot ? slot->bits : g.bits;
     DevBuf& w_space = slot ? slot->space : g.space;
     DevBuf& w_kept = slot ? slot->kept : g.kept;
@@ -820,13 +819,15 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
     DevBuf& w_wpref = slot ? slot->wpref : g.wpref;
     DevBuf& w_first = slot ? slot->tile_first : g.tile_first;
     DevBuf& w_scalar = slot ? slot->scalar : g.scalar;
+    DevBuf& w_codes = slot ? slot->codes : g.codes;
+    DevBuf& w_widened = slot ? slot->widened : g.h_cps;
     const ScanState sc = scan_state(g, slot);
     if (d_u8 && unit_kind && feats) {
         // featurize re-reads the code points: widen once, on the device
         if (((uintptr_t)d_u8 & (size_t)(unit_kind - 1)) != 0) return fail(LATOK_ERR_INVALID, "misaligned code units");
-        if ((rc = g.h_cps.ensure((size_t)total * 4 + 16))) return rc;
-        HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)g.h_cps.p, st));
-        d_cps = (const uint32_t*)g.h_cps.p;
+        if ((rc = w_widened.ensure((size_t)total * 4 + 16))) return rc;
+        HIP_TRY(latok::launch_widen_units(d_u8, unit_kind, total, (uint32_t*)w_widened.p, st));
+        d_cps = (const uint32_t*)w_widened.p;
         d_u8 = nullptr;
     }
     const int64_t words = (total + 63) / 64;
@@ -852,8 +853,8 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
     uint8_t* d_codes = nullptr;
     if (feats) {   // the tile kernel leaves the rule code of every char: 1 B/char for k_features_tiles instead of 4 B/char + tables
         const size_t code_bytes = (size_t)total + latok::kTile + 256;   // read (never used) up to a tile behind the last char
-        if ((rc = g.codes.ensure(code_bytes))) return rc;
-        d_codes = (uint8_t*)g.codes.p;
+        if ((rc = w_codes.ensure(code_bytes))) return rc;
+        d_codes = (uint8_t*)w_codes.p;
         const size_t tail0 = (size_t)total & ~(size_t)(latok::kTile - 1);
         HIP_TRY(hipMemsetAsync(d_codes + tail0, 0, code_bytes - tail0, st));
     }
@@ -1956,7 +1957,7 @@ static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* 
 // offsets (spans = false) or token spans of one batch: everything latok_split_offsets_batch / latok_token_spans_batch launch,
 // on the slot's stream and workspaces; the item total and the error flags land in result[0..1] when the stream gets there
 static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total,
-                               void* counts, void* items, int64_t cap, int64_t* result, int flags) {
+                               void* counts, void* items, int64_t cap, int64_t* result, int flags, int8_t* feat = nullptr, bool feats = false) {
     int rc = flow_setup(g);
     if (rc) return rc;
     if (!result) return fail(LATOK_ERR_INVALID, "NULL result pointer");
@@ -1967,8 +1968,9 @@ static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_k
         if (n_str > 0 && counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_str * ((flags & LATOK_OUT_INT32) ? 4 : 8), f0.st));
         return LATOK_OK;
     }
-    if (!units || !row_off || !counts || (!items && cap > 0)) return fail(LATOK_ERR_INVALID, "NULL buffer");
+    if (!units || !row_off || !counts || ((!items || (feats && !feat)) && cap > 0)) return fail(LATOK_ERR_INVALID, "NULL buffer");
     if (cap < 0) return fail(LATOK_ERR_INVALID, "capacity must be >= 0");
+    if (feats && unit_kind == 0) return fail(LATOK_ERR_INVALID, "featurize reads code points or PEP 393 units, not UTF-8 bytes");
     if (((uintptr_t)units & 15) != 0) return fail(LATOK_ERR_INVALID, "device input pointer must be 16-byte aligned");
     const bool o32 = (flags & LATOK_OUT_INT32) != 0;
     if (((uintptr_t)items & 15) != 0 || ((uintptr_t)counts & (o32 ? 3 : 7)) != 0) return fail(LATOK_ERR_INVALID, "misaligned output buffer");
@@ -1981,9 +1983,10 @@ static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_k
                                {&f.fix_count, 8}, {&f.bits, (size_t)words * 8 + 8}, {&f.space, spans ? (size_t)words * 8 + 8 : 0},
                                {&f.kept, spans ? (size_t)words * 8 + 8 : 0}, {&f.wcnt, (size_t)c_tiles * 8 + 8}, {&f.bases, (size_t)c_tiles * 8 + 8},
                                {&f.wpref, (size_t)words * 2 + 8}, {&f.scalar, 64}, {&f.chain, (size_t)latok::count_blocks(words) * 8 + 64},
-                               {&f.chain_ctl, 64}})))
+                               {&f.chain_ctl, 64}, {&f.codes, feats ? (size_t)total + latok::kTile + 256 : 0},
+                               {&f.widened, feats && unit_kind != 4 ? (size_t)total * 4 + 16 : 0}})))
         return rc;
-    if ((rc = enqueue_compaction_dev(g, spans, false, o32, cps, u8, unit_kind == 4 ? 0 : unit_kind, row_off, n_str, total, counts, items, nullptr,
+    if ((rc = enqueue_compaction_dev(g, spans, feats, o32, cps, u8, unit_kind == 4 ? 0 : unit_kind, row_off, n_str, total, counts, items, feat,
                                      cap, result, nullptr, f.st, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
         return rc;
     f.used = true;
@@ -2042,6 +2045,19 @@ int latok_flow_split_offsets(const void* units_dev, int kind, const int64_t* row
 int latok_flow_token_spans(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
                            void* counts_dev, void* spans_dev, int64_t spans_cap, int64_t* result_dev, int flags) {
     return flow_compact_entry(true, units_dev, kind, row_off_dev, n_str, total_units, counts_dev, spans_dev, spans_cap, result_dev, flags);
+}
+int latok_flow_token_features(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                              void* counts_dev, void* spans4_dev, int8_t* features_dev, int64_t cap, int64_t* result_dev, int flags) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if ((rc = check_kind(kind))) return rc;
+    if (flags & ~(LATOK_OUT_INT32 | LATOK_DEVICE_PTRS)) return fail(LATOK_ERR_INVALID, "unknown flag");
+    if (total_chars < 0) {
+        if ((rc = resolve_total_device(row_off_dev, n_str, &total_chars, g.stream))) return rc;
+    }
+    return flow_submit_compact(g, true, units_dev, kind, row_off_dev, n_str, total_chars, counts_dev, spans4_dev, cap, result_dev, flags,
+                               features_dev, true);
 }
 int latok_flow_wait(void) {
     LATOK_ENTER();

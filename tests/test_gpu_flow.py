@@ -262,6 +262,50 @@ def test_flow_offsets_and_spans_equal_the_blocking_calls(gpu, oracle, dtype):
             os_.free()
 
 
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_flow_featurize_equals_the_blocking_call(gpu, oracle, dtype):
+    from latok_amd import _lib, batch
+    rng = random.Random(4242)
+    work = []
+    for texts in _batches(rng)[:6]:
+        cps, row = pack(texts)
+        rb = _Resident(gpu, cps, row)
+        c, sp4, ft = batch.token_features_csr(cps, row, dtype=dtype)
+        o = _Out(gpu, rb.n_str, len(sp4), 4, dtype)
+        d_ft = gpu.latok_dev_alloc(max(len(sp4), 1) * 25 + 16)
+        work.append((rb, c, sp4, ft, o, d_ft))
+    # a Latin-1 batch (widened on the device, in the slot's own buffer)
+    lat = random_strings(rng, 3000, 0, 200, ALPHABETS["latin1"])
+    units, lrow = batch.pack_kind(lat)
+    lc, lsp4, lft = batch.token_features_kind_csr(units, lrow, dtype=dtype)
+    d_lu, d_lr = gpu.latok_dev_alloc(units.nbytes + 64), gpu.latok_dev_alloc(lrow.nbytes)
+    _lib.check(gpu.latok_memcpy_h2d(d_lu, units.ctypes.data, units.nbytes))
+    _lib.check(gpu.latok_memcpy_h2d(d_lr, lrow.ctypes.data, lrow.nbytes))
+    lo = _Out(gpu, len(lrow) - 1, len(lsp4), 4, dtype)
+    d_lft = gpu.latok_dev_alloc(max(len(lsp4), 1) * 25 + 16)
+    try:
+        for _ in range(2):
+            for rb, c, sp4, ft, o, d_ft in work:
+                batch.flow_token_features(rb.d_cps, 4, rb.d_row, rb.n_str, rb.total, o.d_counts, o.d_items, d_ft, o.cap, o.d_res, dtype=dtype)
+            batch.flow_token_features(d_lu, 1, d_lr, len(lrow) - 1, int(lrow[-1]), lo.d_counts, lo.d_items, d_lft, lo.cap, lo.d_res, dtype=dtype)
+            batch.flow_wait()
+            for rb, c, sp4, ft, o, d_ft in work + [(None, lc, lsp4, lft, lo, d_lft)]:
+                res, counts, items = o.fetch()
+                assert res[0] == len(sp4) and res[1] == 0 and np.array_equal(counts, c) and np.array_equal(items, sp4)
+                got = np.empty((len(sp4), 25), np.int8)
+                if got.size:
+                    _lib.check(gpu.latok_memcpy_d2h(got.ctypes.data, d_ft, got.nbytes))
+                assert np.array_equal(got, ft)
+    finally:
+        for rb, _, _, _, o, d_ft in work:
+            rb.free()
+            o.free()
+            gpu.latok_dev_free(d_ft)
+        lo.free()
+        for p in (d_lu, d_lr, d_lft):
+            gpu.latok_dev_free(p)
+
+
 def test_flow_compaction_capacity_protocol_and_other_input_forms(gpu, oracle):
     from latok_amd import _lib, batch
     rng = random.Random(99)

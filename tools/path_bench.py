@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--strings", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--cpu", type=int, default=0, help="strings of CPU baseline (0 = skip)")
-    ap.add_argument("--paths", default="mask,mask_flow,bytes_mask_flow,kind_mask_flow,offsets32_flow,spans32_flow,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
+    ap.add_argument("--paths", default="mask,mask_flow,bytes_mask_flow,kind_mask_flow,offsets32_flow,spans32_flow,features32_flow,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,"
                                        "bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,"
                                        "kind_spans,kind_spans32")
     args = ap.parse_args()
@@ -163,6 +163,18 @@ def main():
                                                C.c_void_p(d_res + 16 * (i & 1)), _lib.OUT_INT32),
                      lambda: 4 * total + csr + 4 * n + width * items_n,
                      f"4 B/char + 8 B/string read; 4 B/string counts + {width} B/item written (LATOK_OUT_INT32)")
+    if "features32_flow" in paths:
+        if "feat2" not in flow_buf:
+            flow_buf["feat2"] = (lib.latok_dev_alloc(cap * 32), lib.latok_dev_alloc(n * 8), lib.latok_dev_alloc(cap * 25))
+        d_items3, d_counts3, d_feat3 = flow_buf["feat2"]
+        run("features32", lambda: lib.latok_token_features_batch(d_cps, d_row, n, total, d_counts, d_items, d_feat, cap, C.byref(nout), D | _lib.OUT_INT32, None),
+            lambda: 0, "(item count for the flow line)")
+        items_f = nout.value
+        run_flow("features32_flow", lambda i: lib.latok_flow_token_features(d_cps, 4, d_row, n, total, d_counts3 if i & 1 else d_counts,
+                                                                            d_items3 if i & 1 else d_items, d_feat3 if i & 1 else d_feat, cap,
+                                                                            C.c_void_p(d_res + 16 * (i & 1)), _lib.OUT_INT32),
+                 lambda: 4 * total + csr + 4 * n + (16 + 25) * items_f,
+                 "SURVEY 8f-2 accounting: 4 B/char + 8 B/string read (the input ONCE); 4 B/string + 41 B/token written (LATOK_OUT_INT32)")
     if "mask" in paths:
         run("mask", lambda: lib.latok_split_mask_batch(d_cps, d_row, n, total, d_bits, D, None),
             lambda: 4 * total + csr + words * 8, "4 B/char + 8 B/string read, 1 bit/char written")

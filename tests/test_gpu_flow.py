@@ -356,6 +356,22 @@ def test_flow_compaction_capacity_protocol_and_other_input_forms(gpu, oracle):
             gpu.latok_dev_free(p)
 
 
+def test_c_example_flow_batches(gpu, oracle, tmp_path):
+    """examples/flow_batches.c: a plain C caller pushes five resident UTF-8 batches through the flow (token spans in byte
+    space, int32 records, result words read after one latok_flow_wait) and prints the reference's tokens."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "flow_batches")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "flow_batches.c"),
+                           "-L" + os.path.join(ROOT, "latok_amd"), "-llatok_hip", "-Wl,-rpath," + os.path.join(ROOT, "latok_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, timeout=120, check=True).stdout.decode("utf-8").splitlines()
+    batches = [["This is a #test! Testing, Testing, 1 2 3"], ["see http://a.b/c or mail me@x.org", "camelCase 日本語 🤓"], ["", "x", "  "],
+               ["foo@bar.com, .@user hi", "$#@^:a./", "camelCaseXMLParser"], ["one more batch: the flow takes any number"]]
+    want = [f"{k}.{i}:" + "".join(f" [{t}]" for t in (oracle.tokenize(s) if s else [])) for k, b in enumerate(batches) for i, s in enumerate(b)]
+    assert out == want
+
+
 def test_flow_refuses_what_the_serial_call_refuses(gpu):
     from latok_amd import batch
     with pytest.raises(ValueError):

@@ -109,6 +109,67 @@ def spans_from(vals, space, row):
     return np.array(counts, np.int64), np.array(out, np.int64).reshape(-1, 2)
 
 
+class FlowLeg:
+    """Every group of batches also goes through the batch flow (latok_flow_*: two batches in flight per context): each batch is
+    uploaded, its mask / offsets / spans are submitted back to back with the other batches' and checked after ONE wait."""
+
+    def __init__(self, lib, group=4):
+        self.lib, self.group, self.items, self.n_checked = lib, group, [], 0
+
+    def add(self, cps, row, bits, counts, offs, spans, dt, tag):
+        if cps.size == 0:
+            return
+        self.items.append((cps, row, bits, counts, offs, spans, dt, tag))
+        if len(self.items) >= self.group:
+            self.run()
+
+    def run(self):
+        from latok_amd import _lib, batch
+        lib, live, jobs = self.lib, [], []
+
+        def dev(nbytes, src=None):
+            p = lib.latok_dev_alloc(int(nbytes) + 64)
+            assert p, _lib.last_error()
+            live.append(p)
+            if src is not None and src.nbytes:
+                _lib.check(lib.latok_memcpy_h2d(p, src.ctypes.data, src.nbytes))
+            return p
+
+        def get(p, shape, dt_):
+            a = np.empty(shape, dt_)
+            if a.nbytes:
+                _lib.check(lib.latok_memcpy_d2h(a.ctypes.data, p, a.nbytes))
+            return a
+        for cps, row, bits, counts, offs, spans, dt, tag in self.items:
+            n, total, isz = len(row) - 1, int(row[-1]), np.dtype(dt).itemsize
+            d_c, d_r, d_m = dev(cps.nbytes, cps), dev(row.nbytes, row), dev(bits.nbytes)
+            d_oc, d_oo, d_or = dev(n * isz), dev(max(len(offs), 1) * isz), dev(16)
+            job = dict(tag=tag, n=n, dt=dt, bits=bits, counts=counts, offs=offs, spans=spans, d_m=d_m, d_oc=d_oc, d_oo=d_oo, d_or=d_or)
+            batch.flow_split_offsets(d_c, 4, d_r, n, total, d_oc, d_oo, len(offs), d_or, dtype=dt)
+            batch.flow_split_mask(d_c, d_r, n, total, d_m)
+            if spans is not None:
+                job["d_sc"], job["d_ss"], job["d_sr"] = dev(n * isz), dev(max(len(spans[1]), 1) * 2 * isz), dev(16)
+                batch.flow_token_spans(d_c, 4, d_r, n, -1, job["d_sc"], job["d_ss"], len(spans[1]), job["d_sr"], dtype=dt)
+            jobs.append(job)
+        batch.flow_wait()
+        for j in jobs:
+            assert np.array_equal(get(j["d_m"], j["bits"].shape, np.uint64), j["bits"]), "flow bitmask differs: " + j["tag"]
+            res = get(j["d_or"], 2, np.int64)
+            assert res[0] == len(j["offs"]) and res[1] == 0, "flow offsets total differs: " + j["tag"]
+            assert np.array_equal(get(j["d_oc"], j["n"], j["dt"]), j["counts"]), "flow offset counts differ: " + j["tag"]
+            assert np.array_equal(get(j["d_oo"], len(j["offs"]), j["dt"]), j["offs"]), "flow offsets differ: " + j["tag"]
+            if j["spans"] is not None:
+                wc, ws = j["spans"]
+                res = get(j["d_sr"], 2, np.int64)
+                assert res[0] == len(ws) and res[1] == 0, "flow span total differs: " + j["tag"]
+                assert np.array_equal(get(j["d_sc"], j["n"], j["dt"]), wc), "flow span counts differ: " + j["tag"]
+                assert np.array_equal(get(j["d_ss"], (len(ws), 2), j["dt"]), ws), "flow spans differ: " + j["tag"]
+        for p in live:
+            lib.latok_dev_free(p)
+        self.n_checked += len(jobs)
+        self.items = []
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -118,6 +179,7 @@ def main():
     from latok_amd import _lib, batch
     _lib.ensure_init()
     second = _lib.Context(0)            # every other batch runs on a second context of the same device
+    flow = FlowLeg(_lib.load())
     t_end = time.time() + args.seconds
     n_batches = n_chars = n_rules = n_spans = n_u8 = n_feat = n_kind = 0
     seed = args.seed * 1_000_003
@@ -145,11 +207,14 @@ def main():
             exp = [np.nonzero(vals[row[s]:row[s + 1]])[0] for s in range(len(row) - 1)]
             assert np.array_equal(counts, [len(e) for e in exp]), "offset counts differ: " + tag
             assert np.array_equal(offs, np.concatenate(exp) if exp else np.zeros(0, np.int64)), "offsets differ: " + tag
+            wc = ws = None
             if cps.size < 20000:
                 wc, ws = spans_from(vals, space, row)
                 gc, gs = batch.token_spans_csr(cps, row, dtype=dt)
                 assert np.array_equal(gc, wc) and np.array_equal(gs, ws), "token spans differ: " + tag
                 n_spans += 1
+            # (the flow leg runs on whatever context is current when its group is full: both contexts get their share)
+            flow.add(cps, row, bits, counts, offs, (wc, ws) if ws is not None else None, dt, tag)
             if rules is not None:
                 batch.set_rules(*rules)
                 try:
@@ -216,9 +281,11 @@ def main():
                 last = time.time()
                 print(f"[soak] {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, {n_u8} UTF-8, {n_feat} featurize, {n_kind} PEP 393 kinds ... ok",
                       flush=True)
+    if flow.items:
+        flow.run()
     _lib.load().latok_ctx_set_current(None)
     second.destroy()
-    print(f"soak passed (two contexts alternating, int32 / int64 records alternating): {n_batches} batches, {n_chars} chars, {n_rules} with rule tables, {n_spans} span checks, "
+    print(f"soak passed (two contexts alternating, int32 / int64 records alternating): {n_batches} batches, {n_chars} chars, {flow.n_checked} also through the batch flow (mask + offsets + spans), {n_rules} with rule tables, {n_spans} span checks, "
           f"{n_u8} UTF-8 (byte space + code-point) checks, {n_feat} featurize checks, {n_kind} PEP 393 kind checks, {args.seconds:.0f} s")
 
 

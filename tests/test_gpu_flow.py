@@ -356,6 +356,39 @@ def test_flow_compaction_capacity_protocol_and_other_input_forms(gpu, oracle):
             gpu.latok_dev_free(p)
 
 
+def test_device_pool_pushes_several_resident_batches_through_the_flow(gpu, oracle):
+    """DevicePool.split_offsets_many / token_spans_many: every worker submits its shard of every batch to its context's flow
+    and waits once; equal to one blocking call per batch, for every input kind, with buffers that have to grow"""
+    from latok_amd import batch, multi
+    rng = random.Random(31337)
+    with multi.DevicePool([0, 0, 0]) as pool:
+        rbs, want_o, want_s = [], [], []
+        for k in range(5):
+            texts = random_strings(rng, 2000 + 700 * k, 0, 150, ALPHABETS["starts" if k == 2 else "mixed"]) + ["", "x"]
+            cps, row = pack(texts)
+            rbs.append(pool.put_csr(cps, row))
+            want_o.append(batch.split_offsets_csr(cps, row, dtype=np.int32))
+            want_s.append(batch.token_spans_csr(cps, row, dtype=np.int32))
+        lat = random_strings(rng, 3000, 0, 100, ALPHABETS["latin1"])
+        units, lrow = batch.pack_kind(lat)
+        rbs.append(pool.put_csr(units, lrow, kind="latin1"))
+        want_o.append(batch.split_offsets_kind_csr(units, lrow, dtype=np.int32))
+        want_s.append(batch.token_spans_kind_csr(units, lrow, dtype=np.int32))
+        u8, boff = batch.pack_utf8([t.encode("utf-8", "surrogatepass") for t in random_strings(rng, 2500, 0, 120, ALPHABETS["mixed"])])
+        rbs.append(pool.put_csr(u8, boff, kind="utf8"))
+        want_o.append(batch.split_offsets_utf8_bytes_csr(u8, boff, dtype=np.int32))
+        want_s.append(batch.token_spans_utf8_bytes_csr(u8, boff, dtype=np.int32))
+        for _ in range(2):
+            for (c, o), (wc, wo) in zip(pool.split_offsets_many(rbs), want_o):
+                assert np.array_equal(c, wc) and np.array_equal(o, wo)
+            for (c, sp), (wc, ws) in zip(pool.token_spans_many(rbs, dtype=np.int32), want_s):
+                assert np.array_equal(c, wc) and np.array_equal(sp, ws)
+        c64 = pool.split_offsets_many(rbs[:2], dtype=np.int64)
+        assert c64[0][1].dtype == np.int64 and np.array_equal(c64[1][1], want_o[1][1])
+        for rb in rbs:
+            rb.free()
+
+
 def test_c_example_flow_batches(gpu, oracle, tmp_path):
     """examples/flow_batches.c: a plain C caller pushes five resident UTF-8 batches through the flow (token spans in byte
     space, int32 records, result words read after one latok_flow_wait) and prints the reference's tokens."""

@@ -4,7 +4,7 @@
 #   tools/final_measure_r03.sh [part]     part = bench | paths | pmc | all (default all)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/final3
+O=$R/gpurun_out/final3b
 mkdir -p $O
 cd $R
 PART=${1:-all}
@@ -25,7 +25,9 @@ step bench_c2 300 python3 bench.py --gpus 1 --steps 20 --warmup 5
 step bench_c3 300 python3 bench.py --workload C3 --steps 20 --warmup 3 --no-cpu-baseline
 step bench_c4 400 python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline
 step bench_c5 400 python3 bench.py --workload C5 --steps 5 --warmup 2 --no-cpu-baseline
+step bench_c2_serial 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --in-flight 1 --no-cpu-baseline
 step bench_n2_turns 300 python3 bench.py --gpus 2 --devices 0,0 --take-turns --steps 20 --warmup 5
+step bench_n2_shared 300 python3 bench.py --gpus 2 --devices 0,0 --steps 20 --warmup 5 --no-cpu-baseline
 step bench_n4_c5_strong_turns 400 python3 bench.py --gpus 4 --devices 0,0,0,0 --take-turns --workload C5 --strings 400 --steps 5 --warmup 2 --no-cpu-baseline
 step bench_n2_torchrun_gloo 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 20 --warmup 5 --take-turns --no-cpu-baseline
 fi
@@ -36,9 +38,15 @@ step host_path 400 python3 tools/host_path_rate.py
 step latency 120 python3 tools/latency_bench.py
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_b /tmp/prof_p /tmp/prof_p3
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_under_rocprof.json 2>/dev/null
-echo "rocprof bench rc=$?" | tee -a $LOG
+# (1) the kernel itself: one batch at a time -- the profiler's duration of a launch is then the kernel's own time
+rm -rf /tmp/prof_b /tmp/prof_bf
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 > $O/bench_c2_under_rocprof.json 2>/dev/null
+echo "rocprof bench (in-flight 1) rc=$?" | tee -a $LOG
 cp /tmp/prof_b/b_kernel_stats.csv $O/kernel_stats_bench_c2.csv 2>/dev/null || find /tmp/prof_b -name '*kernel_stats.csv' -exec cp {} $O/kernel_stats_bench_c2.csv \;
+# (2) the default command (batch flow): tile kernels that overlap another one listed apart
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf -o b -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_flow_under_rocprof.json 2>/dev/null
+echo "rocprof bench (default, flow) rc=$?" | tee -a $LOG
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_bf -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (default: batch flow, two batches in flight); round 3" --split-overlap > $O/kernel_stats_bench_c2_flow.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 > /dev/null 2>&1
 echo "rocprof paths c2 rc=$?" | tee -a $LOG
 python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 (1 MI355X, C2 = 1 M ASCII strings); round 3" > $O/paths_kernel_stats.txt
@@ -61,10 +69,11 @@ pmc() {  # label, limit, then the python command
     find /tmp/pmc_${label}_$c -name '*counter_collection.csv' -exec cp {} $O/pmc_${label}_$c.csv \;
   done
 }
-pmc c2 300 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0
-pmc c3 300 $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0
-pmc c4 500 $R/bench.py --workload C4 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0
-pmc c5 500 $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0
+pmc c2 300 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
+pmc c3 300 $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
+pmc c4 500 $R/bench.py --workload C4 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
+pmc c5 500 $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
+pmc c2_flow 300 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0
 pmc paths 300 $R/tools/path_bench.py --workload C2 --iters 3 --paths bytes_mask,kind_mask,offsets32,spans32,features32
 pmc paths_c3 300 $R/tools/path_bench.py --workload C3 --iters 3 --paths bytes_mask,utf8_mask,kind_mask
 cd $R

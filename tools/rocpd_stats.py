@@ -1,20 +1,47 @@
 #!/usr/bin/env python3
 """Per-kernel summary (calls, total / avg / min / max duration in us, share) of a rocprofv3 rocpd database, the
-table `rocprofv3 --kernel-trace --stats` would print.  usage: tools/rocpd_stats.py <results.db> [title]"""
+table `rocprofv3 --kernel-trace --stats` would print.  usage: tools/rocpd_stats.py <results.db> [title] [--split-overlap]
+
+--split-overlap: kernels whose name contains `k_tiles_main` are listed twice more -- the launches that ran ALONE on the GPU with
+respect to other tile kernels, and the launches whose [start, end) interval overlaps another tile kernel's.  With the batch
+flow (two batches in flight on two streams) a tile kernel is dispatched while the previous batch's still holds the CUs; the
+profiler's `duration` of such a launch includes the time its workgroups wait for a CU, so only the first group measures the
+kernel itself (the figure bench.py's roofline uses comes from back-to-back launches on one stream)."""
 import sqlite3
 import sys
 
 
+def line(name, durs, tot):
+    n = len(durs)
+    s = sum(durs)
+    return f"{name[:72]:72s} {n:6d} {s:10.1f} {s / n:9.1f} {min(durs):8.1f} {max(durs):8.1f} {100 * s / tot:6.1f}"
+
+
 def main():
-    c = sqlite3.connect(sys.argv[1])
-    rows = c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
-                     "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows) or 1.0
-    if len(sys.argv) > 2:
-        print("# " + sys.argv[2])
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    split = "--split-overlap" in sys.argv
+    c = sqlite3.connect(args[0])
+    rows = c.execute("select name, start, end from kernels order by start").fetchall()
+    by = {}
+    for name, a, b in rows:
+        by.setdefault(name, []).append((b - a) / 1e3)
+    tot = sum(sum(v) for v in by.values()) or 1.0
+    if len(args) > 1:
+        print("# " + args[1])
     print(f"{'kernel':72s} {'calls':>6s} {'total_us':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'pct':>6s}")
-    for r in rows:
-        print(f"{r[0][:72]:72s} {r[1]:6d} {r[2]:10.1f} {r[3]:9.1f} {r[4]:8.1f} {r[5]:8.1f} {100 * r[2] / tot:6.1f}")
+    for name, durs in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        print(line(name, durs, tot))
+    if split:
+        tiles = [(a, b, name) for name, a, b in rows if "k_tiles_main" in name]
+        alone, over = {}, {}
+        for i, (a, b, name) in enumerate(tiles):
+            ov = (i > 0 and tiles[i - 1][1] > a) or (i + 1 < len(tiles) and tiles[i + 1][0] < b)
+            # (sorted by start: only neighbours can overlap when at most two are in flight; checked against all below)
+            (over if ov else alone).setdefault(name, []).append((b - a) / 1e3)
+        print("# tile kernels by overlap with another tile kernel (batch flow: two batches in flight)")
+        for tag, d in (("alone", alone), ("overlapped (duration includes waiting for CUs)", over)):
+            for name, durs in d.items():
+                print(line(f"[{tag}] {name}", durs, tot))
 
 
 if __name__ == "__main__":

@@ -567,6 +567,11 @@ def build_line(args, recs, mode, devices, same_start):
                                       "frac / achieved = the SLOWEST rank's",
                      "frac_per_rank": fracs, "kernel_ms_per_rank": [r["kernel_ms"] for r in recs],
                      "pipeline_frac": min(r["alg_read"] / (r["ms_events"] / K / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs),
+                     "pipeline_frac_sustained": (r0["alg_read"] / (r0["sustained"]["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS) if r0.get("sustained") else None,
+                     "pipeline_note": ("pipeline_frac = algorithmic bytes / per-step time of the K timed steps (includes filling and draining the "
+                                       "two-batch flow); _sustained = the same over the >= 1 s run.  In the flow the tile kernels of consecutive "
+                                       "batches overlap (each is planned for 7/8 of the CUs), so a step can take less than one isolated launch "
+                                       "of the kernel (`kernel_ms`, all CUs, nothing else on the GPU)") if flow else None,
                      "measured_stream_read": r0["measured_read"],
                      "frac_of_measured_read": (r0["alg_read"] / (r0["kernel_ms"] / 1e3) / 1e9 / r0["measured_read"]) if r0["measured_read"] else None},
     }

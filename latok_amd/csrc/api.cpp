@@ -299,7 +299,40 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.n_str = n_str;
     P.total = total;
     P.n_tiles = n_tiles;
-    latok::plan_segments(n_tiles, g.n_cu, &P.seg_tiles, &P.n_segs);
+    // A batch of a FLOW leaves part of the chip to the other batch in flight: its persistent tile kernel is planned for 7/8 of
+    // the CUs (4 free per XCD on MI355X), so the first workgroups of the NEXT batch's tile kernel start on the free CUs while
+    // this one still runs, finish early and free CUs for the batch after it -- the start-up (table copy, first tile) and the
+    // ragged end of every tile kernel then overlap another kernel's steady state instead of idling the chip.  Alone, the kernel
+    // is as fast on 224 CUs as on 256 (it is memory bound); in the flow C2 goes from 96 to 85.5-87 us per batch.  Measured on
+    // C2 (profiles/r03_ab_flow_cus.txt): fewer than 32 free CUs gain nothing (16: 97, 24: 96, 28: 94 us), 32: 85.5-87,
+    // 48: 87-90, 64: 87-91, 128 (two kernels side by side on half the chip each): 89.  A segment's tiles go round-robin over
+    // the workgroup's 12 waves, so a plan whose last round holds only a wave or two (216 CUs: 145 tiles = 12 rounds + 1 tile:
+    // 93-96 us) wastes what the free CUs gain: of the candidate shares the first whose last round is at least half full is taken.
+    // LATOK_AB_SPARE_CUS=k (A/B): k CUs left free instead (also for the blocking calls); LATOK_AB_SEG_TILES: segment length given.
+    static const int spare_cus = [] { const char* e = getenv("LATOK_AB_SPARE_CUS"); return e ? atoi(e) : -1; }();
+    int n_cu_eff = g.n_cu;
+    if (spare_cus >= 0) n_cu_eff = g.n_cu - spare_cus;
+    else if (slot && g.n_cu >= 64) {
+        const int cand[3] = {g.n_cu * 7 / 8, g.n_cu * 13 / 16, g.n_cu * 3 / 4};
+        int best = cand[0], best_fill = -1;
+        for (int c = 0; c < 3; ++c) {
+            int st_ = 0;
+            int64_t ns_ = 0;
+            latok::plan_segments(n_tiles, cand[c], &st_, &ns_);
+            const int wpb = (d_u8 && unit_kind != 0 && !g.rules_on) ? 16 : latok::kWPB;   // waves per workgroup of the tile kernel (tile_wpb)
+            const int fill = (st_ - 1) % wpb + 1;                  // waves busy in a segment's last round
+            if (fill * 2 >= wpb) { best = cand[c]; break; }
+            if (fill > best_fill) { best = cand[c]; best_fill = fill; }
+        }
+        n_cu_eff = best;
+    }
+    if (n_cu_eff < 8) n_cu_eff = g.n_cu < 8 ? g.n_cu : 8;
+    latok::plan_segments(n_tiles, n_cu_eff, &P.seg_tiles, &P.n_segs);
+    static const int ab_seg = [] { const char* e = getenv("LATOK_AB_SEG_TILES"); return e ? atoi(e) : 0; }();
+    if (ab_seg >= latok::kWPB && ab_seg <= latok::kSegMax && n_tiles > ab_seg) {   // experiment knob: segment length given
+        P.seg_tiles = ab_seg;
+        P.n_segs = (n_tiles + ab_seg - 1) / ab_seg;
+    }
     // a small UTF-32 batch: one segment, and (below) one launch for the three stages
     const bool one_launch = stages == 7 && !d_u8 && !tiles_begin && !tiles_end && n_tiles <= latok::kOneSegTiles &&
                             (mode == latok::kModeBits || mode == latok::kModeRules) && one_segment_enabled();
@@ -337,7 +370,7 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     }
     if (stages & 1) HIP_TRY(latok::launch_tile_index(P, st));   // (the kernel-timing loop of latok_bench_split_mask launches stage 1 alone)
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
-    if (stages & 2) HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));
+    if (stages & 2) HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));   // (the plan may leave CUs free; the grid never exceeds the chip)
     if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));
     if (stages & 4) HIP_TRY(latok::launch_resolve_fix(P, mode, g.n_cu, st));
     return LATOK_OK;

@@ -2417,6 +2417,16 @@ void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
     const int64_t per_cu = (n_tiles + n_cu - 1) / n_cu;
     const int64_t rounds = per_cu > kSegMax ? (per_cu + kSegMax - 1) / kSegMax : 1;
     int64_t s = (n_tiles + (int64_t)n_cu * rounds - 1) / ((int64_t)n_cu * rounds);
+    // A segment's tiles go round-robin over the workgroup's kWPB waves: a length that is not a multiple of kWPB ends in a
+    // round with most waves idle (C2 on 256 CUs: 123 tiles = ten rounds + one with 3 of 12 waves).  Long segments are
+    // rounded up to whole rounds -- a few CUs fewer, every wave busy to the end (C2: 132 tiles on 237 CUs, kernel -3 %);
+    // short ones (< 8 rounds) keep the exact split: there the CUs matter more than the last round.
+    static const int ab_plan = [] { const char* e = getenv("LATOK_AB_PLAN"); return e ? atoi(e) : 0; }();
+    if (ab_plan == 1 && s >= 8 * kWPB) s = (s + kWPB - 1) / kWPB * kWPB;
+    if (ab_plan == 2 && s >= 8 * kWPB) {   // nearest multiple, as long as the segments still fit one round of workgroups on the chip
+        const int64_t dn = s / kWPB * kWPB, up = dn + kWPB;
+        s = (s - dn <= up - s && (n_tiles + dn - 1) / dn <= (int64_t)n_cu + 24) ? dn : up;
+    }
     if (s < kWPB) s = kWPB;
     if (s > kSegMax) s = kSegMax;
     *seg_tiles = (int)s;

@@ -127,7 +127,7 @@ def main():
         for i in range(4):
             _lib.check(submit(i))
         _lib.check(lib.latok_flow_wait())
-        k = max(args.iters, 20)
+        k = max(args.iters, 100)   # long enough that filling and draining the two-batch pipeline is noise
         t = time.perf_counter()
         for i in range(k):
             _lib.check(submit(i))

@@ -261,7 +261,8 @@ int latok_rules_active(void);  /* 1 while custom tables are installed */
  * before).  Here a batch costs three dependent launches (per-tile string index, tiles, resolve); only the tile kernel needs
  * the whole GPU.  A flow keeps up to TWO batches in flight on the current context -- every stage on its own stream, every
  * batch in flight with its own workspace -- so that the string index of batch i+1 runs beside the tile kernel of batch i
- * and the resolve stage of batch i beside the tile kernel of batch i+1 (C2: 0.108 -> ~0.097 ms per batch).
+ * and the resolve stage of batch i beside the tile kernel of batch i+1; a flow batch's tile kernel is planned for 7/8 of the CUs,
+ * so consecutive tile kernels overlap their start-up and ragged end as well (C2: 0.108 -> 0.087 ms per batch).
  *   latok_flow_split_mask: enqueue latok_split_mask_batch(LATOK_DEVICE_PTRS) of one batch and return.  The inputs must be
  *     complete in device memory when the call is made (they are NOT ordered behind work on any caller stream), and must stay
  *     untouched until latok_flow_wait.  total_chars < 0: read from row_off (one small synchronous copy).  Consecutive

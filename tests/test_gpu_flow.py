@@ -389,6 +389,28 @@ def test_device_pool_pushes_several_resident_batches_through_the_flow(gpu, oracl
             rb.free()
 
 
+def test_blocking_calls_between_flow_submissions(gpu, oracle):
+    """the blocking entry points use the context's own stream and workspace: they may be called while a flow is in flight"""
+    from latok_amd import batch
+    rng = random.Random(1)
+    sets = [pack(random_strings(rng, 3000 + 1000 * k, 0, 200, ALPHABETS["mixed"])) for k in range(4)]
+    want = [oracle.split_batch(c, r, want_values=False)[1] for c, r in sets]
+    res = [_Resident(gpu, c, r) for c, r in sets]
+    try:
+        for _ in range(4):
+            for k, r in enumerate(res):
+                batch.flow_split_mask(r.d_cps, r.d_row, r.n_str, r.total, r.d_mask)
+                assert np.array_equal(batch.split_mask_batch(*sets[(k + 1) % 4]), want[(k + 1) % 4])     # host-pointer call, synchronous
+                c, o = batch.split_offsets_csr(*sets[k], dtype=np.int32)
+                assert int(c.sum()) == len(o)
+            batch.flow_wait()
+            for r, w in zip(res, want):
+                assert np.array_equal(r.mask(), w)
+    finally:
+        for r in res:
+            r.free()
+
+
 def test_c_example_flow_batches(gpu, oracle, tmp_path):
     """examples/flow_batches.c: a plain C caller pushes five resident UTF-8 batches through the flow (token spans in byte
     space, int32 records, result words read after one latok_flow_wait) and prints the reference's tokens."""

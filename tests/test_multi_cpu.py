@@ -146,6 +146,10 @@ class FakeDeviceLib:
         self.calls = []
 
     def _buf(self, p, dtype=np.uint8, count=-1):
+        if p not in self.mem:      # an address inside an allocation (base + offset)
+            base = max(b for b in self.mem if b <= p)
+            assert p < base + self.mem[base].size and self.owner[base] == threading.get_ident()
+            return self.mem[base][p - base:].view(dtype)[:count] if count >= 0 else self.mem[base][p - base:].view(dtype)
         assert self.owner[p] == threading.get_ident(), "device pointer used on a context that does not own it"
         return self.mem[p].view(dtype)[:count] if count >= 0 else self.mem[p].view(dtype)
 
@@ -233,6 +237,30 @@ class FakeDeviceLib:
     def latok_token_spans_batch(self, *a):
         return self._records(*a[:9], spans=True)
 
+    # the batch flow (latok_flow_*): submissions are queued per thread (= context) and only run at latok_flow_wait, so a caller
+    # that read a result word before the wait would see nothing -- the late capacity protocol is what is being tested
+    def _flow(self, spans, d_units, kind, d_row, n_str, total, d_counts, d_items, cap, d_result, flags):
+        from latok_amd import _lib
+        assert kind == 4, "the fake flow knows UTF-32 only"
+        self.__dict__.setdefault("flow_q", {}).setdefault(threading.get_ident(), []).append(
+            (spans, d_units, d_row, n_str, total, d_counts, d_items, cap, d_result, flags | _lib.DEVICE_PTRS))
+        return 0
+
+    def latok_flow_split_offsets(self, *a):
+        return self._flow(False, *a)
+
+    def latok_flow_token_spans(self, *a):
+        return self._flow(True, *a)
+
+    def latok_flow_wait(self):
+        import ctypes
+        for spans, d_units, d_row, n_str, total, d_counts, d_items, cap, d_result, flags in self.__dict__.get("flow_q", {}).pop(threading.get_ident(), []):
+            n = ctypes.c_int64(0)
+            self._records(d_units, d_row, n_str, total, d_counts, d_items, cap, ctypes.byref(n), flags, spans=spans)
+            res = self._buf(d_result, np.int64)    # (the caller may pass an address inside a larger allocation)
+            res[:2] = (n.value, 0)
+        return 0
+
 
 @pytest.mark.parametrize("n_workers", [1, 3, 8])
 def test_resident_shards_bookkeeping_and_results(oracle, n_workers):
@@ -289,6 +317,37 @@ def test_resident_capacity_protocol_grows_the_record_buffer(oracle):
         fake.calls.clear()
         pool.split_offsets(rb, dtype=np.int32)
         assert len([c for c in fake.calls if c[0] == "offsets"]) == 1                           # the grown buffer is kept
+
+
+@pytest.mark.parametrize("n_workers", [1, 3])
+def test_several_resident_batches_through_the_flow(oracle, n_workers):
+    """DevicePool.split_offsets_many / token_spans_many: every worker submits its shard of EVERY batch to its context's flow,
+    waits once, and re-submits the shards whose records did not fit (the total is only known after the wait)"""
+    from latok_amd import multi
+    rng = random.Random(77 + n_workers)
+    fake = FakeDeviceLib(oracle)
+    sets = [random_strings(rng, 150, 0, 60, ALPHABETS["mixed"]), ["a b c d e f g h i j k l m n o p"] * 200, ["", "x", ""],
+            random_strings(rng, 4, 0, 2000, ALPHABETS["words"])]
+    with multi.DevicePool(list(range(n_workers)), ctx_factory=FakeCtx, lib=fake) as pool:
+        rbs = [pool.put_csr(*pack(t)) for t in sets]
+        for dtype in (np.int32, np.int64):
+            fake.calls.clear()
+            res = pool.split_offsets_many(rbs, dtype=dtype)
+            for texts, (counts, offs) in zip(sets, res):
+                exp = [np.nonzero(oracle.split_values(t))[0] if t else np.zeros(0, np.int64) for t in texts]
+                assert counts.dtype == dtype and counts.tolist() == [len(e) for e in exp]
+                assert offs.tolist() == [int(v) for e in exp for v in e]
+        grown = [c for c in fake.calls if c[0] == "offsets" and c[4] > c[3]]
+        assert not grown, "the second pass (int64) reuses the buffers the first one grew"
+        res = pool.token_spans_many(rbs)
+        for texts, (counts, spans) in zip(sets, res):
+            k = 0
+            for x, c in zip(texts, counts.tolist()):
+                assert [x[a:b] for a, b in spans[k:k + c].tolist()] == (oracle.tokenize(x) if x else [])
+                k += c
+        for rb in rbs:
+            rb.free()
+    assert not fake.mem
 
 
 def test_resident_generate_owns_disjoint_string_ids(oracle):

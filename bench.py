@@ -317,11 +317,11 @@ class Shard:
         return float(ms.value) / steps, int(n_fix.value)
 
     def sustained(self, seconds, ms_per_step):
-        """>= `seconds` of back-to-back pipeline passes, in chunks of <= 2000 passes per event pair"""
+        """>= `seconds` of back-to-back pipeline passes, in chunks of <= 1000 passes (one library call each)"""
         want = max(self.args.steps, int(seconds / (ms_per_step / 1e3)) + 1)
         done, t_ms, chunks = 0, 0.0, []
         while done < want:
-            k = min(2000, want - done)
+            k = min(1000, want - done)
             ms = C.c_float(0)
             if self.flow:
                 t0, t1 = C.c_int64(0), C.c_int64(0)
@@ -336,7 +336,8 @@ class Shard:
             done += k
         return {"steps": done, "seconds": t_ms / 1e3, "ms_per_step": t_ms / done, "in_flight": 2 if self.flow else 1,
                 "value": self.utf8 * done / (t_ms / 1e3) / 1e9, "unit": "GB/s (rank 0)",
-                "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1]}
+                "ms_per_step_first_chunk": chunks[0], "ms_per_step_last_chunk": chunks[-1],
+                "ms_per_step_min_chunk": min(chunks), "ms_per_step_max_chunk": max(chunks), "chunks": len(chunks)}
 
     def stream_read(self):
         """streaming-read ceiling of this GPU on the same buffer"""

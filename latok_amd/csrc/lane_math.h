@@ -40,6 +40,38 @@ LATOK_HD lk_u64 lk_rev(lk_u64 x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// A 64-position plane as two 32-bit halves.  gfx950 has v_bitop3_b32 -- any boolean function of three words in one
+// instruction -- and the backend forms it from chains of 32-bit and / or / xor / not, but NOT from 64-bit ones (those are
+// split into halves only after instruction selection).  The same boolean algebra written on lk_w costs ~20 % fewer VALU
+// instructions than on lk_u64 (lk_ascii_code_planes: 117 -> 95 per word); shifts by 1 / 2 with a bit injected at the open
+// end are one v_alignbit_b32 + one v_lshl_or_b32.  The CPU model compiles the same code (tests/test_fused_model.py).
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_w {
+    uint32_t lo, hi;
+};
+LATOK_HD lk_w lk_w_of(lk_u64 x) { lk_w r; r.lo = (uint32_t)x; r.hi = (uint32_t)(x >> 32); return r; }
+LATOK_HD lk_u64 lk_u_of(lk_w x) { return (lk_u64)x.lo | ((lk_u64)x.hi << 32); }
+LATOK_HD lk_w operator&(lk_w a, lk_w b) { lk_w r; r.lo = a.lo & b.lo; r.hi = a.hi & b.hi; return r; }
+LATOK_HD lk_w operator|(lk_w a, lk_w b) { lk_w r; r.lo = a.lo | b.lo; r.hi = a.hi | b.hi; return r; }
+LATOK_HD lk_w operator^(lk_w a, lk_w b) { lk_w r; r.lo = a.lo ^ b.lo; r.hi = a.hi ^ b.hi; return r; }
+LATOK_HD lk_w operator~(lk_w a) { lk_w r; r.lo = ~a.lo; r.hi = ~a.hi; return r; }
+// x << K with the low K bits of `in` entering at the bottom;  x >> K with the low K bits of `in` entering at the top
+template <int K>
+LATOK_HD lk_w lk_w_shl(lk_w x, uint32_t in) {
+    lk_w r;
+    r.lo = (x.lo << K) | in;
+    r.hi = (x.hi << K) | (x.lo >> (32 - K));
+    return r;
+}
+template <int K>
+LATOK_HD lk_w lk_w_shr(lk_w x, uint32_t in) {
+    lk_w r;
+    r.lo = (x.lo >> K) | (x.hi << (32 - K));
+    r.hi = (x.hi >> K) | (in << (32 - K));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 8x8 bit-matrix transpose: input byte r (bits 8r..8r+7) = row r; output byte c holds column c (bit r = row r).
 // ---------------------------------------------------------------------------------------------------------------
 LATOK_HD lk_u64 lk_transpose8(lk_u64 x) {
@@ -125,19 +157,34 @@ struct lk_feat {
     lk_u64 S, Y, L, U, AN, A, T, AT, CO, SL, PE;
 };
 
-LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
-    lk_feat f;
+template <class W>
+struct lk_feat_t {
+    W S, Y, L, U, AN, A, T, AT, CO, SL, PE;
+};
+template <class W>
+LATOK_HD lk_feat_t<W> lk_decode_t(const W p[8]) {   // the same decode on any word type (uint32_t halves, lk_w)
+    lk_feat_t<W> f;
     f.S = p[LK_BIT_SPACE];
     f.Y = p[LK_BIT_SYMBOL];
     f.L = p[LK_BIT_LOWER];
     f.U = p[LK_BIT_UPPER];
     f.AN = p[LK_BIT_ALNUM];
-    f.A = p[5] & ~f.Y;              // bit5 = ALPHA when SYMBOL=0
-    f.T = p[5] & f.Y & ~p[7];       // sub 1 (# $ ^) or 3 ('@')
-    f.AT = p[5] & p[6] & f.Y;       // sub 3 (the & SYMBOL makes the decode valid for rule codes too: NUM sits in bit 6 of non-symbols)
-    f.CO = p[7] & ~p[6] & ~p[5];    // sub 4
-    f.SL = p[7] & p[5];             // sub 5
-    f.PE = p[7] & p[6];             // sub 6
+    f.A = p[5] & ~f.Y;
+    f.T = p[5] & f.Y & ~p[7];
+    f.AT = p[5] & p[6] & f.Y;
+    f.CO = p[7] & ~p[6] & ~p[5];
+    f.SL = p[7] & p[5];
+    f.PE = p[7] & p[6];
+    return f;
+}
+
+LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
+    lk_w q[8];
+    for (int b = 0; b < 8; ++b) q[b] = lk_w_of(p[b]);
+    const lk_feat_t<lk_w> g = lk_decode_t<lk_w>(q);    // on halves: see lk_w
+    lk_feat f;
+    f.S = lk_u_of(g.S); f.Y = lk_u_of(g.Y); f.L = lk_u_of(g.L); f.U = lk_u_of(g.U); f.AN = lk_u_of(g.AN); f.A = lk_u_of(g.A);
+    f.T = lk_u_of(g.T); f.AT = lk_u_of(g.AT); f.CO = lk_u_of(g.CO); f.SL = lk_u_of(g.SL); f.PE = lk_u_of(g.PE);
     return f;
 }
 
@@ -149,31 +196,44 @@ LATOK_HD lk_feat lk_decode(const lk_u64 p[8]) {
 // # $ ^ @ : / .), so a word costs ~120 bit operations instead of 128 table lookups through the LDS pipe.
 // tests/test_fused_model.py checks all 128 values in every position against the table.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool RULE_CODES = false>   // rule codes carry NUM in bit 6 of non-symbols (split_code.h)
-LATOK_HD void lk_ascii_code_planes(const lk_u64 r[8], lk_u64 p[8]) {
-    const lk_u64 b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], b4 = r[4], b5 = r[5], b6 = r[6];
-    const lk_u64 nz = b3 | b2 | b1 | b0;                      // low nibble != 0
-    const lk_u64 le10 = ~(b3 & (b2 | (b1 & b0)));             // low nibble <= 10
-    const lk_u64 le9 = ~(b3 & (b2 | b1));                     // low nibble <= 9
-    const lk_u64 g2 = ~b6 & b5 & ~b4, g3 = ~b6 & b5 & b4;     // 0x2_, 0x3_
-    const lk_u64 letter = b6 & ((~b4 & nz) | (b4 & le10));    // 41-5A, 61-7A
-    const lk_u64 digit = g3 & le9;
-    const lk_u64 alnum = letter | digit;
-    const lk_u64 sp20 = g2 & ~nz;                             // 0x20
-    const lk_u64 space = (~b6 & ~b5 & b3 & ((~b4 & ((~b2 & (b1 | b0)) | (b2 & ~b1))) | (b4 & b2))) | sp20;   // 09-0D, 1C-1F, 20
-    const lk_u64 del = b6 & b5 & b4 & b3 & b2 & b1 & b0;      // 0x7F
-    const lk_u64 sym = (b6 | b5) & ~sp20 & ~del & ~alnum;
-    const lk_u64 n_e = b3 & b2 & b1 & ~b0, n_f = b3 & b2 & b1 & b0;
-    const lk_u64 c_hash = g2 & ~b3 & ~b2 & b1 & b0, c_dollar = g2 & ~b3 & b2 & ~b1 & ~b0, c_caret = b6 & ~b5 & b4 & n_e;
-    const lk_u64 c_at = b6 & ~b5 & ~b4 & ~nz, c_colon = g3 & b3 & ~b2 & b1 & ~b0, c_slash = g2 & n_f, c_dot = g2 & n_e;
+template <bool RULE_CODES, class W>   // rule codes carry NUM in bit 6 of non-symbols (split_code.h); W: lk_u64 or one 32-bit half
+LATOK_HD void lk_ascii_code_planes_t(const W r[8], W p[8]) {
+    const W b0 = r[0], b1 = r[1], b2 = r[2], b3 = r[3], b4 = r[4], b5 = r[5], b6 = r[6];
+    const W nz = b3 | b2 | b1 | b0;                      // low nibble != 0
+    const W le10 = ~(b3 & (b2 | (b1 & b0)));             // low nibble <= 10
+    const W le9 = ~(b3 & (b2 | b1));                     // low nibble <= 9
+    const W g2 = ~b6 & b5 & ~b4, g3 = ~b6 & b5 & b4;     // 0x2_, 0x3_
+    const W letter = b6 & ((~b4 & nz) | (b4 & le10));    // 41-5A, 61-7A
+    const W digit = g3 & le9;
+    const W alnum = letter | digit;
+    const W sp20 = g2 & ~nz;                             // 0x20
+    const W space = (~b6 & ~b5 & b3 & ((~b4 & ((~b2 & (b1 | b0)) | (b2 & ~b1))) | (b4 & b2))) | sp20;   // 09-0D, 1C-1F, 20
+    const W del = b6 & b5 & b4 & b3 & b2 & b1 & b0;      // 0x7F
+    const W sym = (b6 | b5) & ~sp20 & ~del & ~alnum;
+    const W n_e = b3 & b2 & b1 & ~b0, n_f = b3 & b2 & b1 & b0;
+    const W c_hash = g2 & ~b3 & ~b2 & b1 & b0, c_dollar = g2 & ~b3 & b2 & ~b1 & ~b0, c_caret = b6 & ~b5 & b4 & n_e;
+    const W c_at = b6 & ~b5 & ~b4 & ~nz, c_colon = g3 & b3 & ~b2 & b1 & ~b0, c_slash = g2 & n_f, c_dot = g2 & n_e;
     p[LK_BIT_SPACE] = space;
     p[LK_BIT_SYMBOL] = sym;
     p[LK_BIT_LOWER] = letter & b5;
     p[LK_BIT_UPPER] = letter & ~b5;
     p[LK_BIT_ALNUM] = alnum;
     p[5] = letter | c_hash | c_dollar | c_caret | c_at | c_slash;
-    p[6] = c_at | c_dot | (RULE_CODES ? digit : 0ull);
+    p[6] = c_at | c_dot | (RULE_CODES ? digit : (W)0);
     p[7] = c_colon | c_slash | c_dot;
+}
+
+template <bool RULE_CODES = false>
+LATOK_HD void lk_ascii_code_planes(const lk_u64 r[8], lk_u64 p[8]) {
+    // on 32-bit halves: the backend fuses the chains into v_bitop3_b32 (see lk_w)
+    uint32_t rl[8], rh[8], pl[8], ph[8];
+    for (int b = 0; b < 7; ++b) {
+        rl[b] = (uint32_t)r[b];
+        rh[b] = (uint32_t)(r[b] >> 32);
+    }
+    lk_ascii_code_planes_t<RULE_CODES, uint32_t>(rl, pl);
+    lk_ascii_code_planes_t<RULE_CODES, uint32_t>(rh, ph);
+    for (int b = 0; b < 8; ++b) p[b] = (lk_u64)pl[b] | ((lk_u64)ph[b] << 32);
 }
 
 // neighbour characters outside the word: codes of char (base-1), (base+64), (base+65); 0 when they do not exist
@@ -209,39 +269,43 @@ LATOK_HD lk_feat1 lk_decode1(uint32_t c) {
     return f;
 }
 
-LATOK_HD lk_local lk_rules(const lk_feat& f, lk_halo h, lk_u64 B, lk_u64 Bn) {
+LATOK_HD lk_local lk_rules(const lk_feat& f64, lk_halo h, lk_u64 B64, lk_u64 Bn) {
     const lk_feat1 fp = lk_decode1(h.prev), f0 = lk_decode1(h.next0), f1 = lk_decode1(h.next1);
+    // the planes as 32-bit halves (lk_w): the and / or chains below become v_bitop3_b32
+    const lk_w B = lk_w_of(B64);
+    const lk_w S = lk_w_of(f64.S), Y = lk_w_of(f64.Y), L = lk_w_of(f64.L), U = lk_w_of(f64.U), AN = lk_w_of(f64.AN), A = lk_w_of(f64.A),
+               T = lk_w_of(f64.T), AT = lk_w_of(f64.AT), CO = lk_w_of(f64.CO), SL = lk_w_of(f64.SL), PE = lk_w_of(f64.PE);
 
-    const lk_u64 E = (B >> 1) | ((Bn & 1ull) << 63);               // last char of a string
-    const lk_u64 E2 = E | (B >> 2) | ((Bn & 3ull) << 62);          // last or second-to-last char
-    const lk_u64 nB = ~B, nE = ~E, nE2 = ~E2;
+    const lk_w E = lk_w_shr<1>(B, (uint32_t)(Bn & 1ull));                   // last char of a string
+    const lk_w E2 = E | lk_w_shr<2>(B, (uint32_t)(Bn & 3ull));              // last or second-to-last char
+    const lk_w nB = ~B, nE = ~E, nE2 = ~E2;
 
-#define LK_PREV(X) ((((f.X) << 1) | (lk_u64)fp.X) & nB)
-#define LK_NEXT(X) ((((f.X) >> 1) | ((lk_u64)f0.X << 63)) & nE)
-#define LK_ANEXT(X) ((((f.X) >> 2) | ((lk_u64)f0.X << 62) | ((lk_u64)f1.X << 63)) & nE2)
-    const lk_u64 prevS = ((f.S << 1) | (lk_u64)fp.S) | B;
-    const lk_u64 nextS = ((f.S >> 1) | ((lk_u64)f0.S << 63)) | E;
-    const lk_u64 prevY = LK_PREV(Y), prevL = LK_PREV(L), prevAN = LK_PREV(AN), prevA = LK_PREV(A);
-    const lk_u64 nextL = LK_NEXT(L), nextA = LK_NEXT(A), nextAN = LK_NEXT(AN), nextAT = LK_NEXT(AT),
-                 nextSL = LK_NEXT(SL);
-    const lk_u64 anA = LK_ANEXT(A), anSL = LK_ANEXT(SL);
+#define LK_PREV(X) (lk_w_shl<1>(X, fp.X) & nB)
+#define LK_NEXT(X) (lk_w_shr<1>(X, f0.X) & nE)
+#define LK_ANEXT(X) (lk_w_shr<2>(X, f0.X | (f1.X << 1)) & nE2)
+    const lk_w prevS = lk_w_shl<1>(S, fp.S) | B;
+    const lk_w nextS = lk_w_shr<1>(S, f0.S) | E;
+    const lk_w prevY = LK_PREV(Y), prevL = LK_PREV(L), prevAN = LK_PREV(AN), prevA = LK_PREV(A);
+    const lk_w nextL = LK_NEXT(L), nextA = LK_NEXT(A), nextAN = LK_NEXT(AN), nextAT = LK_NEXT(AT), nextSL = LK_NEXT(SL);
+    const lk_w anA = LK_ANEXT(A), anSL = LK_ANEXT(SL);
 #undef LK_PREV
 #undef LK_NEXT
 #undef LK_ANEXT
 
     lk_local r;
-    r.S = f.S;
-    r.t_space = f.S;                  // [SPACE]
-    r.t_sym = f.Y;                    // [SYMBOL]
-    r.t_prevsym = prevY;              // [PREV_SYMBOL]
-    r.t_camel_next = f.U & nextL;     // [UPPER, NEXT_LOWER]
-    r.t_camel_prev = f.U & prevL;     // [UPPER, PREV_LOWER]
-    r.raw = r.t_space | r.t_sym | r.t_prevsym | r.t_camel_next | r.t_camel_prev;
-    r.start = (f.T & prevS & nextA)                 // [TWITTER, PREV_SPACE, NEXT_ALPHA]
-              | (f.PE & prevS & nextAT & anA)       // [CHAR_PERIOD, PREV_SPACE, NEXT_AT, AFTER_NEXT_ALPHA]
-              | (f.AT & prevAN & nextAN)            // [CHAR_AT, PREV_ALPHA_NUM, NEXT_ALPHA_NUM]
-              | (f.CO & nextSL & anSL & prevA);     // [CHAR_COLON, NEXT_SLASH, AFTER_NEXT_SLASH, PREV_ALPHA]
-    r.sym = f.Y & nextS;              // [SYMBOL, NEXT_SPACE]
+    r.S = f64.S;
+    r.t_space = f64.S;                // [SPACE]
+    r.t_sym = f64.Y;                  // [SYMBOL]
+    const lk_w camel_next = U & nextL, camel_prev = U & prevL;
+    r.t_prevsym = lk_u_of(prevY);     // [PREV_SYMBOL]
+    r.t_camel_next = lk_u_of(camel_next);   // [UPPER, NEXT_LOWER]
+    r.t_camel_prev = lk_u_of(camel_prev);   // [UPPER, PREV_LOWER]
+    r.raw = lk_u_of(S | Y | prevY | camel_next | camel_prev);
+    r.start = lk_u_of((T & prevS & nextA)                 // [TWITTER, PREV_SPACE, NEXT_ALPHA]
+                      | (PE & prevS & nextAT & anA)       // [CHAR_PERIOD, PREV_SPACE, NEXT_AT, AFTER_NEXT_ALPHA]
+                      | (AT & prevAN & nextAN)            // [CHAR_AT, PREV_ALPHA_NUM, NEXT_ALPHA_NUM]
+                      | (CO & nextSL & anSL & prevA));    // [CHAR_COLON, NEXT_SLASH, AFTER_NEXT_SLASH, PREV_ALPHA]
+    r.sym = lk_u_of(Y & nextS);       // [SYMBOL, NEXT_SPACE]
     return r;
 }
 
@@ -302,12 +366,13 @@ LATOK_HD void lk_smear_planes(lk_u64 p[8], lk_u64 C, uint32_t cin_code, int cin_
 #endif
     for (int b = 0; b < 8; ++b) {
         if (!((PLANES >> b) & 1u)) continue;
-        lk_u64 x = p[b];                      // the leads inside the word reach at most 3 continuation bytes each
-        x |= (x << 1) & C;
-        x |= (x << 1) & C;
-        x |= (x << 1) & C;
+        lk_w x = lk_w_of(p[b]);               // the leads inside the word reach at most 3 continuation bytes each
+        const lk_w Cw = lk_w_of(C);           // (on halves: see lk_w)
+        x = x | (lk_w_shl<1>(x, 0u) & Cw);
+        x = x | (lk_w_shl<1>(x, 0u) & Cw);
+        x = x | (lk_w_shl<1>(x, 0u) & Cw);
         // the entering char: only the word's leading continuation bytes (which no lead of the word reaches), `take` of them
-        p[b] = x | (((cin_code >> b) & 1u) ? in_mask : 0ull);
+        p[b] = lk_u_of(x) | (((cin_code >> b) & 1u) ? in_mask : 0ull);
     }
 }
 
@@ -385,50 +450,56 @@ LATOK_HD int lk_rules_bytes_weird(const lk_u64 p[8], lk_u64 C, lk_u64 next_codes
     const lk_u64 Pn = (Tn >> (8 * LK_BIT_SYMBOL)) & ((Tn >> 40) | (Tn >> 48) | (Tn >> 56)) & ~Cn & 0xFFull;
     return ((P & ((C >> 1) | (Cn << 63))) | (Pn & (Cn >> 1) & 1ull)) != 0ull;
 }
-LATOK_HD lk_local lk_rules_bytes_fast(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {
-    const lk_feat fs = lk_decode(p);                 // smeared features (planes 0, 1, 2, 4, 5 are smeared)
-    const lk_u64 Lead = ~C;
+LATOK_HD lk_local lk_rules_bytes_fast(const lk_u64 p[8], lk_u64 C64, lk_halo_bytes h, lk_u64 B64, lk_u64* Ss_out) {
+    // (on 32-bit halves throughout: see lk_w)
+    lk_w q[8];
+    for (int b = 0; b < 8; ++b) q[b] = lk_w_of(p[b]);
+    const lk_feat_t<lk_w> fs = lk_decode_t<lk_w>(q);   // smeared features (planes 0, 1, 2, 4, 5 are smeared)
+    const lk_w C = lk_w_of(C64), B = lk_w_of(B64);
+    const lk_w Lead = ~C;
     const lk_u64 Tn = lk_transpose8(h.next_codes);
-    const lk_u64 Cn = (Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull;
-    const lk_u64 Ln = ~Cn & 0xFFull;
-#define LK_PN(b) ((Tn >> (8 * (b))) & 0xFFull)
-    const lk_u64 Sn = LK_PN(0) & Ln, Lwn = LK_PN(2) & Ln, ANn = LK_PN(4) & Ln, An = LK_PN(5) & ~LK_PN(1) & Ln,
-                 ATn = LK_PN(5) & LK_PN(6) & LK_PN(1) & Ln, SLn = LK_PN(7) & LK_PN(5) & Ln;
+    const uint32_t Cn = (uint32_t)((Tn >> 56) & ~(Tn >> (8 * LK_BIT_SYMBOL)) & 0xFFull);
+    const uint32_t Ln = ~Cn & 0xFFu;
+#define LK_PN(b) ((uint32_t)(Tn >> (8 * (b))) & 0xFFu)
+    const uint32_t Sn = LK_PN(0) & Ln, Lwn = LK_PN(2) & Ln, ANn = LK_PN(4) & Ln, An = LK_PN(5) & ~LK_PN(1) & Ln,
+                   ATn = LK_PN(5) & LK_PN(6) & LK_PN(1) & Ln, SLn = LK_PN(7) & LK_PN(5) & Ln;
 #undef LK_PN
-    const lk_u64 Bn = (lk_u64)(h.next_B & 0xFFFFu);
-    const lk_u64 S = fs.S & Lead, Lw = fs.L & Lead, AN = fs.AN & Lead, A = fs.A & Lead, AT = fs.AT & Lead, SL = fs.SL & Lead;
-    const lk_u64 Y = fs.Y & Lead, U = fs.U & Lead, T = fs.T & Lead, PE = fs.PE & Lead, CO = fs.CO & Lead;
-#define LK_SH(X, Xn_, k) (((X) >> (k)) | ((Xn_) << (64 - (k))))
+    const uint32_t Bn = h.next_B & 0xFFFFu;
+    const lk_w S = fs.S & Lead, Lw = fs.L & Lead, AN = fs.AN & Lead, A = fs.A & Lead, AT = fs.AT & Lead, SL = fs.SL & Lead;
+    const lk_w Y = fs.Y & Lead, U = fs.U & Lead, T = fs.T & Lead, PE = fs.PE & Lead, CO = fs.CO & Lead;
+    // X >> k with the first k positions of the next word (Xn_) entering at the top
+#define LK_SH(X, Xn_, k) lk_w_shr<k>(X, Xn_)
     // "next lead byte" operator for lead-only planes: the value at the first lead after position i (at most 4 bytes on)
-    const lk_u64 Q1 = LK_SH(C, Cn, 1), Q2 = Q1 & LK_SH(C, Cn, 2), Q3 = Q2 & LK_SH(C, Cn, 3);
+    const lk_w Q1 = LK_SH(C, Cn, 1), Q2 = Q1 & LK_SH(C, Cn, 2), Q3 = Q2 & LK_SH(C, Cn, 3);
 #define LK_NEXTQ(X, Xn_) (LK_SH(X, Xn_, 1) | (Q1 & LK_SH(X, Xn_, 2)) | (Q2 & LK_SH(X, Xn_, 3)) | (Q3 & LK_SH(X, Xn_, 4)))
-    const lk_u64 E = Lead & LK_NEXTQ(B, Bn);                        // string ends: the next lead is a string start
-    const lk_u64 nextS = LK_NEXTQ(S, Sn) | E;
-    const lk_u64 nextL = LK_NEXTQ(Lw, Lwn) & ~E;
+    const lk_w E = Lead & LK_NEXTQ(B, Bn);                          // string ends: the next lead is a string start
+    const lk_w nextS = LK_NEXTQ(S, Sn) | E;
+    const lk_w nextL = LK_NEXTQ(Lw, Lwn) & ~E;
 #undef LK_NEXTQ
     // the ASCII-started terms: the next char is the next byte, the one after it the byte after that
-    const lk_u64 nB1 = ~LK_SH(B, Bn, 1), nB2 = nB1 & ~LK_SH(B, Bn, 2);
-    const lk_u64 nextA = LK_SH(A, An, 1) & nB1, nextAN = LK_SH(AN, ANn, 1) & nB1, nextAT = LK_SH(AT, ATn, 1) & nB1,
-                 nextSL = LK_SH(SL, SLn, 1) & nB1;
-    const lk_u64 anA = LK_SH(A, An, 2) & nB2, anSL = LK_SH(SL, SLn, 2) & nB2;
+    const lk_w nB1 = ~LK_SH(B, Bn, 1), nB2 = nB1 & ~LK_SH(B, Bn, 2);
+    const lk_w nextA = LK_SH(A, An, 1) & nB1, nextAN = LK_SH(AN, ANn, 1) & nB1, nextAT = LK_SH(AT, ATn, 1) & nB1,
+               nextSL = LK_SH(SL, SLn, 1) & nB1;
+    const lk_w anA = LK_SH(A, An, 2) & nB2, anSL = LK_SH(SL, SLn, 2) & nB2;
 #undef LK_SH
-    const lk_u64 nB = ~B;
+    const lk_w nB = ~B;
     const lk_feat1 fp = lk_decode1(h.prev);
-#define LK_PREVB(X) ((((fs.X) << 1) | (lk_u64)fp.X) & nB)
-    const lk_u64 prevS = ((fs.S << 1) | (lk_u64)fp.S) | B;
-    const lk_u64 prevY = LK_PREVB(Y), prevL = LK_PREVB(L), prevAN = LK_PREVB(AN), prevA = LK_PREVB(A);
+#define LK_PREVB(X) (lk_w_shl<1>(fs.X, fp.X) & nB)
+    const lk_w prevS = lk_w_shl<1>(fs.S, fp.S) | B;
+    const lk_w prevY = LK_PREVB(Y), prevL = LK_PREVB(L), prevAN = LK_PREVB(AN), prevA = LK_PREVB(A);
 #undef LK_PREVB
+    const lk_w t_prevsym = prevY & Lead, camel_next = U & nextL, camel_prev = U & prevL;
     lk_local r;
-    r.S = S;
-    r.t_space = S;
-    r.t_sym = Y;
-    r.t_prevsym = prevY & Lead;
-    r.t_camel_next = U & nextL;
-    r.t_camel_prev = U & prevL;
-    r.raw = r.t_space | r.t_sym | r.t_prevsym | r.t_camel_next | r.t_camel_prev;
-    r.start = (T & prevS & nextA) | (PE & prevS & nextAT & anA) | (AT & prevAN & nextAN) | (CO & nextSL & anSL & prevA);
-    r.sym = Y & nextS;
-    *Ss_out = fs.S;
+    r.S = lk_u_of(S);
+    r.t_space = r.S;
+    r.t_sym = lk_u_of(Y);
+    r.t_prevsym = lk_u_of(t_prevsym);
+    r.t_camel_next = lk_u_of(camel_next);
+    r.t_camel_prev = lk_u_of(camel_prev);
+    r.raw = lk_u_of(S | Y | t_prevsym | camel_next | camel_prev);
+    r.start = lk_u_of((T & prevS & nextA) | (PE & prevS & nextAT & anA) | (AT & prevAN & nextAN) | (CO & nextSL & anSL & prevA));
+    r.sym = lk_u_of(Y & nextS);
+    *Ss_out = lk_u_of(fs.S);
     return r;
 }
 LATOK_HD lk_local lk_rules_bytes(const lk_u64 p[8], lk_u64 C, lk_halo_bytes h, lk_u64 B, lk_u64* Ss_out) {

@@ -47,12 +47,21 @@ cp /tmp/prof_b/b_kernel_stats.csv $O/kernel_stats_bench_c2.csv 2>/dev/null || fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf -o b -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_flow_under_rocprof.json 2>/dev/null
 echo "rocprof bench (default, flow) rc=$?" | tee -a $LOG
 python3 $R/tools/rocpd_stats.py $(find /tmp/prof_bf -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (default: batch flow, two batches in flight); round 3" --split-overlap > $O/kernel_stats_bench_c2_flow.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
 echo "rocprof paths c2 rc=$?" | tee -a $LOG
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 (1 MI355X, C2 = 1 M ASCII strings); round 3" > $O/paths_kernel_stats.txt
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p3 -o paths -- python3 $R/tools/path_bench.py --workload C3 --iters 5 > /dev/null 2>&1
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round 3" > $O/paths_kernel_stats.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p3 -o paths -- python3 $R/tools/path_bench.py --workload C3 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
 echo "rocprof paths c3 rc=$?" | tee -a $LOG
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 (1 MI355X, C3 = 1 M mixed-Unicode strings); round 3" > $O/paths_kernel_stats_c3.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round 3" > $O/paths_kernel_stats_c3.txt
+cd $R
+fi
+if [ "$PART" = "pathstats" ]; then
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_p /tmp/prof_p3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round 3" > $O/paths_kernel_stats.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p3 -o paths -- python3 $R/tools/path_bench.py --workload C3 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round 3" > $O/paths_kernel_stats_c3.txt
 cd $R
 fi
 if [ "$PART" = "pmc" ] || [ "$PART" = "all" ]; then

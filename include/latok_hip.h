@@ -268,7 +268,8 @@ int latok_rules_active(void);  /* 1 while custom tables are installed */
  *     untouched until latok_flow_wait.  total_chars < 0: read from row_off (one small synchronous copy).  Consecutive
  *     batches should write different mask buffers; a batch that writes the buffer of a batch still in flight simply waits
  *     for it (correct, not overlapped).  Results are bit-identical to latok_split_mask_batch.
- *   latok_flow_wait: block until every batch submitted on the current context is complete (latok_sync does the same).
+ *   latok_flow_wait: block until every batch submitted on the current context is complete (latok_sync does the same).  The
+ *     streams are polled for up to 2 ms before the call sleeps on them (a sleeping wait returns ~15 us late).
  * The blocking entry points may be called on the same context while a flow is in flight (they use the context's own stream
  * and workspace).  Output buffers of batches in flight must not overlap, except that a whole output buffer may be reused (see
  * above).  A batch larger than any its slot has seen grows the slot's workspace, which first waits for the flow to drain. */

@@ -23,7 +23,9 @@ same corpus (string ids rank*1M ...) -> "scaling": "weak".  The other workloads:
     C4   configs[3]  100 M strings as C2, the WHOLE batch split over the N ranks (strong; 51 GB resident at N = 1)
     C5   configs[4]  10 K documents x 1 M chars, split over the N ranks (strong; 40 GB resident at N = 1)
 
-Timing: W untimed warm-up steps, then EXACTLY K steps.  The timed region of a rank is ONE library call
+Timing: W untimed warm-up steps (then untimed passes until the GPU has been under load for `--settle-s`, 50 ms: the GPU
+idles while the shard is built and reaches its steady clocks only after tens of ms -- without it the first 20-step region
+after 5 warm-up steps runs 2 % (C2) to 14 % (C3) below the fourth; reported as `warmup_settle`), then EXACTLY K steps.  The timed region of a rank is ONE library call
 (latok_bench_split_mask_flow_gated / latok_bench_split_mask_gated): rendezvous of all ranks -> host monotonic clock -> HIP
 event -> K passes -> HIP event -> stream(s) synchronise -> host clock -> rendezvous.  By default the K passes go through the
 product's batch flow (include/latok_hip.h "batch flow", `--in-flight 2`): consecutive batches alternate between two streams,
@@ -292,6 +294,27 @@ class Shard:
             self.api.check(self.lib.latok_bench_split_mask_flow_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits,
                                                                       self.d_bits2, n, None, C.byref(ms), C.byref(t0), C.byref(t1)))
 
+    def settle(self, seconds):
+        """untimed passes (the form the timed region uses) until `seconds` of GPU time have gone by: the clocks of a GPU that
+        sat idle while the shard was built take tens of milliseconds of load to reach their steady state (the first 20-step
+        region after W = 5 warm-up steps runs 2-8 % slower than the fourth: profiles/r03_flow_k.txt).  Returns the step count."""
+        done, t_ms = 0, 0.0
+        while seconds > 0 and t_ms < seconds * 1e3 and done < 100000:
+            k = 50
+            ms, t0, t1 = C.c_float(0), C.c_int64(0), C.c_int64(0)
+            if self.flow:
+                self.api.check(self.lib.latok_bench_split_mask_flow_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits,
+                                                                          self.d_bits2, k, None, C.byref(ms), C.byref(t0), C.byref(t1)))
+            else:
+                self.api.check(self.lib.latok_bench_split_mask_gated(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, k, None,
+                                                                     C.byref(ms), C.byref(t0), C.byref(t1)))
+            dt = (t1.value - t0.value) / 1e6
+            if dt <= 0:      # (a fake device layer in the tests: no time passes)
+                break
+            t_ms += dt
+            done += k
+        return done
+
     def timed(self, steps, gate, flow=None):
         """EXACTLY `steps` pipeline passes: gate -> host clock -> HIP event -> passes -> HIP event -> stream sync -> host
         clock -> gate, all inside one library call (no interpreter between the clocks).  flow: the passes go through the
@@ -366,6 +389,7 @@ def measure_shard(sh, args, gate, phase):
     sh.build()
     sh.warmup(args.warmup)
     sh.warmup_flow(args.warmup)
+    n_settle = sh.settle(args.settle_s)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
     with phase():
         rec = sh.timed(args.steps, None if args.take_turns else gate)
@@ -378,6 +402,7 @@ def measure_shard(sh, args, gate, phase):
     with phase():
         k_ms, n_fix = sh.kernel_only(args.steps)
     rec["serial"] = serial
+    rec["settle_steps"] = n_settle
     rec.update(rank=sh.rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                sustained=None, measured_read=None)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
@@ -471,6 +496,7 @@ def run_under_launcher(api, args, rank, world, local_rank):
         sh.build()
         sh.warmup(args.warmup)
         sh.warmup_flow(args.warmup)
+        n_settle = sh.settle(args.settle_s)
         dist.barrier()
         with _Barrier("timed"):
             rec = sh.timed(args.steps, None)
@@ -483,6 +509,7 @@ def run_under_launcher(api, args, rank, world, local_rank):
         with _Barrier("kernel"):
             k_ms, n_fix = sh.kernel_only(args.steps)
         rec["serial"] = serial
+        rec["settle_steps"] = n_settle
         rec.update(rank=rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                    sustained=None, measured_read=None)
         dist.barrier()
@@ -535,6 +562,9 @@ def build_line(args, recs, mode, devices, same_start):
         "metric": "input UTF-8 GB/s tokenized (fused feature+split-mask path)",
         "value": value, "unit": "GB/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "warmup_settle": {"seconds": args.settle_s, "steps_rank0": r0.get("settle_steps"),
+                          "why": "after the W warm-up steps, untimed passes until the GPU has been under load for this long: a GPU that "
+                                 "idled while the shard was built reaches its steady clocks only after tens of ms (outside the timed region)"},
         "ms_per_step": job_s / K * 1e3,
         "higher_is_better": True, "scaling": SCALING[args.workload], "vs_baseline": None,
         "dtype": "u64", "dtype_note": "u32 code points in, 64-bit bit-sliced boolean words, u64 bitmask out (integer / bit ops)",
@@ -617,6 +647,8 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
                     help="batches in flight per GPU in the timed region: 2 = the batch flow (latok_flow_split_mask; default), "
                          "1 = one batch at a time; 0 = 2, except 1 for N > 1 host threads in one process (--launch threads)")
+    ap.add_argument("--settle-s", type=float, default=0.05,
+                    help="untimed passes after the W warm-up steps until the GPU has been busy this long (clock settling; 0 = off)")
     ap.add_argument("--take-turns", action="store_true",
                     help="rehearsal on shared GPU(s): the ranks run their timed regions one after the other, so each rank's "
                          "time is what a GPU of its own would give; the line is marked as a rehearsal and carries no `value`")

@@ -164,7 +164,7 @@ def _run(argv, api):
     return json.loads(lines[0])
 
 
-BASE = ["--steps", "5", "--warmup", "1", "--strings", "2000", "--no-cpu-baseline", "--sustain-s", "0"]
+BASE = ["--steps", "5", "--warmup", "1", "--strings", "2000", "--no-cpu-baseline", "--sustain-s", "0", "--settle-s", "0"]
 
 
 @pytest.mark.parametrize("n", [1, 2, 4, 8])

@@ -106,7 +106,7 @@ def _launcher_worker(rank, world, port, q, take_turns):
     from test_bench_launcher import FakeApi
     api = FakeApi(n_dev=1)     # a launcher that narrows HIP_VISIBLE_DEVICES to one GPU per rank: LOCAL_RANK 1 -> device 0
     out = io.StringIO()
-    argv = ["--gpus", str(world), "--steps", "4", "--warmup", "1", "--strings", "1500", "--no-cpu-baseline", "--sustain-s", "0"]
+    argv = ["--gpus", str(world), "--steps", "4", "--warmup", "1", "--strings", "1500", "--no-cpu-baseline", "--sustain-s", "0", "--settle-s", "0"]
     rc = bench.main(argv + (["--take-turns"] if take_turns else []), api=api, out=out)
     q.put((rank, rc, out.getvalue(), [c.device for c in api.contexts], list(api.lib.fills), list(api.lib.timed)))
 

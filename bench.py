@@ -63,6 +63,7 @@ from latok_amd import _lib  # noqa: E402
 
 GATE_TIMEOUT_S = 900.0
 CHILD_TIMEOUT_S = 1500.0   # --launch procs: a rank that has not finished by then is killed (its own process handle)
+AUTO_FLOW_MAX_CHARS = 4_000_000_000   # --in-flight 0: batches below ~1 M tiles go through the batch flow
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 WORKLOADS = {
@@ -259,7 +260,7 @@ class Shard:
             self.sid0, self.n_str = split_string_ids(args.strings or n_default, rank, world)
         self.total = self.utf8 = 0
         self.d_row = self.d_cps = self.d_bits = self.d_bits2 = None
-        self.flow = args.in_flight >= 2
+        self.flow = args.in_flight >= 2     # (0 = decided in build() by the size of the rank's batch)
 
     def build(self):
         """the shard directly in HBM: offsets on the host (8 B/string), code points generated on the device"""
@@ -268,6 +269,10 @@ class Shard:
         row = np.zeros(self.n_str + 1, np.int64)
         chk(lib.latok_corpus_offsets(seed, self.sid0, self.n_str, lo, hi, row.ctypes.data))
         self.total = int(row[-1])
+        if self.args.in_flight == 0:
+            # one huge batch per GPU (C4: 51 GB, C5: 40 GB at N = 1): start-up and end of a 7-9 ms tile kernel are noise and two
+            # such kernels in flight only contend (C5 -4 %, C4 +-0 %; 10 M strings = 0.3 M tiles still +3-8 %): one batch at a time
+            self.flow = self.total < AUTO_FLOW_MAX_CHARS
         self.d_row = lib.latok_dev_alloc(row.nbytes)
         self.d_cps = lib.latok_dev_alloc(self.total * 4)
         self.d_bits = lib.latok_dev_alloc(((self.total + 63) // 64) * 8)
@@ -645,8 +650,9 @@ def parse_args(argv=None):
     ap.add_argument("--child-lock", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-api", default="", help=argparse.SUPPRESS)               # tests: module:factory of a fake device layer
     ap.add_argument("--in-flight", type=int, default=0, choices=[0, 1, 2],
-                    help="batches in flight per GPU in the timed region: 2 = the batch flow (latok_flow_split_mask; default), "
-                         "1 = one batch at a time; 0 = 2, except 1 for N > 1 host threads in one process (--launch threads)")
+                    help="batches in flight per GPU in the timed region: 2 = the batch flow (latok_flow_split_mask), 1 = one batch at "
+                         "a time; 0 (default) = by the size of the rank's batch (the flow below 4 G chars per GPU: C2, C3, the "
+                         "shards of C4 / C5 from 4 / 3 GPUs on), 1 for N > 1 host threads in one process (--launch threads)")
     ap.add_argument("--settle-s", type=float, default=0.05,
                     help="untimed passes after the W warm-up steps until the GPU has been busy this long (clock settling; 0 = off)")
     ap.add_argument("--take-turns", action="store_true",
@@ -657,7 +663,8 @@ def parse_args(argv=None):
         ap.error("--gpus and --steps must be >= 1, --warmup >= 0")
     if args.in_flight == 0:
         threads_n = args.gpus > 1 and args.launch == "threads" and args.child_rank < 0 and not args.take_turns
-        args.in_flight = 1 if threads_n else 2
+        # (0 stays 0 = by batch size, see Shard.build: a rank whose batch is huge runs one batch at a time)
+        args.in_flight = 1 if threads_n else 0
     return args
 
 

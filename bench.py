@@ -344,6 +344,16 @@ class Shard:
                                                        C.byref(ms), C.byref(n_fix)))
         return float(ms.value) / steps, int(n_fix.value)
 
+    def kernel_in_flow(self, steps):
+        """the dominant kernel alone in the flow's launch scheme (two streams, 7/8 of the CUs per launch, launches overlap):
+        wall time per launch over `steps` launches"""
+        fn = getattr(self.lib, "latok_bench_tiles_flow", None)
+        if not self.flow or fn is None:
+            return None
+        ms = C.c_float(0)
+        self.api.check(fn(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, self.d_bits2, max(steps, 100), C.byref(ms)))
+        return float(ms.value) / max(steps, 100)
+
     def sustained(self, seconds, ms_per_step):
         """>= `seconds` of back-to-back pipeline passes, in chunks of <= 1000 passes (one library call each)"""
         want = max(self.args.steps, int(seconds / (ms_per_step / 1e3)) + 1)
@@ -408,6 +418,8 @@ def measure_shard(sh, args, gate, phase):
         k_ms, n_fix = sh.kernel_only(args.steps)
     rec["serial"] = serial
     rec["settle_steps"] = n_settle
+    with phase():
+        rec["kernel_flow_ms"] = sh.kernel_in_flow(args.steps)
     rec.update(rank=sh.rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                sustained=None, measured_read=None)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
@@ -515,6 +527,8 @@ def run_under_launcher(api, args, rank, world, local_rank):
             k_ms, n_fix = sh.kernel_only(args.steps)
         rec["serial"] = serial
         rec["settle_steps"] = n_settle
+        with _Barrier("kernel-flow"):
+            rec["kernel_flow_ms"] = sh.kernel_in_flow(args.steps)
         rec.update(rank=rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
                    sustained=None, measured_read=None)
         dist.barrier()
@@ -602,6 +616,13 @@ def build_line(args, recs, mode, devices, same_start):
                      "kernel_timing": f"{K} back-to-back launches between one HIP event pair on the launch stream, per rank; "
                                       "frac / achieved = the SLOWEST rank's",
                      "frac_per_rank": fracs, "kernel_ms_per_rank": [r["kernel_ms"] for r in recs],
+                     "in_flow": ({"kernel_ms_per_launch": max(r["kernel_flow_ms"] for r in recs),
+                                  "frac": min(r["alg_read"] / (r["kernel_flow_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs),
+                                  "how": "max(K, 100) launches of k_tiles_main ALONE in the flow's launch scheme (alternating between the "
+                                         "two slot streams, each launch planned for 7/8 of the CUs, no other kernel): host wall time / launches; "
+                                         "the launches overlap their start-up and ragged end, so this is the kernel's average cost per launch in "
+                                         "the product's scheme, not one launch's duration (that is kernel_ms above, which rocprofv3 confirms)"}
+                                 if all(r.get("kernel_flow_ms") for r in recs) else None),
                      "pipeline_frac": min(r["alg_read"] / (r["ms_events"] / K / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs),
                      "pipeline_frac_sustained": (r0["alg_read"] / (r0["sustained"]["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS) if r0.get("sustained") else None,
                      "pipeline_note": ("pipeline_frac = algorithmic bytes / per-step time of the K timed steps (includes filling and draining the "

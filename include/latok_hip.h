@@ -354,6 +354,13 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
                                       uint64_t* mask_a_dev, uint64_t* mask_b_dev, int iters, latok_gate* gate,
                                       float* ms_events_out, int64_t* t0_ns_out, int64_t* t1_ns_out);
 
+/* The dominant kernel alone in the flow's launch scheme: `iters` launches of k_tiles_main (planned for 7/8 of the CUs, as every
+ * batch of a flow is) alternating between the two slot streams, nothing else launched; ms_out = host wall time from the first
+ * launch to the end of the last (streams polled).  The launches overlap, so ms_out / iters is the kernel's average cost per
+ * launch in the flow, not the duration of one launch. */
+int latok_bench_tiles_flow(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
+                           uint64_t* mask_a_dev, uint64_t* mask_b_dev, int iters, float* ms_out);
+
 #ifdef __cplusplus
 }
 #endif

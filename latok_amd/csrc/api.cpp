@@ -2384,4 +2384,33 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
     return LATOK_OK;
 }
 
+int latok_bench_tiles_flow(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total, uint64_t* mask_a_dev,
+                           uint64_t* mask_b_dev, int iters, float* ms_out) {
+    LATOK_ENTER();
+    int rc = need_init(g);
+    if (rc) return rc;
+    if (iters < 1 || !ms_out || !mask_a_dev || !mask_b_dev) return fail(LATOK_ERR_INVALID, "iters >= 1, two mask buffers and ms_out are needed");
+    if ((rc = resolve_total_device(row_off_dev, n_str, &total, g.stream))) return rc;
+    if (total <= 0) { *ms_out = 0.f; return LATOK_OK; }
+    // one whole pass per slot first: workspaces sized, the per-tile string index of the batch in place in BOTH slots
+    for (int i = 0; i < 2; ++i)
+        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, i ? mask_b_dev : mask_a_dev))) return rc;
+    if ((rc = flow_drain(g))) return rc;
+    const int64_t t0 = mono_ns();
+    for (int i = 0; i < iters && !rc; ++i) {
+        Ctx::FlowSlot& f = g.flow[i % g.flow_slots];
+        rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev, nullptr, latok::kModeBits, f.st, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f);
+    }
+    const int rc_drain = flow_drain(g);
+    const int64_t t1 = mono_ns();
+    if (rc) return rc;
+    if (rc_drain) return rc_drain;
+    *ms_out = (float)((t1 - t0) / 1e6);
+    // leave resolved masks behind
+    for (int i = 0; i < 2; ++i)
+        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, i ? mask_b_dev : mask_a_dev))) return rc;
+    return flow_drain(g);
+}
+
 }  // extern "C"

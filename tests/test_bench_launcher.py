@@ -116,6 +116,10 @@ class FakeLib:
             self.flow_calls += 1
         return self._region(iters, gate, ms, t0, t1, self.timed)
 
+    def latok_bench_tiles_flow(self, cps, row, n_str, total, bits_a, bits_b, iters, ms):
+        ms._obj.value = 0.8 * self.ms_per_pass * iters
+        return 0
+
     def latok_bench_stream_read(self, buf, nbytes, warmup, iters, ms):
         ms._obj.value = 1.0
         return 0
@@ -194,6 +198,7 @@ def test_in_process_launch_runs_every_rank_on_its_own_context(n, monkeypatch):
     # the headline region went through the batch flow (two batches in flight), the same K steps one at a time ride along
     assert line["in_flight"] == 2 and api.lib.flow_calls == n and len(api.lib.timed_serial) == n
     assert line["serial"]["value"] > 0 and len(line["serial"]["ms_per_rank"]) == n
+    assert line["roofline"]["in_flow"]["frac"] > line["roofline"]["frac"]      # (the fake: 0.8 vs 0.9 of a pass)
 
 
 def test_in_flight_1_times_one_batch_at_a_time(monkeypatch):

@@ -42,6 +42,23 @@ def main():
         for tag, d in (("alone", alone), ("overlapped (duration includes waiting for CUs)", over)):
             for name, durs in d.items():
                 print(line(f"[{tag}] {name}", durs, tot))
+        # chains of overlapping tile kernels: what one launch costs on average = (end of the chain - its start) / launches
+        chains, cur = [], None
+        for a, b, name in tiles:
+            if cur is not None and a < cur[1]:
+                cur[1] = max(cur[1], b)
+                cur[2] += 1
+            else:
+                if cur is not None and cur[2] >= 8:
+                    chains.append(cur)
+                cur = [a, b, 1]
+        if cur is not None and cur[2] >= 8:
+            chains.append(cur)
+        if chains:
+            n = sum(c[2] for c in chains)
+            span = sum(c[1] - c[0] for c in chains) / 1e3
+            print(f"# {len(chains)} chains of >= 8 overlapping tile-kernel launches: {n} launches in {span:.1f} us = {span / n:.2f} us per launch "
+                  "(under the profiler; includes the other kernels of the batches where there are any)")
 
 
 if __name__ == "__main__":

@@ -351,8 +351,8 @@ class Shard:
         if not self.flow or fn is None:
             return None
         ms = C.c_float(0)
-        self.api.check(fn(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, self.d_bits2, max(steps, 100), C.byref(ms)))
-        return float(ms.value) / max(steps, 100)
+        self.api.check(fn(self.d_cps, self.d_row, self.n_str, self.total, self.d_bits, self.d_bits2, max(steps, 400), C.byref(ms)))
+        return float(ms.value) / max(steps, 400)
 
     def sustained(self, seconds, ms_per_step):
         """>= `seconds` of back-to-back pipeline passes, in chunks of <= 1000 passes (one library call each)"""
@@ -618,7 +618,7 @@ def build_line(args, recs, mode, devices, same_start):
                      "frac_per_rank": fracs, "kernel_ms_per_rank": [r["kernel_ms"] for r in recs],
                      "in_flow": ({"kernel_ms_per_launch": max(r["kernel_flow_ms"] for r in recs),
                                   "frac": min(r["alg_read"] / (r["kernel_flow_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs),
-                                  "how": "max(K, 100) launches of k_tiles_main ALONE in the flow's launch scheme (alternating between the "
+                                  "how": "max(K, 400) launches of k_tiles_main ALONE in the flow's launch scheme (alternating between the "
                                          "two slot streams, each launch planned for 7/8 of the CUs, no other kernel): host wall time / launches; "
                                          "the launches overlap their start-up and ragged end, so this is the kernel's average cost per launch in "
                                          "the product's scheme, not one launch's duration (that is kernel_ms above, which rocprofv3 confirms)"}

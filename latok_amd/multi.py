@@ -408,6 +408,39 @@ class DevicePool:
                 result.append((np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])))
         return result
 
+    def split_mask_many(self, rbs, to_host=True):
+        """split_mask of several resident batches (same pool), every shard through its context's batch flow: the merged host
+        bitmask of each batch, or (to_host=False) nothing -- the per-shard masks stay in sh.d_bits."""
+        lib = self.lib
+        rbs = list(rbs)
+
+        def worker(r):
+            mine = [(b, rb.shards[r]) for b, rb in enumerate(rbs) if rb.shards[r] is not None and rb.shards[r].total > 0]
+            for b, sh in mine:
+                words = (sh.total + 63) // 64
+                if sh.d_bits is None:
+                    sh.d_bits = self._alloc(max(words * 8, 16))
+                kind = rbs[b].kind
+                if kind == "utf32":
+                    rc = lib.latok_flow_split_mask(sh.d_units, sh.d_row, sh.n_str, sh.total, sh.d_bits)
+                elif kind == "utf8":
+                    rc = lib.latok_flow_split_mask_utf8_bytes(sh.d_units, sh.d_row, sh.n_str, sh.total, sh.d_bits)
+                else:
+                    rc = lib.latok_flow_split_mask_kind(sh.d_units, _KINDS[kind][1], sh.d_row, sh.n_str, sh.total, sh.d_bits)
+                self._check(rc)
+            self._check(lib.latok_flow_wait())
+            out = {}
+            if to_host:
+                for b, sh in mine:
+                    bits = np.empty((sh.total + 63) // 64, np.uint64)
+                    self._check(lib.latok_memcpy_d2h(bits.ctypes.data, sh.d_bits, bits.nbytes))
+                    out[b] = (sh.unit0, bits)
+            return out
+        per_worker = self.run([(lambda r=r: worker(r)) for r in range(len(self))])
+        if not to_host:
+            return None
+        return [_merge_masks([pw[b] for pw in per_worker if pw and b in pw], rb.total) for b, rb in enumerate(rbs)]
+
     def split_offsets_many(self, rbs, dtype=np.int32):
         """split_offsets of several resident batches (same pool), overlapped on every device by the context's batch flow:
         [(counts, offsets), ...].  C2-sized batches: ~20 % less time per batch than one split_offsets call after another."""

@@ -378,6 +378,8 @@ def test_device_pool_pushes_several_resident_batches_through_the_flow(gpu, oracl
         rbs.append(pool.put_csr(u8, boff, kind="utf8"))
         want_o.append(batch.split_offsets_utf8_bytes_csr(u8, boff, dtype=np.int32))
         want_s.append(batch.token_spans_utf8_bytes_csr(u8, boff, dtype=np.int32))
+        for got, rb in zip(pool.split_mask_many(rbs), rbs):
+            assert np.array_equal(got, pool.split_mask(rb))
         for _ in range(2):
             for (c, o), (wc, wo) in zip(pool.split_offsets_many(rbs), want_o):
                 assert np.array_equal(c, wc) and np.array_equal(o, wo)

@@ -246,6 +246,11 @@ class FakeDeviceLib:
             (spans, d_units, d_row, n_str, total, d_counts, d_items, cap, d_result, flags | _lib.DEVICE_PTRS))
         return 0
 
+    def latok_flow_split_mask(self, d_cps, d_row, n_str, total, d_bits):
+        from latok_amd import _lib
+        self.__dict__.setdefault("flow_masks", {}).setdefault(threading.get_ident(), []).append((d_cps, d_row, n_str, total, d_bits))
+        return 0
+
     def latok_flow_split_offsets(self, *a):
         return self._flow(False, *a)
 
@@ -254,6 +259,9 @@ class FakeDeviceLib:
 
     def latok_flow_wait(self):
         import ctypes
+        from latok_amd import _lib
+        for a in self.__dict__.get("flow_masks", {}).pop(threading.get_ident(), []):
+            self.latok_split_mask_batch(*a, _lib.DEVICE_PTRS, None)
         for spans, d_units, d_row, n_str, total, d_counts, d_items, cap, d_result, flags in self.__dict__.get("flow_q", {}).pop(threading.get_ident(), []):
             n = ctypes.c_int64(0)
             self._records(d_units, d_row, n_str, total, d_counts, d_items, cap, ctypes.byref(n), flags, spans=spans)
@@ -339,6 +347,8 @@ def test_several_resident_batches_through_the_flow(oracle, n_workers):
                 assert offs.tolist() == [int(v) for e in exp for v in e]
         grown = [c for c in fake.calls if c[0] == "offsets" and c[4] > c[3]]
         assert not grown, "the second pass (int64) reuses the buffers the first one grew"
+        for texts, bits in zip(sets, pool.split_mask_many(rbs)):
+            assert np.array_equal(bits, oracle.split_batch(*pack(texts), want_values=False)[1])
         res = pool.token_spans_many(rbs)
         for texts, (counts, spans) in zip(sets, res):
             k = 0

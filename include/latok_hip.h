@@ -155,7 +155,7 @@ int latok_token_spans_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, i
  *            is the UTF-8 encoding of the token the reference yields
  * Input must be valid UTF-8 ("surrogatepass" forms are accepted as they decode); a truncated sequence counts as
  * U+FFFD, stray continuation bytes belong to no char.  With LATOK_DEVICE_PTRS the byte buffer must be 16-byte aligned.
- * Run-time rule tables (latok_set_rules) are not available in byte space. */
+ * Run-time rule tables (latok_set_rules) apply in byte space too (evaluated by the byte-space tile kernel itself). */
 int latok_split_mask_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                       uint64_t* mask_bits_out, int flags, void* stream);
 int latok_split_offsets_utf8_bytes_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
@@ -179,9 +179,9 @@ int latok_token_features_batch(const uint32_t* cps, const int64_t* row_off, int6
  * packed units of all strings, row_off / total_chars / every result in units = chars (CPython stores text with astral
  * chars as kind 4, so a kind-2 unit is always a whole code point; lone surrogates are classified as the code points
  * they are).  A caller that holds Python strings never widens them to UTF-32, and a Latin-1 / UCS-2 batch costs 1 / 2
- * bytes per char on the bus and in HBM: the tile kernel reads the narrow units itself (mask, offsets, spans); featurize
- * and run-time rule tables widen them once on the device.  Results are identical to the UTF-32 entry points on the
- * widened text.  kind = 4 forwards to those.  With LATOK_DEVICE_PTRS `units` must be 16-byte aligned. */
+ * bytes per char on the bus and in HBM: the tile kernel reads the narrow units itself (mask, offsets, spans), under
+ * run-time rule tables as well; only featurize widens them once on the device (it re-reads the code points).  Results
+ * are identical to the UTF-32 entry points on the widened text.  kind = 4 forwards to those.  With LATOK_DEVICE_PTRS `units` must be 16-byte aligned. */
 int latok_split_mask_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
                                 uint64_t* mask_bits_out, int flags, void* stream);
 int latok_split_offsets_kind_batch(const void* units, int kind, const int64_t* row_off, int64_t n_str, int64_t total_chars,
@@ -259,20 +259,26 @@ int latok_rules_active(void);  /* 1 while custom tables are installed */
 /* ---- batch flow: many device-resident batches through one context, overlapped -------------------------------------------
  * The reference tokenizes one string after another (default_tokenizer.py:137-160: every call is independent of the one
  * before).  Here a batch costs three dependent launches (per-tile string index, tiles, resolve); only the tile kernel needs
- * the whole GPU.  A flow keeps up to TWO batches in flight on the current context -- every stage on its own stream, every
- * batch in flight with its own workspace -- so that the string index of batch i+1 runs beside the tile kernel of batch i
- * and the resolve stage of batch i beside the tile kernel of batch i+1; a flow batch's tile kernel is planned for 7/8 of the CUs,
- * so consecutive tile kernels overlap their start-up and ragged end as well (C2: 0.108 -> 0.087 ms per batch).
+ * the whole GPU.  A flow keeps up to TWO batches in flight on the current context -- every batch in flight on a stream and
+ * a workspace set of its own (a "slot"; submissions take the slots in turn), with no dependency between the slots -- so that
+ * the two small launches of one batch run beside the tile kernel of the other; a flow batch's tile kernel is planned for 7/8 of
+ * the CUs, so consecutive tile kernels overlap their start-up and ragged end as well (C2: 0.108 -> 0.087 ms per batch).
  *   latok_flow_split_mask: enqueue latok_split_mask_batch(LATOK_DEVICE_PTRS) of one batch and return.  The inputs must be
  *     complete in device memory when the call is made (they are NOT ordered behind work on any caller stream), and must stay
- *     untouched until latok_flow_wait.  total_chars < 0: read from row_off (one small synchronous copy).  Consecutive
- *     batches should write different mask buffers; a batch that writes the buffer of a batch still in flight simply waits
- *     for it (correct, not overlapped).  Results are bit-identical to latok_split_mask_batch.
+ *     untouched by the caller until latok_flow_wait.  total_chars < 0: read from row_off (one small synchronous copy).
+ *     Results are bit-identical to latok_split_mask_batch.
  *   latok_flow_wait: block until every batch submitted on the current context is complete (latok_sync does the same).  The
  *     streams are polled for up to 2 ms before the call sleeps on them (a sleeping wait returns ~15 us late).
+ * Ordering between batches of one flow.  Every call is independent, as the reference's calls are -- batches that touch
+ * disjoint memory overlap freely.  The library tracks the byte RANGE of every buffer a batch in flight reads (units, row
+ * offsets) or writes (mask; for the compaction calls: records, counts, result words, feature sums) until the flow is next
+ * idle.  A new batch that writes any byte a batch still in flight reads or writes, or reads one it writes -- whole buffer or
+ * partial overlap, however many other batches were submitted in between -- is ordered behind that batch (it is enqueued on that
+ * batch's slot; if batches on both slots are in its way the call first waits for the flow to drain).  So reusing an output
+ * buffer is always correct, it just does not overlap; callers that want the overlap alternate their buffers.
  * The blocking entry points may be called on the same context while a flow is in flight (they use the context's own stream
- * and workspace).  Output buffers of batches in flight must not overlap, except that a whole output buffer may be reused (see
- * above).  A batch larger than any its slot has seen grows the slot's workspace, which first waits for the flow to drain. */
+ * and workspace; their buffers are NOT tracked against the flow's).  A batch larger than any its slot has seen grows the
+ * slot's workspace, which first waits for the flow to drain. */
 int latok_flow_split_mask(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total_chars,
                           uint64_t* mask_dev);
 /* The same for the other input forms of the path: PEP 393 units (kind 1 / 2 / 4 as latok_split_mask_kind_batch; positions are
@@ -292,7 +298,7 @@ int latok_flow_split_mask_utf8_bytes(const uint8_t* utf8_dev, const int64_t* byt
  *     nonzero when the batch could not be reported (low half: a string of >= 2^31 chars under LATOK_OUT_INT32; high half:
  *     internal scan error, the call is safe to repeat).  When result[0] exceeds the capacity nothing was written to the
  *     records (counts are valid): resubmit with a larger buffer -- the capacity protocol of the blocking calls, read late.
- * Batches whose records go to the buffer of a batch still in flight are ordered behind it. */
+ * Every output (records, counts, result words) takes part in the ordering rule above. */
 int latok_flow_split_offsets(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,
                              void* counts_dev, void* offsets_dev, int64_t offsets_cap, int64_t* result_dev, int flags);
 int latok_flow_token_spans(const void* units_dev, int kind, const int64_t* row_off_dev, int64_t n_str, int64_t total_units,

@@ -24,6 +24,7 @@
 
 #include "../../include/latok_hip.h"
 #include "corpus_gen.h"
+#include "flow_hazards.h"
 #include "kernels.h"
 #include "unicode_tables.inc"
 
@@ -188,14 +189,13 @@ struct Ctx {
         unsigned scan_epoch = 0, chain_seen = 0, chain_ctl_seen = 0;
         bool chain_ready = false;
         hipStream_t st = nullptr;
-        bool used = false;
-        const void* out = nullptr;       // the mask buffer the slot's last batch writes
     };
     static constexpr int kFlowSlots = 4;
     FlowSlot flow[kFlowSlots];
     int flow_slots = 2;                  // slots in use (LATOK_FLOW_SLOTS, A/B)
     bool flow_ready = false;
     unsigned long long flow_seq = 0;     // batches submitted so far
+    latok::FlowHazards flow_held;        // memory ranges of the batches in flight, per slot (flow_hazards.h)
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
     bool turn_stream_valid = false;
@@ -511,9 +511,8 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
             b->release();
         f.scan_epoch = f.chain_seen = f.chain_ctl_seen = 0;
         f.chain_ready = false;
-        f.used = false;
-        f.out = nullptr;
     }
+    g.flow_held.clear();
     g.flow_ready = false;
     g.flow_seq = 0;
     if (g.s_h2d) (void)hipStreamDestroy(g.s_h2d);
@@ -1897,6 +1896,29 @@ int latok_debug_set_scan_epoch(unsigned epoch) {
     return LATOK_OK;
 }
 
+/* test hook (not part of the ABI; needs no device): the flow's routing of batches to slots (flow_hazards.h) driven without a
+ * GPU.  One call = one batch touching n ranges (lo[i], bytes[i], is_write[i]); returns the slot it is enqueued on, *drained_out = 1
+ * when the flow had to be drained first.  n < 0: forget everything (= latok_flow_wait).  State of the calling thread. */
+extern "C" int latok_debug_flow_route(int n_slots, const uint64_t* lo, const uint64_t* bytes, const int* is_write, int n, int* drained_out) {
+    static thread_local latok::FlowHazards held;
+    static thread_local unsigned long long seq = 0;
+    if (drained_out) *drained_out = 0;
+    if (n < 0) { held.clear(); seq = 0; return 0; }
+    if (n_slots < 1 || n_slots > latok::FlowHazards::kMaxSlots || n > 16) return fail(LATOK_ERR_INVALID, "1..4 slots, <= 16 ranges");
+    latok::FlowRange r[16];
+    for (int i = 0; i < n; ++i) r[i] = latok::flow_range((const void*)(uintptr_t)lo[i], (size_t)bytes[i], is_write[i] != 0);
+    const int turn = (int)(seq % (unsigned)n_slots);
+    int s = held.route(n_slots, turn, r, n);
+    if (s == latok::FlowHazards::kDrainFirst) {
+        held.clear();
+        if (drained_out) *drained_out = 1;
+        s = turn;
+    }
+    held.note(s, r, n);
+    ++seq;
+    return s;
+}
+
 /* test hook (not part of the ABI; needs no device): the host decoder of small UTF-8 batches (host_decode_small).  Returns 1 and
  * fills cps_out[<= total bytes], cp_row_out[n_str + 1], bytepos_out[<= total bytes + 1] when every string is well formed,
  * 0 when the batch is left to the device paths, < 0 on a bad argument. */
@@ -1958,7 +1980,7 @@ static int flow_drain(Ctx& g) {
         }
         if (!done) HIP_TRY(hipStreamSynchronize(g.flow[i].st));
     }
-    for (int i = 0; i < g.flow_slots; ++i) g.flow[i].used = false;   // nothing in flight: no mask buffer is being written
+    g.flow_held.clear();   // nothing in flight: no buffer is being read or written
     return LATOK_OK;
 }
 // Reserve what a batch needs in a slot.  A buffer that has to grow is reallocated only once nothing in flight can still use it.
@@ -1975,17 +1997,34 @@ static int flow_reserve(Ctx& g, std::initializer_list<SlotNeed> needs) {
         if (!rc) rc = n.buf->ensure(n.bytes);
     return rc;
 }
-// Slots are used in turn -- except that a batch which writes an output buffer of a batch still in flight goes to THAT batch's
-// slot, whose stream orders the two (callers that alternate buffers never hit this; an event per batch to order such pairs
-// across streams would cost every batch ~3 us).
-static Ctx::FlowSlot& flow_pick(Ctx& g, const void* out) {
-    Ctx::FlowSlot* fp = &g.flow[g.flow_seq % (unsigned)g.flow_slots];
-    for (int i = 0; i < g.flow_slots; ++i)
-        if (g.flow[i].used && g.flow[i].out == out) fp = &g.flow[i];
-    return *fp;
+// Slots are used in turn -- except that a batch which touches memory a batch still in flight writes (or writes memory one
+// reads) goes to THAT batch's slot, whose stream orders the two; when batches of several slots are in its way the flow is
+// drained first (flow_hazards.h; callers that alternate buffers never hit either; an event per batch to order such pairs
+// across streams would cost every batch ~3 us).  *slot_out = the slot to enqueue on; flow_note after the batch is enqueued.
+static int flow_pick(Ctx& g, const latok::FlowRange* r, int n, int* slot_out) {
+    const int turn = (int)(g.flow_seq % (unsigned)g.flow_slots);
+    int s = g.flow_held.route(g.flow_slots, turn, r, n);
+    if (s == latok::FlowHazards::kDrainFirst) {
+        const int rc = flow_drain(g);
+        if (rc) return rc;
+        s = turn;
+    }
+    // a caller that never waits and never repeats a buffer: forget what an idle slot held; bound the list of a busy one
+    if (g.flow_held.held(s) >= latok::FlowHazards::kPruneAt) {
+        const hipError_t q = hipStreamQuery(g.flow[s].st);
+        if (q == hipSuccess) g.flow_held.clear_slot(s);
+        else if (q != hipErrorNotReady) return fail(LATOK_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        else if (g.flow_held.held(s) >= 4 * latok::FlowHazards::kPruneAt) {
+            HIP_TRY(hipStreamSynchronize(g.flow[s].st));
+            g.flow_held.clear_slot(s);
+        }
+    }
+    *slot_out = s;
+    return LATOK_OK;
 }
 // units: UTF-32 code points (unit_kind 4), PEP 393 units (1 / 2; positions are chars) or UTF-8 bytes (0; byte space)
-static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask) {
+static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* row_off, int64_t n_str, int64_t total, uint64_t* mask,
+                       int* slot_used = nullptr) {
     int rc = flow_setup(g);
     if (rc) return rc;
     if (n_str <= 0 || total <= 0) return LATOK_OK;
@@ -1994,15 +2033,21 @@ static int flow_submit(Ctx& g, const void* units, int unit_kind, const int64_t* 
     const uint32_t* cps = unit_kind == 4 ? (const uint32_t*)units : nullptr;
     const uint8_t* u8 = unit_kind == 4 ? nullptr : (const uint8_t*)units;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
-    Ctx::FlowSlot& f = flow_pick(g, mask);
+    const size_t unit_bytes = unit_kind == 0 ? 1 : (size_t)unit_kind;
+    const latok::FlowRange touched[3] = {latok::flow_range(mask, (size_t)((total + 63) / 64) * 8, true),
+                                         latok::flow_range(units, (size_t)total * unit_bytes, false),
+                                         latok::flow_range(row_off, (size_t)(n_str + 1) * 8, false)};
+    int slot = 0;
+    if ((rc = flow_pick(g, touched, 3, &slot))) return rc;
+    Ctx::FlowSlot& f = g.flow[slot];
     if ((rc = flow_reserve(g, {{&f.summ, ws_summ_bytes(n_tiles)}, {&f.seg_agg, ws_seg_bytes(n_tiles)}, {&f.tile_first, ws_first_bytes(n_tiles)},
                                {&f.fix_count, 8}})))
         return rc;
     if ((rc = run_pipeline(g, cps, row_off, n_str, total, mask, nullptr, latok::kModeBits, f.st, nullptr, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr, u8, unit_kind == 4 ? 0 : unit_kind, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
         return rc;
-    f.used = true;
-    f.out = mask;
+    g.flow_held.note(slot, touched, 3);
+    if (slot_used) *slot_used = slot;
     ++g.flow_seq;
     return LATOK_OK;
 }
@@ -2014,10 +2059,14 @@ static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_k
     if (rc) return rc;
     if (!result) return fail(LATOK_ERR_INVALID, "NULL result pointer");
     if (((uintptr_t)result & 7) != 0) return fail(LATOK_ERR_INVALID, "result pointer must be 8-byte aligned");
+    const size_t rec = (flags & LATOK_OUT_INT32) ? 4 : 8;   // bytes of a count / of one field of a record
     if (n_str <= 0 || total <= 0) {   // nothing to launch: counts of empty strings are zero, no items
-        Ctx::FlowSlot& f0 = flow_pick(g, items);
-        HIP_TRY(hipMemsetAsync(result, 0, 16, f0.st));
-        if (n_str > 0 && counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_str * ((flags & LATOK_OUT_INT32) ? 4 : 8), f0.st));
+        const latok::FlowRange w[2] = {latok::flow_range(result, 16, true), latok::flow_range(counts, n_str > 0 ? (size_t)n_str * rec : 0, true)};
+        int s0 = 0;
+        if ((rc = flow_pick(g, w, 2, &s0))) return rc;
+        HIP_TRY(hipMemsetAsync(result, 0, 16, g.flow[s0].st));
+        if (n_str > 0 && counts) HIP_TRY(hipMemsetAsync(counts, 0, (size_t)n_str * rec, g.flow[s0].st));
+        g.flow_held.note(s0, w, 2);
         return LATOK_OK;
     }
     if (!units || !row_off || !counts || ((!items || (feats && !feat)) && cap > 0)) return fail(LATOK_ERR_INVALID, "NULL buffer");
@@ -2030,7 +2079,18 @@ static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_k
     const uint8_t* u8 = unit_kind == 4 ? nullptr : (const uint8_t*)units;
     const int64_t n_tiles = (total + latok::kTile - 1) / latok::kTile;
     const int64_t words = (total + 63) / 64, c_tiles = (words + 63) / 64;
-    Ctx::FlowSlot& f = flow_pick(g, items);
+    // every output of the batch -- records, counts, result words, feature sums -- and its inputs
+    const size_t unit_bytes = unit_kind == 0 ? 1 : (size_t)unit_kind;
+    const size_t fields = feats ? 4 : (spans ? 2 : 1);
+    const latok::FlowRange touched[6] = {latok::flow_range(items, (size_t)cap * fields * rec, true),
+                                         latok::flow_range(counts, (size_t)n_str * rec, true),
+                                         latok::flow_range(result, 16, true),
+                                         latok::flow_range(feat, feats ? (size_t)cap * LATOK_FEATURE_COUNT : 0, true),
+                                         latok::flow_range(units, (size_t)total * unit_bytes, false),
+                                         latok::flow_range(row_off, (size_t)(n_str + 1) * 8, false)};
+    int slot = 0;
+    if ((rc = flow_pick(g, touched, 6, &slot))) return rc;
+    Ctx::FlowSlot& f = g.flow[slot];
     if ((rc = flow_reserve(g, {{&f.summ, ws_summ_bytes(n_tiles)}, {&f.seg_agg, ws_seg_bytes(n_tiles)}, {&f.tile_first, ws_first_bytes(n_tiles)},
                                {&f.fix_count, 8}, {&f.bits, (size_t)words * 8 + 8}, {&f.space, spans ? (size_t)words * 8 + 8 : 0},
                                {&f.kept, spans ? (size_t)words * 8 + 8 : 0}, {&f.wcnt, (size_t)c_tiles * 8 + 8}, {&f.bases, (size_t)c_tiles * 8 + 8},
@@ -2041,8 +2101,7 @@ static int flow_submit_compact(Ctx& g, bool spans, const void* units, int unit_k
     if ((rc = enqueue_compaction_dev(g, spans, feats, o32, cps, u8, unit_kind == 4 ? 0 : unit_kind, row_off, n_str, total, counts, items, feat,
                                      cap, result, nullptr, f.st, latok::DoneSignal{nullptr, 0, nullptr}, &f)))
         return rc;
-    f.used = true;
-    f.out = items;
+    g.flow_held.note(slot, touched, 6);
     ++g.flow_seq;
     return LATOK_OK;
 }
@@ -2364,10 +2423,11 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
     if ((rc = latok_gate_wait(gate, 120.0))) return rc;
     const int64_t t0 = mono_ns();
     HIP_TRY(hipEventRecord(g.ev[0], g.flow[g.flow_seq % (unsigned)g.flow_slots].st));   // the stream of the first submission
+    int last_slot = 0;
     for (int i = 0; i < iters; ++i)
-        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev))) break;
+        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev, &last_slot))) break;
     if (!rc) {
-        hipError_t e = hipEventRecord(g.ev[1], g.flow[(g.flow_seq + (unsigned)g.flow_slots - 1) % (unsigned)g.flow_slots].st);   // ... of the last one
+        hipError_t e = hipEventRecord(g.ev[1], g.flow[last_slot].st);   // ... of the last one
         if (e != hipSuccess) rc = fail(LATOK_ERR_HIP, "timed region failed: %s", hipGetErrorString(e));
     }
     const int rc_drain = flow_drain(g);

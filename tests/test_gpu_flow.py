@@ -103,6 +103,93 @@ def test_two_batches_in_flight_may_name_the_same_output_buffer(gpu, oracle):
             r.free()
 
 
+def _long_batch(rng, oracle, chars):
+    """a batch of >= `chars` chars made of whole repeats of one oracle-checked batch whose length is a multiple of 64 (so
+    the mask of the long batch is the repeated mask: strings are independent, default_tokenizer.py:137)"""
+    texts = random_strings(rng, 12000, 0, 300, ALPHABETS["mixed"])
+    texts.append("p" * ((-sum(len(t) for t in texts)) % 64))
+    cps, row = pack(texts)
+    want = oracle.split_batch(cps, row, want_values=False)[1]
+    reps = -(-chars // len(cps))
+    big_row = np.concatenate([[0]] + [row[1:] + i * len(cps) for i in range(reps)]).astype(np.int64)
+    return np.tile(cps, reps), big_row, np.tile(want, reps)
+
+
+def test_output_buffer_reused_behind_other_batches_is_ordered_behind_its_first_writer(gpu, oracle):
+    """A (long) -> X, B -> Y, C -> Z, D -> X: between A and D two other batches have passed through BOTH slots, and D must still
+    be ordered behind A (flow_hazards.h keeps every in-flight range of a slot, not its last output).  Second leg: D writes only
+    the TAIL of X's range (partial overlap; the words A writes last), where an unordered D would be overwritten by A."""
+    from latok_amd import _lib, batch
+    rng = random.Random(404)
+    a_cps, a_row, a_want = _long_batch(rng, oracle, 400_000_000)       # 1.6 GB of code points: ~0.3 ms of tile kernel
+    small = [pack(random_strings(rng, 300, 0, 120, ALPHABETS["mixed"])) for _ in range(3)]
+    ra = _Resident(gpu, a_cps, a_row)
+    rs = [_Resident(gpu, *p) for p in small]
+    wants = [oracle.split_batch(*p, want_values=False)[1] for p in small]
+    rb_, rc, rd = rs
+    try:
+        assert a_cps.nbytes >= 200 << 20
+        for leg in range(4):
+            tail = leg & 1
+            # D's place in X: the start of the buffer, or (16-byte aligned) flush with the end of A's words
+            d_word0 = ((ra.words - rd.words) & ~1) if tail else 0
+            d_ptr = ra.d_mask + 8 * d_word0
+            _lib.check(gpu.latok_memset_dev(ra.d_mask, 0xA5, ra.words * 8))
+            batch.flow_split_mask(ra.d_cps, ra.d_row, ra.n_str, ra.total, ra.d_mask)     # A -> X
+            batch.flow_split_mask(rb_.d_cps, rb_.d_row, rb_.n_str, rb_.total, rb_.d_mask)   # B -> Y
+            batch.flow_split_mask(rc.d_cps, rc.d_row, rc.n_str, rc.total, rc.d_mask)     # C -> Z
+            batch.flow_split_mask(rd.d_cps, rd.d_row, rd.n_str, rd.total, d_ptr)         # D -> (part of) X
+            batch.flow_wait()
+            got = ra.mask()
+            assert np.array_equal(got[d_word0:d_word0 + rd.words], wants[2]), "D's mask was overwritten"
+            assert np.array_equal(got[:d_word0], a_want[:d_word0])
+            assert np.array_equal(got[d_word0 + rd.words:], a_want[d_word0 + rd.words:])
+            assert np.array_equal(rb_.mask(), wants[0]) and np.array_equal(rc.mask(), wants[1])
+    finally:
+        for r in [ra] + rs:
+            r.free()
+
+
+def test_compaction_outputs_reused_across_the_flow_are_ordered(gpu, oracle):
+    """the same for the compaction calls: records, COUNTS and RESULT words all count as outputs (a batch that reuses only the counts
+    or result buffer of a batch in flight is ordered behind it too)"""
+    from latok_amd import _lib, batch
+    rng = random.Random(405)
+    a_cps, a_row, _ = _long_batch(rng, oracle, 120_000_000)
+    d_texts = random_strings(rng, 400, 0, 150, ALPHABETS["mixed"])
+    d_cps, d_row = pack(d_texts)
+    d_vals = oracle.split_batch(d_cps, d_row)[0]
+    d_offs = np.concatenate([np.nonzero(d_vals[d_row[i]:d_row[i + 1]])[0] for i in range(len(d_texts))]).astype(np.int32)
+    d_counts = np.array([np.count_nonzero(d_vals[d_row[i]:d_row[i + 1]]) for i in range(len(d_texts))], np.int32)
+    ra, rd = _Resident(gpu, a_cps, a_row), _Resident(gpu, d_cps, d_row)
+    cap_a = ra.total
+    bufs = {k: gpu.latok_dev_alloc(n) for k, n in (("items", cap_a * 4 + 64), ("counts", ra.n_str * 4 + 64), ("res", 64), ("items2", rd.total * 4 + 64),
+                                                    ("counts2", rd.n_str * 4 + 64), ("res2", 64), ("items3", rd.total * 4 + 64))}
+    assert all(bufs.values())
+    try:
+        for leg in range(3):
+            # leg 0: D reuses A's records buffer; leg 1: only A's counts buffer; leg 2: only A's result words
+            batch.flow_split_offsets(ra.d_cps, 4, ra.d_row, ra.n_str, ra.total, bufs["counts"], bufs["items"], cap_a, bufs["res"], dtype=np.int32)
+            for _ in range(2):   # two unrelated batches: one through each slot
+                batch.flow_split_offsets(rd.d_cps, 4, rd.d_row, rd.n_str, rd.total, bufs["counts2"], bufs["items2"], rd.total, bufs["res2"], dtype=np.int32)
+            items = bufs["items"] if leg == 0 else bufs["items3"]
+            counts = bufs["counts"] if leg == 1 else bufs["counts2"]
+            res = bufs["res"] if leg == 2 else bufs["res2"]
+            batch.flow_split_offsets(rd.d_cps, 4, rd.d_row, rd.n_str, rd.total, counts, items, rd.total, res, dtype=np.int32)
+            batch.flow_wait()
+            got_o, got_c, got_r = np.empty(d_offs.size, np.int32), np.empty(rd.n_str, np.int32), np.empty(2, np.int64)
+            _lib.check(gpu.latok_memcpy_d2h(got_o.ctypes.data, items, got_o.nbytes))
+            _lib.check(gpu.latok_memcpy_d2h(got_c.ctypes.data, counts, got_c.nbytes))
+            _lib.check(gpu.latok_memcpy_d2h(got_r.ctypes.data, res, 16))
+            assert got_r.tolist() == [d_offs.size, 0], (leg, got_r)
+            assert np.array_equal(got_c, d_counts) and np.array_equal(got_o, d_offs), leg
+    finally:
+        for p_ in bufs.values():
+            gpu.latok_dev_free(p_)
+        ra.free()
+        rd.free()
+
+
 @pytest.mark.parametrize("name", ["sym_everywhere", "all_starts"])
 def test_flow_under_run_time_rule_tables(gpu, oracle, name):
     from latok_amd import batch

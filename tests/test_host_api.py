@@ -267,3 +267,88 @@ def test_host_decoder_of_small_utf8_batches():
         assert pos.tolist() == want_pos + [b]
     for bad in ([b"ab\x80"], [b"\xbf"], [b"x\xe6\x97", b"\xa5y"], [b"\xf0\x9f\xa4"], [b"\xc3"], [b"ok", b"\xe6\x97 z"], [b"\xc3\x28"]):
         assert run(bad)[0] == 0, bad
+
+
+def _router():
+    import ctypes as C
+    from latok_amd import _lib
+    fn = _lib.load().latok_debug_flow_route
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+
+    def submit(*ranges, slots=2):
+        """ranges: (base, bytes, 'w' | 'r'); returns (slot, drained)"""
+        lo = np.array([r[0] for r in ranges], np.uint64)
+        nb = np.array([r[1] for r in ranges], np.uint64)
+        wr = np.array([r[2] == "w" for r in ranges], np.int32)
+        d = C.c_int(0)
+        s = fn(slots, lo.ctypes.data, nb.ctypes.data, wr.ctypes.data, len(ranges), C.byref(d))
+        assert s >= 0
+        return s, d.value
+
+    def reset():
+        fn(2, None, None, None, -1, None)
+
+    reset()
+    return submit, reset
+
+
+def test_flow_routing_orders_every_conflicting_pair():
+    """flow_hazards.h, the routing of latok_flow_* batches to slots (= streams), without a device.  The reference's contract
+    is that every call is independent (default_tokenizer.py:137-160): two batches in flight that touch the same memory must
+    share a stream, whichever batches went in between."""
+    submit, reset = _router()
+    X, Y, Z, IN = 0x10000, 0x20000, 0x30000, 0x900000
+    # the round-3 hole: A->X (slot 0), B->Y (1), C->Z (0), D->X would have gone to slot 1 with nothing ordering it behind A
+    assert submit((X, 4096, "w"), (IN, 1 << 20, "r")) == (0, 0)
+    assert submit((Y, 4096, "w"), (IN, 1 << 20, "r")) == (1, 0)
+    assert submit((Z, 4096, "w"), (IN, 1 << 20, "r")) == (0, 0)
+    assert submit((X, 4096, "w"), (IN, 1 << 20, "r")) == (0, 0)          # behind A on A's stream
+    # the turn has moved on by one for every batch: the next free batch takes the next slot in turn
+    assert submit((0x40000, 4096, "w"))[0] == 0
+    assert submit((0x50000, 4096, "w"))[0] == 1
+    # partial overlap (the tail of Y) is a conflict; touching ranges are not
+    reset()
+    assert submit((Y, 4096, "w")) == (0, 0)
+    assert submit((Z, 4096, "w")) == (1, 0)
+    assert submit((0x60000, 64, "w")) == (0, 0)
+    assert submit((Y + 4000, 4096, "w")) == (0, 0)    # turn says slot 1; the overlap with Y sends it to slot 0
+    assert submit((Z + 4096, 64, "w"))[1] == 0        # starts where Z ends: free
+    # a batch in the way of batches on BOTH slots: the flow is drained first
+    reset()
+    assert submit((X, 4096, "w")) == (0, 0)
+    assert submit((Y, 4096, "w")) == (1, 0)
+    s, drained = submit((X + 8, 8, "w"), (Y + 8, 8, "w"))
+    assert drained == 1
+    assert submit((X, 4096, "w"))[1] == 0 and submit((Y, 4096, "w"))[1] == 0
+    # reads: two readers of one buffer never conflict; a writer of a buffer that is being read does (and the other way round)
+    reset()
+    assert submit((X, 64, "w"), (IN, 4096, "r")) == (0, 0)
+    assert submit((Y, 64, "w"), (IN, 4096, "r")) == (1, 0)
+    assert submit((Z, 64, "w"), (Y, 64, "r")) == (1, 0)                 # reads what the batch on slot 1 writes (turn: 0)
+    reset()
+    assert submit((X, 64, "w"), (IN, 4096, "r")) == (0, 0)
+    assert submit((Y, 64, "w")) == (1, 0)
+    assert submit((Z, 64, "w")) == (0, 0)
+    assert submit((IN + 100, 8, "w")) == (0, 0)                         # overwrites input of the first batch (turn: 1)
+    # secondary outputs count too (counts / result words of a compaction batch): same counts buffer, different records
+    reset()
+    assert submit((X, 4096, "w"), (0x70000, 800, "w"), (0x80000, 16, "w")) == (0, 0)
+    assert submit((Y, 4096, "w"), (0x71000, 800, "w"), (0x80100, 16, "w")) == (1, 0)
+    assert submit((Z, 4096, "w"), (0x72000, 800, "w"), (0x80100, 16, "w")) == (1, 0)   # result words of the batch on slot 1
+    # alternating two buffers for ever keeps the lists short and the slots in turn
+    reset()
+    for i in range(1000):
+        assert submit((X if i % 2 == 0 else Y, 4096, "w"), (IN, 1 << 20, "r")) == (i % 2, 0)
+    # three buffers in rotation over two slots: every reuse lands behind its previous writer
+    reset()
+    where = {}
+    for i in range(300):
+        buf = (X, Y, Z)[i % 3]
+        s, drained = submit((buf, 4096, "w"))
+        if buf in where and not drained:
+            assert s == where[buf]
+        if drained:
+            where = {}
+        where[buf] = s
+    reset()

@@ -275,7 +275,9 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
                  const uint8_t* d_u8 = nullptr, int unit_kind = 0, int stages = 7,   // stages: 1 = tile index, 2 = tiles, 4 = resolve
                  uint8_t* d_codes = nullptr,     // d_codes: also leave the rule code of every char (featurize)
                  latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr},   // completion word stored by the last launch
-                 Ctx::FlowSlot* slot = nullptr) {   // the workspace of a batch-flow slot instead of the context's own
+                 Ctx::FlowSlot* slot = nullptr,   // the workspace of a batch-flow slot instead of the context's own
+                 uint64_t* d_lead = nullptr, uint16_t* d_lead_pref = nullptr, int64_t* d_lead_cnt = nullptr) {   // byte space: also leave the
+                 // lead-byte mask, the leads of a tile before each word and the leads per tile (code-point results, mask_utf8_via_bytes)
     if (total <= 0 || n_str <= 0) return LATOK_OK;
     if (d_u8) {   // byte space: UTF-8 bytes in, positions are bytes; or (unit_kind 1 / 2) fixed-width code units, positions are chars
         if (mode != latok::kModeBits) return fail(LATOK_ERR_INVALID, "byte-space input supports the bitmask outputs only");
@@ -353,6 +355,9 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     P.bits_out = d_bits;
     P.values_out = d_values;
     P.space_out = d_space;
+    P.lead_out = d_lead;
+    P.lead_pref_out = d_lead_pref;
+    P.lead_cnt_out = d_lead_cnt;
     P.codes_out = d_codes;
     if (!d_tile_first) d_tile_first = (int64_t*)w_first.p;   // the per-tile string index lives in the workspace
     P.tile_first = d_tile_first;
@@ -1401,6 +1406,75 @@ int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_
     return LATOK_OK;
 }
 
+// Code-point boundary mask of a UTF-8 batch WITHOUT a UTF-32 copy of it (the reference reads code points, latok.c:53-55,79; a
+// UTF-8 caller has bytes): the byte-space tile kernel on the bytes, which also leaves the lead-byte mask and the lead counts
+// per word and per tile; one scan of the tile counts (k_scan_chained); then k_lead_compress packs the boundary bits at lead bytes and
+// turns the byte offsets into code-point offsets.  HBM traffic: the bytes once + ~5 bits per byte of masks and ranks, against
+// 1 + 4 + 4 bytes per char through the staged decoder.  Nothing waits for the host between the launches; the code-point total,
+// the capacity check and the malformed-input flag are read after one synchronisation.  *fallback_out = 1: the batch holds a
+// continuation byte that the byte-space model and the decoder treat differently (malformed UTF-8): the caller takes the decoder.
+static int mask_utf8_via_bytes(Ctx& g, const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes, bool dev,
+                               uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out, int64_t* total_cps_out,
+                               hipStream_t st, int* fallback_out) {
+    int rc;
+    *fallback_out = 0;
+    const uint8_t* d_u8 = utf8;
+    const int64_t* d_boff = byte_off;
+    if (!dev) {
+        if ((rc = g.u_bytes.ensure((size_t)total_bytes + 16))) return rc;
+        if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+        d_u8 = (const uint8_t*)g.u_bytes.p;
+        d_boff = (const int64_t*)g.u_boff.p;
+    }
+    const int64_t words_b = (total_bytes + 63) / 64, c_tiles = (words_b + 63) / 64;
+    const int64_t out_words = mask_cap_words < words_b ? mask_cap_words : words_b;   // (a batch has at most one char per byte)
+    if ((rc = g.bits.ensure((size_t)words_b * 8 + 8)) || (rc = g.space.ensure((size_t)words_b * 8 + 8)) ||
+        (rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8)) || (rc = g.bases.ensure((size_t)c_tiles * 8 + 8)) ||
+        (rc = g.wpref.ensure((size_t)words_b * 2 + 8)) || (rc = g.scalar.ensure(64)) || (rc = g.pin_tot.ensure(64)))
+        return rc;
+    uint64_t* d_out = mask_bits_out;
+    int64_t* d_cp_row = cp_row_off_out;
+    if (!dev) {
+        if ((rc = g.h_out.ensure((size_t)out_words * 8 + 8)) || (rc = g.u_row.ensure((size_t)(n_str + 1) * 8))) return rc;
+        d_out = (uint64_t*)g.h_out.p;
+        d_cp_row = (int64_t*)g.u_row.p;
+    }
+    unsigned epoch = 0;
+    if ((rc = next_scan_epoch(scan_state(g, nullptr), latok::count_blocks(words_b), st, &epoch))) return rc;
+    uint64_t* d_bmask = (uint64_t*)g.bits.p;
+    uint64_t* d_lead = (uint64_t*)g.space.p;
+    if ((rc = run_pipeline(g, nullptr, d_boff, n_str, total_bytes, d_bmask, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, d_u8, 0, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, nullptr, d_lead,
+                           (uint16_t*)g.wpref.p, (int64_t*)g.wcnt.p)))
+        return rc;
+    volatile int64_t* h_tot = (volatile int64_t*)g.pin_tot.h;
+    int64_t* p_tot = (int64_t*)g.pin_tot.d;
+    h_tot[0] = 0;
+    h_tot[1] = 0;
+    h_tot[3] = 0;
+    int* d_err = (int*)(p_tot + 1);
+    HIP_TRY(latok::launch_tile_scan((const int64_t*)g.wcnt.p, c_tiles, (int64_t*)g.bases.p, (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p,
+                                    epoch, (int64_t*)g.scalar.p, p_tot, d_err + 1, st));
+    HIP_TRY(latok::launch_lead_compress(d_bmask, d_lead, (const int64_t*)g.bases.p, (const int64_t*)g.wcnt.p, (const uint16_t*)g.wpref.p,
+                                        words_b, total_bytes, d_boff, n_str, (const int64_t*)g.scalar.p, d_out, out_words, d_cp_row,
+                                        (int*)(p_tot + 3), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_tot[1] != 0) return fail(LATOK_ERR_HIP, "internal: the chained scan did not complete (flag %lld)", (long long)h_tot[1]);
+    if (h_tot[3] != 0) { *fallback_out = 1; return LATOK_OK; }
+    const int64_t total_cps = h_tot[0];
+    *total_cps_out = total_cps;
+    const int64_t words = (total_cps + 63) / 64;
+    if (words > mask_cap_words) return fail(LATOK_ERR_INVALID, "mask_cap_words too small: need %lld", (long long)words);
+    if (!dev) {
+        if (words > 0) HIP_TRY(hipMemcpyAsync(mask_bits_out, d_out, (size_t)words * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cp_row_off_out, d_cp_row, (size_t)(n_str + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return LATOK_OK;
+}
+
 int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes,
                                 uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out,
                                 int64_t* total_cps_out, int flags, void* stream) {
@@ -1411,6 +1485,22 @@ int latok_split_mask_utf8_batch(const uint8_t* utf8, const int64_t* byte_off, in
     StreamTurn turn(g, stream);
     hipStream_t st = turn.st;
     const bool dev = (flags & LATOK_DEVICE_PTRS) != 0;
+    // large batches: byte space + compaction of the mask (no UTF-32 copy)
+    {
+        int64_t tb = total_bytes;
+        if (dev) {
+            if ((rc = resolve_total_device(byte_off, n_str, &tb, st))) return rc;
+        } else if ((rc = check_csr_host(byte_off, n_str, &tb))) {
+            return rc;
+        }
+        if (n_str > 0 && tb > kSmallChars && utf8 && cp_row_off_out && mask_bits_out && mask_cap_words >= 0 &&
+            (!dev || ((uintptr_t)utf8 & 15) == 0)) {
+            int fallback = 0;
+            rc = mask_utf8_via_bytes(g, utf8, byte_off, n_str, tb, dev, mask_bits_out, mask_cap_words, cp_row_off_out, total_cps_out, st,
+                                     &fallback);
+            if (rc || !fallback) return rc;
+        }
+    }
     int64_t total = 0;
     BytesRoute br;
     if ((rc = decode_utf8_to_workspace(g, utf8, byte_off, n_str, total_bytes, dev, st, &total, &br))) return rc;

@@ -355,11 +355,20 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t
     __shared__ uint32_t out_s[kU8Block];
     const int64_t chunk = (int64_t)blockIdx.x * kU8Threads + threadIdx.x;
     const int64_t p = chunk * kU8Chunk;
-    uint4 v = make_uint4(0, 0, 0, 0);
+    uint4 v = make_uint4(0, 0, 0, 0), vd = v;   // vd: the same bytes as the decode windows see them
     uint32_t leads = 0;
     if (p < total) {
         v = utf8_load16(u8, p, total);
         leads = utf8_lead_mask16(v);
+        vd = v;
+        if (total - p < 16) {
+            // the batch ends inside my chunk: for the lead count the padding had to look like continuation bytes, for the
+            // decode WINDOWS a byte that does not exist is "not a continuation byte" (a lead cut short by the end of the batch
+            // is U+FFFD, as everywhere else -- the 0x80 padding used to complete it: b"\xc3" at the very end decoded as U+00C0)
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int i = (int)(total - p); i < 16; ++i) w[i >> 2] |= 0xFFu << (8 * (i & 3));
+            vd = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
     int tot;
     const int excl = block_exclusive_scan_int(__popc(leads), &tot, lds);
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t
     // bytes p+16 .. p+18 (what a sequence that starts in my last bytes may need): the next thread's first dword, taken
     // while every lane is active; the last lane of a wave reads them from memory.  A byte that does not exist reads as 0xFF
     // ("not a continuation byte": the sequence is truncated -> U+FFFD).
-    uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vd.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
     if ((threadIdx.x & 63) == 63) {
         nx = 0;
         for (int i = 0; i < 3; ++i) {
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(kU8Threads) void k_utf8_decode_chunks(const uint8_t
             // 554 us for the 471 MB of C3.)
             // bytes p+16 .. p+18: the next thread's first dword; the last lane of a wave reads them from memory
             const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-            const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx};
+            const uint32_t w[5] = {vd.x, vd.y, vd.z, vd.w, nx};
             uint32_t rest[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

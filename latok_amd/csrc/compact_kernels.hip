@@ -21,6 +21,7 @@
 
 #include "bitscan.h"
 #include "kernels.h"
+#include "lane_math.h"
 
 namespace latok {
 
@@ -473,6 +474,142 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
     counts_scatter_block<KIND, OUT>(bits, space, item_mask, tile_rank, tile_cnt, word_pref, n_words, total, row_off, n_str, tile_first,
                                     out, n_items_dev, cap, counts, n_scatter_blocks, err, blockIdx.x);
     signal_block_done(done);   // (pinned outputs of a small host batch: the host polls the completion word)
+}
+
+// ---- code-point results of a UTF-8 batch from its BYTE-space results ------------------------------------------------------
+// The reference reads a str as code points (latok.c:53-55,79) and reports boundaries as code-point indices.  A UTF-8 batch in
+// code-point units used to be decoded into a UTF-32 copy first (1 B read + 4 B written + 4 B read again per char); instead the
+// byte-space tile kernel runs on the bytes themselves and leaves two bitmasks over the BYTES -- boundaries (set at lead bytes)
+// and lead bytes -- plus, per 64-byte word, the number of leads of its tile before it and the leads per tile.  Code point k of
+// the batch is the k-th lead byte, so
+//   cp mask        = the boundary bits at the lead positions, packed: per word pext(boundaries, leads), appended at the word's
+//                    rank = leads before it (tile_rank from k_scan_chained over the tile counts + the word's prefix);
+//   cp_row_off[s]  = number of leads before byte_off[s].
+// One wave per tile of 64 words; the compressed chunks of the tile's words meet in LDS (a chunk straddles at most two output
+// words) and leave as whole words.  Every output word is written exactly once, by the tile that holds the lead of its LAST
+// bit (the batch's final, partial word: by the last tile with a lead): the bits of such a word that belong to earlier tiles
+// are recomputed from the words in front of the tile (the 63 leads before a tile lie in its previous 4 words in well-formed
+// text; the look-back goes on for as long as malformed input makes it).  No atomics on global memory, no cleared output
+// (two global atomics per tile cost 40 of 110 us on C3).  Role 2 (the workgroups behind): one thread per row offset.
+// *odd is raised when the byte-space model and the decoder's model of MALFORMED input differ: a continuation byte with no lead
+// byte within the 3 bytes before it, or at the start of a string (the host then takes the staged decoder instead).
+__global__ __launch_bounds__(256) void k_lead_compress(const uint64_t* __restrict__ bmask, const uint64_t* __restrict__ lead,
+                                                       const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt,
+                                                       const uint16_t* __restrict__ word_pref, int64_t n_words, int64_t total_bytes,
+                                                       const int64_t* __restrict__ byte_off, int64_t n_str,
+                                                       const int64_t* __restrict__ total_cps_dev, uint64_t* __restrict__ out_mask,
+                                                       int64_t cap_words, int64_t* __restrict__ cp_row_off, int* __restrict__ odd,
+                                                       unsigned n_tile_blocks) {
+    if (blockIdx.x >= n_tile_blocks) {   // role 2: code-point offset of every string (and of the end of the batch)
+        const int64_t total_cps = *total_cps_dev;
+        const int64_t s = (int64_t)(blockIdx.x - n_tile_blocks) * 256 + threadIdx.x;
+        if (s > n_str) return;
+        const int64_t b = byte_off[s];
+        if (b >= total_bytes) { cp_row_off[s] = total_cps; return; }
+        const int64_t bw = b >> 6;
+        const uint64_t mw = lead[bw];
+        cp_row_off[s] = tile_rank[bw >> 6] + word_pref[bw] + __popcll(mw & low_mask((int)(b & 63)));
+        if (s < n_str && byte_off[s + 1] > b && !((mw >> (b & 63)) & 1ull)) *odd = 1;   // a string begins with a continuation byte
+        return;
+    }
+    __shared__ unsigned long long win_s[4][66];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t w0 = t * 64;
+    if (w0 >= n_words) return;                                      // whole wave
+    const int64_t w = w0 + lane;
+    const bool in = w < n_words;
+    // everything the wave needs from memory is requested here, in one round trip, by unconditional loads at clamped addresses
+    // (a predicated load is a branch, and hipcc waits for everything in flight at it)
+    const int64_t total_cps = *total_cps_dev;
+    const int64_t wc = in ? w : n_words - 1;
+    uint64_t m = lead[wc];
+    uint64_t x = bmask[wc];
+    const uint64_t m_before = lead[wc > 0 ? wc - 1 : 0];            // (the word before mine: every lane loads its own, coalesced)
+    const int64_t wk = w0 - 1 - lane > 0 ? w0 - 1 - lane : 0;       // look-back: lane k takes the k-th word in front of the tile
+    uint64_t mb = lead[wk], xb = bmask[wk];
+    const int n_wave = (int)tile_cnt[t];
+    const int64_t pos0 = tile_rank[t];                              // code-point index of the tile's first lead
+    const int pref = (int)word_pref[wc];
+    unsigned long long* win = win_s[wave];
+    win[lane] = 0ull;
+    if (lane < 2) win[64 + lane] = 0ull;
+    if (!in) { m = 0ull; x = 0ull; }
+    // continuation bytes without a lead byte in the 3 bytes before them (malformed input)
+    {
+        const uint64_t C = in ? (~m & valid_mask(w, total_bytes)) : 0ull;
+        const uint64_t Cp = w > 0 ? ~m_before : 0ull;
+        const uint64_t run = C & ((C << 1) | (Cp >> 63)) & ((C << 2) | (Cp >> 62)) & ((C << 3) | (Cp >> 61));
+        if (run) *odd = 1;
+    }
+    if ((total_cps + 63) / 64 > cap_words) return;                  // the caller's mask is too small: nothing is written
+    if (n_wave == 0) return;
+    const int64_t ow0 = pos0 >> 6;                                  // first output word the tile has bits in
+    const int64_t end = pos0 + n_wave;                              // one past the tile's last code point
+    // words I own: those whose last bit is mine, + the batch's final partial word if its last lead is mine
+    const int64_t own_end = end == total_cps ? (end + 63) >> 6 : end >> 6;   // one past my last owned word
+    if (own_end <= ow0) return;                                     // all my bits lie in a word a later tile owns
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (x) {                                                        // (a word without boundaries adds nothing)
+        const uint64_t c = lk_pext64(x, m);
+        const int64_t pos = pos0 + pref;
+        const int rel = (int)((pos >> 6) - ow0), sh = (int)(pos & 63);
+        atomicOr(&win[rel], c << sh);
+        if (sh && (c >> (64 - sh))) atomicOr(&win[rel + 1], c >> (64 - sh));
+    }
+    // the bits of my first word that belong to earlier tiles: the `need` leads in front of the tile, nearest word first
+    int need = (int)(pos0 & 63);
+    for (int64_t back = 0; need > 0; back += 64) {                  // wave-uniform; one round unless the input is malformed
+        if (back > 0) {
+            const int64_t wj = w0 - 1 - back - lane;
+            mb = wj >= 0 ? lead[wj] : 0ull;
+            xb = wj >= 0 ? bmask[wj] : 0ull;
+        } else if (w0 - 1 - lane < 0) {
+            mb = 0ull;
+            xb = 0ull;
+        }
+        const int cnt = __popcll(mb);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        const int before = inc - cnt;                               // leads between my word and the tile
+        if (cnt > 0 && before < need) {
+            const int take = min(cnt, need - before);               // my top `take` leads
+            const uint64_t c = lk_pext64(xb, mb) >> (cnt - take);
+            if (c) atomicOr(&win[0], c << (need - before - take));
+        }
+        need -= __shfl(inc, 63);
+        if (w0 - 1 - back - 63 <= 0) break;                         // the batch begins here (cannot happen with need > 0: ranks are exact)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n_out = (int)(own_end - ow0);                         // 1..65
+    for (int j = lane; j < n_out; j += 64) out_mask[ow0 + j] = win[j];
+}
+
+hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* lead, const int64_t* tile_rank, const int64_t* tile_cnt,
+                                const uint16_t* word_pref, int64_t n_words, int64_t total_bytes, const int64_t* byte_off, int64_t n_str,
+                                const int64_t* total_cps_dev, uint64_t* out_mask, int64_t cap_words, int64_t* cp_row_off, int* odd,
+                                hipStream_t st) {
+    const int64_t n_tiles = (n_words + 63) / 64;
+    const unsigned nb_tiles = (unsigned)((n_tiles + 3) / 4), nb_rows = (unsigned)((n_str + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_lead_compress, dim3(nb_tiles + nb_rows), dim3(256), 0, st, bmask, lead, tile_rank, tile_cnt, word_pref, n_words,
+                       total_bytes, byte_off, n_str, total_cps_dev, out_mask, cap_words, cp_row_off, odd, nb_tiles);
+    return hipGetLastError();
+}
+
+// exclusive scan of per-tile counts that some other kernel left (the byte-space tile kernel: leads per tile): k_scan_chained alone
+hipError_t launch_tile_scan(const int64_t* tile_cnt, int64_t n_tiles, int64_t* tile_rank, unsigned long long* chain, unsigned* ticket,
+                            unsigned epoch, int64_t* total_dev, int64_t* total_host, int* err, hipStream_t st) {
+    if (n_tiles <= 0) return hipSuccess;
+    const unsigned n_blocks = (unsigned)((n_tiles + kChainChunk - 1) / kChainChunk);
+    hipLaunchKernelGGL(k_scan_chained, dim3(n_blocks), dim3(kChainBlock), 0, st, tile_cnt, n_tiles, tile_rank, chain, ticket, epoch,
+                       n_blocks, total_dev, total_host, err);
+    return hipGetLastError();
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------------------

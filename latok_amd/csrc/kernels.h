@@ -98,6 +98,10 @@ struct SplitParams {
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
     uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)
+    uint64_t* lead_out;         // optional (kModeBytes): bit i = byte i is a LEAD byte (not 10xxxxxx), same layout as bits_out
+                                // (code-point results from the byte-space mask: compact_kernels.hip, k_lead_compress)
+    uint16_t* lead_pref_out;    // with lead_out: [words] leads of the tile before each word, and
+    int64_t* lead_cnt_out;      //                [n_tiles] leads per tile (what k_word_counts would compute from lead_out)
     uint8_t* codes_out;         // optional (kModeBits / kModeRules on UTF-32 input, t2 = rule codes): the code byte of every char
                                 // (featurize: k_features_tiles reads 1 B/char instead of classifying 4 B/char again)
     int64_t* tile_first;        // [n_tiles]: first string that starts at or after each tile's first char (k_tile_index; also read by the compaction passes)
@@ -183,6 +187,13 @@ hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, con
                                  const int64_t* tile_rank, const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words,
                                  int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
                                  const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st, DoneSignal done = DoneSignal{nullptr, 0, nullptr});
+// code-point boundary mask + code-point row offsets from the byte-space mask and the lead-byte mask of a UTF-8 batch
+hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* lead, const int64_t* tile_rank, const int64_t* tile_cnt,
+                                const uint16_t* word_pref, int64_t n_words, int64_t total_bytes, const int64_t* byte_off, int64_t n_str,
+                                const int64_t* total_cps_dev, uint64_t* out_mask, int64_t cap_words, int64_t* cp_row_off, int* odd,
+                                hipStream_t st);
+hipError_t launch_tile_scan(const int64_t* tile_cnt, int64_t n_tiles, int64_t* tile_rank, unsigned long long* chain, unsigned* ticket,
+                            unsigned epoch, int64_t* total_dev, int64_t* total_host, int* err, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder
 hipError_t launch_utf8_block_counts(const uint8_t* u8, int64_t total, int64_t* block_cnt, hipStream_t st);
 hipError_t launch_utf8_decode(const uint8_t* u8, int64_t total, const int64_t* byte_off, int64_t n_str,

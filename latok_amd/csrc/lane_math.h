@@ -72,6 +72,69 @@ LATOK_HD lk_w lk_w_shr(lk_w x, uint32_t in) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Parallel bit extract (x86 pext; Hacker's Delight 7-4 "compress"): the bits of x at the set positions of m, packed at the
+// bottom in order.  Code-point results from a byte-space mask: m = the lead bytes of a 64-byte word, x = boundary bits at lead
+// bytes -> boundary bits of the word's chars (compact_kernels.hip: k_lead_compress).  On 32-bit halves: five rounds each.
+// ---------------------------------------------------------------------------------------------------------------
+LATOK_HD uint32_t lk_pext32(uint32_t x, uint32_t m) {
+    x &= m;
+    uint32_t mk = ~m << 1;                    // counts the 0s to the right of every position, one bit of the count per round
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 5; ++i) {
+        uint32_t mp = mk ^ (mk << 1);         // parallel suffix: parity of the zeros below
+        mp ^= mp << 2;
+        mp ^= mp << 4;
+        mp ^= mp << 8;
+        mp ^= mp << 16;
+        const uint32_t mv = mp & m;           // bits that move by 2^i in this round
+        m = (m ^ mv) | (mv >> (1 << i));
+        const uint32_t t = x & mv;
+        x = (x ^ t) | (t >> (1 << i));
+        mk &= ~mp;
+    }
+    return x;
+}
+LATOK_HD lk_u64 lk_pext64(lk_u64 x, lk_u64 m) {
+    const uint32_t lo = lk_pext32((uint32_t)x, (uint32_t)m), hi = lk_pext32((uint32_t)(x >> 32), (uint32_t)(m >> 32));
+    return (lk_u64)lo | ((lk_u64)hi << __builtin_popcount((uint32_t)m));   // (a shift by 32 is fine on 64 bits)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Byte space: class-table indices of a multi-byte char straight from its bytes (split_kernels.hip: lead_hi_lo explains the
+// scheme).  lk_lead_entry_of(b0) = the table entry of lead byte b0 (0xC0..0xFF); lk_lead_hi_lo(entry, W) with W = the 4 bytes
+// from the lead on: hi = cp >> 7, lo = cp & 127 of the char, returns true when the sequence is cut short (U+FFFD).
+// ---------------------------------------------------------------------------------------------------------------
+struct lk_lead_entry {
+    uint32_t sel;    // byte selector (v_perm_b32 encoding: 0..3 = byte of W, 0x0C = zero): R = {last, before last, before that, 0}
+    uint32_t hi0;    // the lead byte's own contribution to cp >> 7
+    uint32_t need;   // 0xC0 in every byte of R that must be a continuation byte
+};
+LATOK_HD lk_lead_entry lk_lead_entry_of(uint32_t b0) {
+    const int n = 2 + (b0 >= 0xE0u) + (b0 >= 0xF0u);     // 0xF8..0xFF count as 4-byte leads with 3 payload bits
+    lk_lead_entry e;
+    e.sel = n == 2 ? 0x0C0C0001u : (n == 3 ? 0x0C0C0102u : 0x0C010203u);
+    e.hi0 = n == 2 ? 0u : (n == 3 ? (b0 & 15u) << 5 : (b0 & 7u) << 11);
+    e.need = n == 2 ? 0x000000C0u : (n == 3 ? 0x0000C0C0u : 0x00C0C0C0u);
+    return e;
+}
+LATOK_HD bool lk_lead_hi_lo(lk_lead_entry e, uint32_t W, uint32_t* hi, uint32_t* lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t R = __builtin_amdgcn_perm(W, W, e.sel);
+#else
+    uint32_t R = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t s = (e.sel >> (8 * k)) & 0xFFu;
+        if (s < 4u) R |= ((W >> (8 * s)) & 0xFFu) << (8 * k);
+    }
+#endif
+    *lo = (R & 0x3Fu) | ((R >> 2) & 0x40u);
+    *hi = e.hi0 + ((R >> 9) & 0x1Fu) + (((R >> 16) & 0x3Fu) << 5);
+    return ((R ^ 0x80808080u) & e.need) != 0u;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 8x8 bit-matrix transpose: input byte r (bits 8r..8r+7) = row r; output byte c holds column c (bit r = row r).
 // ---------------------------------------------------------------------------------------------------------------
 LATOK_HD lk_u64 lk_transpose8(lk_u64 x) {

@@ -159,7 +159,8 @@ struct TileLds {
     uint8_t* halo;         // 16 bytes, wave private
     lk_u64* bw;            // 65 words of string-start bits, wave private
     const uint8_t* lut;    // kModeLatin1: slice LUT (kSliceLutBytes) in place of the Unicode tables
-    const uint8_t* ctab;   // kModeLatin1: split code of each of the 256 Latin-1 chars
+    const uint8_t* ctab;   // kModeLatin1: split code of each of the 256 Latin-1 chars (kModeBytes: the stage-2 block of U+0000, for its ASCII tiles)
+    const uint8_t* ltab;   // kModeBytes: decode table of the multi-byte lead bytes (kLeadTabBytes, build_lead_table)
     uint64_t* small_bits;  // k_small_batch: where the tile's boundary / SPACE words go (LDS) in place of P.bits_out /
     uint64_t* small_space; // P.space_out -- the kernel arguments stay where they are (no private copy of the rule tables)
 };
@@ -342,6 +343,37 @@ __device__ __forceinline__ bool units_phase1(const SplitParams& P, const TileLds
 // the window of slot (dword Q, lead mask m within the dword): its 4 bytes and where in the dword the lead sits
 // the window of a slot of dword Q: m = lead mask within the dword in "bit 7 of the byte" form; the slot takes its lowest
 // lead: *r_out = which byte of the dword, returns the 4 bytes from there on
+// ---------------------------------------------------------------------------------------------------------------
+// kModeBytes: class of a multi-byte char straight from its bytes.  What the two-stage class table wants is hi = cp >> 7 and
+// lo = cp & 127; with Z = "the payload bits of every byte but the last" = cp >> 6 they are hi = Z >> 1, lo = (Z & 1) << 6 | last
+// payload.  The code point itself is never assembled: a 16-byte table entry per lead byte (0xC0..0xFF) holds
+//   .x  a v_perm selector that brings the sequence into ONE order whatever its length: R = {last, the byte before it, the one
+//       before that (4-byte sequences; else 0), 0}
+//   .y  what the lead byte itself contributes to hi:  0 | (b0 & 15) << 5 | (b0 & 7) << 11   (2 / 3 / 4 bytes)
+//   .z  the bytes of R that must be continuation bytes (0xC0 per byte)
+// so hi = .y + (R.byte1 & 0x3E) >> 1 + (R.byte2 & 0x3F) << 5 (for a 2-byte sequence R.byte1 is the lead itself: bit 5 of
+// 110xxxxx is 0), lo = R.byte0 & 0x3F | (R.byte1 & 1) << 6.  15 VALU instructions + one ds_read_b128 per char instead of 27
+// through utf8_cp_of (sequence length by compares, variable shifts, validity by variable masks): the byte-space kernel is
+// VALU bound and spends half its instructions here on non-ASCII text.  Same results as utf8_cp_of + classify1: a sequence cut
+// short is U+FFFD, overlong / surrogate forms decode as they are, 0xF8..0xFF are 4-byte leads with 3 payload bits.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLeadTabBytes = 64 * 16;
+template <int NT>
+__device__ __forceinline__ void build_lead_table(uint8_t* lds) {
+    for (int i = threadIdx.x; i < 64; i += NT) {
+        const lk_lead_entry e = lk_lead_entry_of(0xC0u + (uint32_t)i);
+        reinterpret_cast<uint4*>(lds)[i] = make_uint4(e.sel, e.hi0, e.need, 0u);
+    }
+}
+// W = the 4 bytes from a lead byte >= 0xC0 on (memory order); *hi / *lo = the class-table indices of its char, returns whether
+// the sequence is cut short (the char is U+FFFD then; hi / lo are in range but meaningless)
+__device__ __forceinline__ bool lead_hi_lo(const uint8_t* ltab, uint32_t W, uint32_t* hi, uint32_t* lo) {
+    const uint4 q = *reinterpret_cast<const uint4*>(ltab + ((W & 0x3Fu) << 4));
+    lk_lead_entry e;
+    e.sel = q.x; e.hi0 = q.y; e.need = q.z;
+    return lk_lead_hi_lo(e, W, hi, lo);
+}
+
 template <int Q>
 __device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], uint32_t m, uint32_t* r_out) {
     const uint32_t r = ((uint32_t)__builtin_ctz(m | 0x80000000u) >> 3) & 3u;   // m == 0: a dummy decode, dropped by the caller
@@ -349,7 +381,31 @@ __device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], ui
     return __builtin_amdgcn_alignbyte(w[Q + 1], w[Q], r);
 }
 
-__device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane) {
+// byte space: the halo bytes of the tile at t0 -- lane 0: the dword before the tile, lanes 1..11: the 11 bytes after it
+__device__ __forceinline__ uint32_t bytes_halo_load(const uint8_t* __restrict__ u8, int64_t t0, int64_t total, int lane) {
+    uint32_t hb = 0;
+    if (lane == 0) {
+        if (t0 > 0) hb = *reinterpret_cast<const uint32_t*>(u8 + t0 - 4);
+    } else if (lane < 12) {
+        const int64_t q = t0 + kTile + (lane - 1);
+        if (q < total) hb = u8[q];
+    }
+    return hb;
+}
+
+#ifndef LATOK_AB_CPS_PREFETCH
+#define LATOK_AB_CPS_PREFETCH 2
+#endif
+struct CpsPrefetch {
+    u32x4 v[LATOK_AB_CPS_PREFETCH > 0 ? LATOK_AB_CPS_PREFETCH : 1];
+    bool valid;
+};
+
+__device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds& L, int64_t t0, int lane
+#ifdef LATOK_STAMPS
+                                             , unsigned long long* stamp_acc, unsigned long long& stamp_prev
+#endif
+                                             ) {
     const int64_t total = P.total;
     const uint8_t* __restrict__ u8 = P.u8;
     // the tile: 4 x 16 bytes per lane (row i covers bytes 1024 i + 16 lane ..)
@@ -370,19 +426,19 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
     }
     // halo bytes: lane 0 holds the dword before the tile (t0 is a multiple of 4096 and u8 is 16-byte aligned; byte j of it
     // = byte t0 - 4 + j), lanes 1..11 the 11 bytes after the tile (0 where the batch has ended)
-    uint32_t hb = 0;
-    if (lane == 0) {
-        if (t0 > 0) hb = *reinterpret_cast<const uint32_t*>(u8 + t0 - 4);
-    } else if (lane < 12) {
-        const int64_t q = t0 + kTile + (lane - 1);
-        if (q < total) hb = u8[q];
-    }
-    uint32_t hi_bits = hb & 0x80808080u;
+    uint32_t hb = bytes_halo_load(u8, t0, total, lane);
+    // All-ASCII tiles take their own road, which needs all four rows; a tile whose row 0 already holds a multi-byte char does not
+    // wait for the others to find that out.  (Requesting row 0 and the halo bytes of the wave's NEXT tile during phase 2 was
+    // measured on top of this: C3 0.505 -> 0.515 ms, C2 0.073 -> 0.077; the 16 extra bytes of scratch cost more than the wait.)
+    uint32_t hi_bits = (hb | v[0].x | v[0].y | v[0].z | v[0].w) & 0x80808080u;
+    if (__all(hi_bits == 0u)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) hi_bits |= (v[i].x | v[i].y | v[i].z | v[i].w) & 0x80808080u;
+        for (int i = 1; i < 4; ++i) hi_bits |= (v[i].x | v[i].y | v[i].z | v[i].w) & 0x80808080u;
+    }
     if (lane < 2) *reinterpret_cast<lk_u64*>(L.halo + 8u * lane) = 0ull;
     const bool all_ascii = __all(hi_bits == 0u);
     wave_lds_sync();   // the zero stores are ordered before everything below
+    LATOK_STAMP(11);   // (share of stamp 2: the tile's bytes have arrived)
 
     if (all_ascii) {
         // no multi-byte char in or around the tile (the common case): the RAW bytes go to the staging buffer and phase 2
@@ -410,75 +466,122 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         }
     }
 
+    const uint32_t code_fffd = classify1(L.t1, L.t2, 0xFFFDu);   // a sequence that is cut short
+    LATOK_STAMP(12);   // (share of stamp 2: owner of the byte before the tile)
+    // R rows (1 KiB each) per round, every stage over all of them: the table lookups of a round -- R x 16 ASCII, then R x 8 per
+    // level of the multi-byte decode (lead table, stage 1, stage 2) -- are in flight together, so a round is four trips to the
+    // LDS whatever R is.  (Stamped build on C3: the rows were 3.7 K clocks each for ~250 VALU instructions -- the wave sat in the
+    // LDS latency of one row at a time.)
+    constexpr int R = 1;   // (2 rows per round: 128 B more scratch, 0.505 -> 0.56 ms on C3; 4: 0.78 KB of scratch, 1.4 ms)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t d[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    for (int i0 = 0; i0 < 4; i0 += R) {
+        uint32_t d[R][4], out[R][4];
+#pragma unroll
+        for (int a = 0; a < R; ++a) { d[a][0] = v[i0 + a].x; d[a][1] = v[i0 + a].y; d[a][2] = v[i0 + a].z; d[a][3] = v[i0 + a].w; }
         // every byte as if it were ASCII: one lookup each in the stage-2 block of U+0000 (t1[0] == 0 by construction of the
         // tables); the results at non-ASCII positions are cleared below
-        uint32_t out[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            out[j] = (uint32_t)L.t2[d[j] & 0x7Fu] | ((uint32_t)L.t2[(d[j] >> 8) & 0x7Fu] << 8) |
-                     ((uint32_t)L.t2[(d[j] >> 16) & 0x7Fu] << 16) | ((uint32_t)L.t2[(d[j] >> 24) & 0x7Fu] << 24);
-        const uint32_t st = stage_addr(1024u * i + 16u * lane);
-        if (__all(((d[0] | d[1] | d[2] | d[3]) & 0x80808080u) == 0u)) {        // this 1 KiB row is pure ASCII
-            *reinterpret_cast<uint4*>(L.stage + st) = make_uint4(out[0], out[1], out[2], out[3]);
+        for (int a = 0; a < R; ++a) {
+            // all 16 lookups of the row requested before the first one is used: left to itself hipcc keeps two or three in flight
+            // (a register each), and the row waits for the LDS eight times instead of once
+            uint32_t c[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) c[k] = L.t2[(d[a][k >> 2] >> (8 * (k & 3))) & 0x7Fu];
+            asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
+                              "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[a][j] = c[4 * j] | (c[4 * j + 1] << 8) | (c[4 * j + 2] << 16) | (c[4 * j + 3] << 24);
+        }
+        uint32_t any_hi = 0;
+#pragma unroll
+        for (int a = 0; a < R; ++a) any_hi |= (d[a][0] | d[a][1] | d[a][2] | d[a][3]) & 0x80808080u;
+        if (__all(any_hi == 0u)) {        // these rows are pure ASCII
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+                *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * (i0 + a) + 16u * lane)) = make_uint4(out[a][0], out[a][1], out[a][2], out[a][3]);
             continue;
         }
         // bytes 16..18 after my chunk: the next lane's first dword; lane 63: lane 0's next row, or the bytes after the tile
-        uint32_t nx = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)d[0]);
-        {
+        uint32_t w[R][5];
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+            const int i = i0 + a;
+            uint32_t nx = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)d[a][0]);
             const uint32_t wrap = i < 3 ? (uint32_t)lane_read((int)v[(i + 1) & 3].x, 0)
                                         : ((uint32_t)lane_read((int)hb, 1) | ((uint32_t)lane_read((int)hb, 2) << 8) |
                                            ((uint32_t)lane_read((int)hb, 3) << 16));
             if (lane == 63) nx = wrap;
+            w[a][0] = d[a][0]; w[a][1] = d[a][1]; w[a][2] = d[a][2]; w[a][3] = d[a][3]; w[a][4] = nx;
         }
-        const uint32_t w[5] = {d[0], d[1], d[2], d[3], nx};
         // Per dword, all masks in "bit 7 of the byte" form (no bit gathering): hi = not ASCII, cont = 10xxxxxx, nl = the
         // leads that need a decode.  (Bytes past the end of the batch were loaded as 0: ASCII, never a continuation.)
-        uint32_t m1[4], m2[4], rest[4];
+        uint32_t m1[R][4], m2[R][4], rest[R][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t hi = d[q] & 0x80808080u;
-            const uint32_t cont = hi & ~(d[q] << 1);
-            const uint32_t ff = hi | (hi - (hi >> 7));                          // 0xFF at the non-ASCII bytes
-            out[q] = (out[q] & ~ff) | cont;                                     // ASCII codes | LK_CODE_CONT at continuation bytes
-            m1[q] = hi ^ cont;
-            m2[q] = m1[q] & (m1[q] - 1u);
-            rest[q] = m2[q] & (m2[q] - 1u);                                     // leads beyond two per dword (malformed input)
-        }
-        {
-            // stage by stage over the eight slots, so that the 8 + 8 table lookups are in flight together
-            uint32_t r[8], cp[8], blk[8], code[8];
-            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, m1[0], &r[0]));
-            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, m1[1], &r[1]));
-            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, m1[2], &r[2]));
-            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, m1[3], &r[3]));
-            cp[4] = utf8_cp_of(bytes_slot_window<0>(w, m2[0], &r[4]));
-            cp[5] = utf8_cp_of(bytes_slot_window<1>(w, m2[1], &r[5]));
-            cp[6] = utf8_cp_of(bytes_slot_window<2>(w, m2[2], &r[6]));
-            cp[7] = utf8_cp_of(bytes_slot_window<3>(w, m2[3], &r[7]));
-#pragma unroll
-            for (int s = 0; s < 8; ++s) blk[s] = L.t1[min(cp[s] >> kTblShift, (uint32_t)(kStage1Len - 1))];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) code[s] = L.t2[(blk[s] << kTblShift) | (cp[s] & ((1u << kTblShift) - 1u))];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) out[s & 3] |= ((s < 4 ? m1[s & 3] : m2[s & 3]) ? code[s] : 0u) << (8u * r[s]);
-        }
-        while (__any((rest[0] | rest[1] | rest[2] | rest[3]) != 0u)) {          // wave-uniform; never taken on well-formed UTF-8
-            uint32_t r[4], cp[4];
-            cp[0] = utf8_cp_of(bytes_slot_window<0>(w, rest[0], &r[0]));
-            cp[1] = utf8_cp_of(bytes_slot_window<1>(w, rest[1], &r[1]));
-            cp[2] = utf8_cp_of(bytes_slot_window<2>(w, rest[2], &r[2]));
-            cp[3] = utf8_cp_of(bytes_slot_window<3>(w, rest[3], &r[3]));
+        for (int a = 0; a < R; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                out[q] |= (rest[q] ? classify1(L.t1, L.t2, cp[q]) : 0u) << (8u * r[q]);
-                rest[q] &= rest[q] - 1u;
+                const uint32_t hi = d[a][q] & 0x80808080u;
+                const uint32_t cont = hi & ~(d[a][q] << 1);
+                const uint32_t ff = hi | (hi - (hi >> 7));                      // 0xFF at the non-ASCII bytes
+                out[a][q] = (out[a][q] & ~ff) | cont;                           // ASCII codes | LK_CODE_CONT at continuation bytes
+                m1[a][q] = hi ^ cont;
+                m2[a][q] = m1[a][q] & (m1[a][q] - 1u);
+                rest[a][q] = m2[a][q] & (m2[a][q] - 1u);                        // leads beyond two per dword (malformed input)
             }
+        {
+            // stage by stage over the 8 R slots
+            uint32_t r[R][8], W[R][8], hi[R][8], lo[R][8], blk[R][8], code[R][8];
+            bool bad[R][8];
+#pragma unroll
+            for (int a = 0; a < R; ++a) {
+                W[a][0] = bytes_slot_window<0>(w[a], m1[a][0], &r[a][0]);
+                W[a][1] = bytes_slot_window<1>(w[a], m1[a][1], &r[a][1]);
+                W[a][2] = bytes_slot_window<2>(w[a], m1[a][2], &r[a][2]);
+                W[a][3] = bytes_slot_window<3>(w[a], m1[a][3], &r[a][3]);
+                W[a][4] = bytes_slot_window<0>(w[a], m2[a][0], &r[a][4]);
+                W[a][5] = bytes_slot_window<1>(w[a], m2[a][1], &r[a][5]);
+                W[a][6] = bytes_slot_window<2>(w[a], m2[a][2], &r[a][6]);
+                W[a][7] = bytes_slot_window<3>(w[a], m2[a][3], &r[a][7]);
+            }
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    bad[a][s] = lead_hi_lo(L.ltab, W[a][s], &hi[a][s], &lo[a][s]);
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) blk[a][s] = L.t1[min(hi[a][s], (uint32_t)(kStage1Len - 1))];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) code[a][s] = L.t2[(blk[a][s] << kTblShift) | lo[a][s]];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const uint32_t c = bad[a][s] ? code_fffd : code[a][s];
+                    out[a][s & 3] |= ((s < 4 ? m1[a][s & 3] : m2[a][s & 3]) ? c : 0u) << (8u * r[a][s]);
+                }
         }
-        *reinterpret_cast<uint4*>(L.stage + st) = make_uint4(out[0], out[1], out[2], out[3]);
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+            while (__any((rest[a][0] | rest[a][1] | rest[a][2] | rest[a][3]) != 0u)) {   // wave-uniform; never taken on well-formed UTF-8
+                uint32_t r[4], cp[4];
+                cp[0] = utf8_cp_of(bytes_slot_window<0>(w[a], rest[a][0], &r[0]));
+                cp[1] = utf8_cp_of(bytes_slot_window<1>(w[a], rest[a][1], &r[1]));
+                cp[2] = utf8_cp_of(bytes_slot_window<2>(w[a], rest[a][2], &r[2]));
+                cp[3] = utf8_cp_of(bytes_slot_window<3>(w[a], rest[a][3], &r[3]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    out[a][q] |= (rest[a][q] ? classify1(L.t1, L.t2, cp[q]) : 0u) << (8u * r[q]);
+                    rest[a][q] &= rest[a][q] - 1u;
+                }
+            }
+            *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * (i0 + a) + 16u * lane)) = make_uint4(out[a][0], out[a][1], out[a][2], out[a][3]);
+        }
     }
+    LATOK_STAMP(13);   // (share of stamp 2: the four rows)
     // the 8 bytes after the tile -> halo[8..15] as staging bytes (code at a lead, LK_CODE_CONT at a continuation byte).
     // Lane k+1 owns byte k.
     {
@@ -556,6 +659,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     lk_local loc;
     lk_rule_counts counts;    // kModeValuesRules only: rows of C_SPLIT / C_SYM that hold at each char
     lk_u64 space_plane = 0;   // SPACE plane for the token-span passes (byte mode: smeared over continuation bytes)
+    lk_u64 cont_plane = 0;    // byte mode: continuation bytes of my word (P.lead_out)
     int no_patch = 0;         // byte mode: the tile holds multi-byte chars, the resolve stage must recompute, not patch
     if (MODE == kModeBlockMask) {
         // a1 -> start plane, a2 -> space plane; 64 bytes each, non-zero = set (PyArray_Nonzero, latok.c:178,198)
@@ -602,13 +706,6 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         if (mode_base(MODE) == kModeLatin1 || (mode_base(MODE) == kModeBytes && raw_stage)) {
             // d = raw bytes: classify + slice through the LUT; the neighbour bytes become codes through the code table
             LATOK_STAMP(9);    // (share of stamp 4: the four ds_read_b128 + neighbour bytes)
-#if defined(LATOK_AB_NO_SLICE)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) plane[b] = (lk_u64)d[2 * b] | ((lk_u64)d[2 * b + 1] << 32);
-#elif defined(LATOK_AB_ARITH_SLICE)
-            lk_bitslice64(d, plane);
-#else
-#ifndef LATOK_AB_LUT_ALWAYS
             if (ascii_tile) {
                 // all 4096 bytes are ASCII: bit-slice the raw bytes and derive the code planes as boolean functions of the
                 // raw planes -- no table, nothing through the LDS pipe (128 ds_read_b32 per word otherwise, which hit a bank
@@ -616,10 +713,9 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 lk_u64 rawp[8];
                 lk_bitslice64(d, rawp);
                 lk_ascii_code_planes<mode_rules(MODE)>(rawp, plane);
-            } else
-#endif
-                slice_lut64(d, L.lut, plane);
-#endif
+            } else {
+                slice_lut64(d, L.lut, plane);   // (Latin-1 tiles with chars >= 0x80; a raw byte-space tile is always ASCII)
+            }
             LATOK_STAMP(10);   // (share of stamp 4: LUT slicing)
             h.prev = lane > 0 ? L.ctab[h.prev] : h.prev;
             h.next0 = lane < 63 ? L.ctab[h.next0] : h.next0;
@@ -649,6 +745,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         } else if (mode_base(MODE) == kModeBytes) {
             // byte space: the continuation bytes carry LK_CODE_CONT -> continuation plane of my word
             const lk_u64 C = lk_take_cont_plane(plane);
+            cont_plane = C;
             lk_halo_bytes hb;
             bool next_has_cont;
             uint32_t own_code;
@@ -823,6 +920,25 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             }
         }
     }
+    if (mode_base(MODE) == kModeBytes && !SMALL && P.lead_out) {
+        // code-point results (k_lead_compress): the lead bytes of my word, how many leads the tile has before it, leads per tile
+        const int64_t remain = total - base;
+        const lk_u64 valid = remain >= 64 ? ~0ull : (remain <= 0 ? 0ull : ((1ull << remain) - 1ull));
+        const lk_u64 leadw = ~cont_plane & valid;
+        const int cnt = lk_popc(leadw);
+        int inc = cnt;
+        inc += dpp_mov<kDppRowShr1, 0xF>(0, inc);
+        inc += dpp_mov<kDppRowShr2, 0xF>(0, inc);
+        inc += dpp_mov<kDppRowShr4, 0xF>(0, inc);
+        inc += dpp_mov<kDppRowShr8, 0xF>(0, inc);
+        inc += dpp_mov<kDppRowBcast15, 0xA>(0, inc);
+        inc += dpp_mov<kDppRowBcast31, 0xC>(0, inc);
+        if (base < total) {
+            P.lead_out[base >> 6] = leadw;
+            P.lead_pref_out[base >> 6] = (uint16_t)(inc - cnt);
+        }
+        if (lane == 63) P.lead_cnt_out[t] = inc;
+    }
     LATOK_STAMP(8);
     wave_lds_sync();  // staging buffer is reused by this wave's next tile
     return out_word;
@@ -834,13 +950,6 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
 // register it loses track of, and the prefetch silently does nothing).  Measured on C2, same box, twice: kernel 96.1-96.3 ->
 // 94.4-94.5 us with R = 2 (R = 1: 93.9-94.1, R = 4: 95-99), step 106.6-107.3 -> 105.0-105.1; C3 / C4 / C5 within their noise
 // (profiles/r03_ab_headline_prefetch.txt).  -DLATOK_AB_CPS_PREFETCH=0: off.
-#ifndef LATOK_AB_CPS_PREFETCH
-#define LATOK_AB_CPS_PREFETCH 2
-#endif
-struct CpsPrefetch {
-    u32x4 v[LATOK_AB_CPS_PREFETCH > 0 ? LATOK_AB_CPS_PREFETCH : 1];
-    bool valid;
-};
 
 template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
@@ -883,7 +992,11 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     } else if (mode_base(MODE) == kModeUcs2) {
         units_phase1<2>(P, L, t0, lane);
     } else if (mode_base(MODE) == kModeBytes) {
-        raw_stage = bytes_phase1(P, L, t0, lane);
+        raw_stage = bytes_phase1(P, L, t0, lane
+#ifdef LATOK_STAMPS
+                                 , stamp_acc, stamp_prev
+#endif
+                                 );
         ascii_tile = raw_stage;
     } else if (FAST_TAIL) {
         // Small batches: the batch's last, partial tile takes the same road as a full one -- only the rows of 256 chars that
@@ -1156,9 +1269,9 @@ constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSeg
 constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
 constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
 constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
-constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: [slice LUT | code table] (ASCII tiles); Latin-1 has it at 0
+constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: the lead-byte decode table (kLeadTabBytes); Latin-1 has its [slice LUT | code table] at 0
 constexpr int kLdsTotalBase = kLdsSlice;
-constexpr int kLdsTotalBytes = kLdsSlice + kSliceLutBytes + 256;
+constexpr int kLdsTotalBytes = kLdsSlice + kLeadTabBytes;
 constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
 // Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
 // per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
@@ -1189,7 +1302,7 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
         build_latin1_tables<NT>(lds, P);
         return;
     }
-    if (mode_base(MODE) == kModeBytes) build_latin1_tables<NT>(lds + kLdsSlice, P);   // for its all-ASCII tiles
+    if (mode_base(MODE) == kModeBytes) build_lead_table<NT>(lds + kLdsSlice);
     constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
     constexpr int kPer = (kVec + NT - 1) / NT;                    // 4 with 768 threads
     const uint4* src = reinterpret_cast<const uint4*>(P.t1);
@@ -1220,8 +1333,9 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.stage = mine;
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
-    L.lut = lds + (mode_base(MODE) == kModeBytes ? kLdsSlice : 0);   // build_latin1_tables: kModeLatin1 at 0, kModeBytes behind the rest
-    L.ctab = L.lut + kSliceLutBytes;
+    L.lut = lds;                                                     // build_latin1_tables (kModeLatin1: in place of the Unicode tables)
+    L.ctab = mode_base(MODE) == kModeBytes ? L.t2 : L.lut + kSliceLutBytes;   // (byte space reads it for ASCII bytes only: stage-2 block of U+0000)
+    L.ltab = lds + kLdsSlice;
     L.small_bits = L.small_space = nullptr;
     return L;
 }
@@ -1263,7 +1377,10 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     // (b) the tiles
     // Output write combining (bitmask mode): the words of up to 8 tiles stay in registers and are stored together.
     // One 512-byte store per 16 KiB tile, interleaved with the read stream, costs ~5 % of HBM throughput.
-    constexpr bool kDefer = mode_writes_bits(MODE);
+    // UTF-32 input only: that kernel is HBM bound.  The narrow-input kernels are bound by instruction issue and registers: without
+    // the 16 VGPRs of the buffer Latin-1 104 VGPRs (was 121), UCS-2 123 + 64 B scratch (128 + 96), byte space 128 B scratch (192);
+    // C3 byte space 0.538 -> 0.506 ms, UCS-2 0.157 -> 0.142, C2 byte space 0.085 -> 0.073, Latin-1 0.069 -> 0.067.
+    constexpr bool kDefer = mode_writes_bits(MODE) && !mode_is_bytes(MODE);
     lk_u64 obuf[8];
     int slot = 0, k_first = wave;   // buffered tiles are k_first, k_first + kWPB, ...
     const int64_t n_words = (P.total + 63) >> 6;
@@ -2089,7 +2206,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     if (!(P.n_tokens_dev && *P.n_tokens_dev > P.cap)) {
         TileLds L;
         L.small_bits = L.small_space = nullptr;
-        L.t1 = L.t2 = L.lut = L.ctab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
+        L.t1 = L.t2 = L.lut = L.ctab = L.ltab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
         uint8_t* mine = lds + wave * kFeatWaveLds;
         L.stage = mine;
         L.halo = mine + kFeatWinBytes;
@@ -2137,7 +2254,7 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     TileLds L;
     L.t1 = S.P.t1;          // global memory
     L.t2 = S.P.t2;
-    L.lut = L.ctab = nullptr;
+    L.lut = L.ctab = L.ltab = nullptr;
     L.stage = lds;
     L.halo = lds + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(lds + kStageBytes + 16);
@@ -2349,7 +2466,7 @@ __global__ __launch_bounds__(64) void k_small_block_mask(SmallParams S) {
     __shared__ int s_flags[2];
     const int lane = threadIdx.x;
     TileLds L;
-    L.t1 = L.t2 = L.lut = L.ctab = nullptr;
+    L.t1 = L.t2 = L.lut = L.ctab = L.ltab = nullptr;
     L.small_bits = L.small_space = nullptr;
     L.stage = lds;
     L.halo = lds + kStageBytes;
@@ -2453,7 +2570,7 @@ hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStrea
     else if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);
     else if (mode == kModeRules) hipLaunchKernelGGL((k_tiles_main<kModeRules>), grid, block, 0, st, P);
-    else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, block, 0, st, P);
+    else if (mode == kModeBytes) hipLaunchKernelGGL((k_tiles_main<kModeBytes>), grid, dim3(tile_wpb(kModeBytes) * 64), 0, st, P);
     else if (mode == kModeLatin1) hipLaunchKernelGGL((k_tiles_main<kModeLatin1>), grid, dim3(tile_wpb(kModeLatin1) * 64), 0, st, P);
     else if (mode == kModeUcs2) hipLaunchKernelGGL((k_tiles_main<kModeUcs2>), grid, dim3(tile_wpb(kModeUcs2) * 64), 0, st, P);
     else if (mode == kModeBytesRules) hipLaunchKernelGGL((k_tiles_main<kModeBytesRules>), grid, block, 0, st, P);

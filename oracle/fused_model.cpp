@@ -418,3 +418,15 @@ extern "C" void fused_ascii_codes(const uint8_t* bytes64, uint8_t* planes_codes_
         table_codes_out[i] = (uint8_t)classify(bytes64[i]);
     }
 }
+
+// test hook: lane_math.h lk_pext64 (code-point results from byte-space masks: compact_kernels.hip, k_lead_compress)
+extern "C" unsigned long long fused_pext64(unsigned long long x, unsigned long long m) { return lk_pext64(x, m); }
+
+// test hook: lane_math.h lk_lead_entry_of + lk_lead_hi_lo (the byte-space kernel's table-driven decode of multi-byte chars):
+// W = 4 bytes from a lead byte >= 0xC0 on; returns 1 when the sequence is cut short, else 0 with *cp = (hi << 7) | lo
+extern "C" int fused_lead_decode(uint32_t W, uint32_t* cp) {
+    uint32_t hi = 0, lo = 0;
+    const bool bad = lk_lead_hi_lo(lk_lead_entry_of(W & 0xFFu), W, &hi, &lo);
+    *cp = (hi << 7) | lo;
+    return bad ? 1 : 0;
+}

@@ -223,3 +223,144 @@ def test_model_runtime_rule_tables_in_byte_space(model, oracle, name):
                                                       bits.ctypes.data, None) == 0
             got = np.unpackbits(bits.view(np.uint8), bitorder="little")[:total].astype(bool)
             assert np.array_equal(got, want), (name, rep, int(np.nonzero(got != want)[0][0]))
+
+
+def test_pext_of_the_lane_math_is_bit_extraction(model):
+    """lane_math.h lk_pext64 (five-round compress on 32-bit halves) against the definition, on random words, sparse / dense
+    masks, and the lead-byte masks UTF-8 text produces."""
+    model.fused_pext64.restype = C.c_uint64
+    model.fused_pext64.argtypes = [C.c_uint64, C.c_uint64]
+
+    def want(x, m):
+        out, k = 0, 0
+        for i in range(64):
+            if (m >> i) & 1:
+                out |= ((x >> i) & 1) << k
+                k += 1
+        return out
+
+    rng = random.Random(77)
+    cases = [(0, 0), (2**64 - 1, 2**64 - 1), (2**64 - 1, 0), (0x8000000000000001, 0x8000000000000001), (2**64 - 1, 0xFFFFFFFF00000000),
+             (2**64 - 1, 0x00000000FFFFFFFF), (0x123456789ABCDEF0, 0x5555555555555555)]
+    for _ in range(3000):
+        m = rng.getrandbits(64)
+        if rng.random() < 0.3:
+            m &= rng.getrandbits(64)
+        if rng.random() < 0.3:
+            m |= rng.getrandbits(64)
+        cases.append((rng.getrandbits(64), m))
+    for _ in range(500):   # lead masks of UTF-8: every lead followed by 0..3 continuation bytes
+        m, i = 0, rng.randint(0, 3)
+        while i < 64:
+            m |= 1 << i
+            i += rng.choice([1, 1, 2, 3, 3, 4])
+        cases.append((rng.getrandbits(64), m))
+    for x, m in cases:
+        assert model.fused_pext64(x, m) == want(x, m), (hex(x), hex(m))
+
+
+def _decode_per_lead(u8):
+    """the device decoder's rule (utf8_decode.h): one code point per lead byte (any byte that is not 10xxxxxx), read from the lead and
+    the continuation bytes right behind it; a sequence that is cut short gives U+FFFD; 0xF8..0xFF count as 4-byte leads.
+    Returns (cps, byte position of every cp)."""
+    b = u8.astype(np.int64)
+    n = b.size
+    is_cont = (b & 0xC0) == 0x80
+    lead = np.nonzero(~is_cont)[0]
+    b0 = b[lead]
+    extra = (b0 >= 0xC0).astype(np.int64) + (b0 >= 0xE0) + (b0 >= 0xF0)
+    cp = np.where(b0 < 0x80, b0, np.where(b0 >= 0xF0, b0 & 7, np.where(b0 >= 0xE0, b0 & 15, b0 & 31)))
+    bad = np.zeros(lead.size, bool)
+    for j in (1, 2, 3):
+        idx = lead + j
+        ok = idx < n
+        nxt = np.where(ok, b[np.minimum(idx, n - 1)], 0xFF)
+        need = extra >= j
+        good = need & ((nxt & 0xC0) == 0x80)
+        bad |= need & ~good
+        cp = np.where(good & ~bad, (cp << 6) | (nxt & 0x3F), cp)
+    cp = np.where(bad, 0xFFFD, cp)
+    return cp.astype(np.uint32), lead
+
+
+def test_model_code_point_mask_is_the_byte_space_mask_at_lead_bytes(model):
+    """The claim behind the code-point UTF-8 route (api.cpp mask_utf8_via_bytes): on ANY bytes -- well formed or not -- in which
+    every continuation byte has a lead byte within the 3 bytes before it inside its string, the boundaries of the decoded
+    code points (one per lead byte) are the byte-space boundaries read at the lead bytes.  Both sides in the CPU model.  Batches
+    that break the condition are what the kernel flags as `odd` (they go to the decoder)."""
+    model.fused_split_batch_utf8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(17)
+    # strings made of chunks: chars of every length, truncated sequences, lone leads, stray continuation bytes behind ASCII rule
+    # chars and behind complete sequences, 0xF8..0xFF leads; a few chunks that break the condition
+    chunks = [b"a", b"b", b"Z", b" ", b" ", b".", b"@", b"#", b":", b"/", b"\t", b"1", b"\xc3\xa9", b"\xe3\x81\x82", b"\xe6\x97\xa5",
+              b"\xf0\x9f\xa4\x93", b"\xe3\x80\x80", b"\xe3\x81", b"\xc3", b"\xf0\x9f", b"\xf0\x9f\xa4", b"a\x80", b".\x80", b"@\xbf\x80",
+              b"\xc3\xa9\x80", b"\xff", b"\xf8\x80\x80\x80", b"\xe3\x81\x82\x80", b"\xd0\x96", b"\xce\xb4", b"http://", b"\xed\xa0\x80"]
+    odd_chunks = [b"\x80\x80\x80\x80", b"\xf0\x9f\xa4\x93\x80", b"a\x80\x80\x80\x80\x80"]
+    checked = odd_seen = 0
+    for it in range(400):
+        n_str = int(rng.integers(1, 12))
+        blobs = []
+        for _ in range(n_str):
+            k = int(rng.integers(0, [6, 40, 400][it % 3]))
+            parts = [chunks[i] for i in rng.integers(0, len(chunks), k)]
+            if it % 7 == 0 and k:
+                parts[int(rng.integers(0, k))] = odd_chunks[int(rng.integers(0, len(odd_chunks)))]
+            if it % 11 == 0:
+                parts = [b"\x80"] + parts                  # a string that begins with a continuation byte
+            blobs.append(b"".join(parts))
+        lens = np.array([len(x) for x in blobs], np.int64)
+        boff = np.zeros(n_str + 1, np.int64)
+        np.cumsum(lens, out=boff[1:])
+        total = int(boff[-1])
+        if total == 0:
+            continue
+        u8 = np.frombuffer(b"".join(blobs), np.uint8).copy()
+        is_cont = (u8 & 0xC0) == 0x80
+        # odd: a continuation byte at a string start, or behind three other continuation bytes
+        odd = bool(is_cont[boff[:-1][lens > 0]].any())
+        run = is_cont.copy()
+        for k in (1, 2, 3):
+            run[k:] &= is_cont[:-k]
+            run[:k] = False
+        odd = odd or bool(run.any())
+        if odd:
+            odd_seen += 1
+            continue
+        bits = np.zeros((total + 63) // 64, np.uint64)
+        sp = np.zeros_like(bits)
+        assert model.fused_split_batch_utf8(u8.ctypes.data, boff.ctypes.data, n_str, bits.ctypes.data, sp.ctypes.data, None) == 0
+        by_byte = np.unpackbits(bits.view(np.uint8), bitorder="little")[:total].astype(bool)
+        cps, lead = _decode_per_lead(u8)
+        row = np.searchsorted(lead, boff).astype(np.int64)          # leads before every string start
+        vals, cbits, _ = run_model(model, np.ascontiguousarray(cps), row)
+        by_cp = np.unpackbits(cbits.view(np.uint8), bitorder="little")[:cps.size].astype(bool)
+        assert np.array_equal(by_byte[lead], by_cp), (it, u8.tolist() if total < 100 else total)
+        assert not by_byte[is_cont].any()
+        checked += 1
+    assert checked > 250 and odd_seen > 40
+
+
+def test_table_driven_lead_decode_is_the_decoder_rule(model):
+    """lane_math.h lk_lead_hi_lo (the byte-space kernel classifies a multi-byte char from cp >> 7 and cp & 127 computed straight
+    from its bytes, one table entry per lead byte) against the decoder's rule (utf8_decode.h): every lead byte 0xC0..0xFF with
+    every second byte, third / fourth bytes over a set that holds both ends of the continuation range and non-continuation bytes."""
+    model.fused_lead_decode.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+    tail = [0x00, 0x41, 0x7F, 0x80, 0x81, 0x9F, 0xA0, 0xBE, 0xBF, 0xC0, 0xE3, 0xFF]
+    cp = C.c_uint32(0)
+    n = 0
+    for b0 in range(0xC0, 0x100):
+        k = 1 + (b0 >= 0xE0) + (b0 >= 0xF0)          # continuation bytes the lead asks for
+        for b1 in range(256):
+            for b2 in tail:
+                for b3 in tail:
+                    bs = (b0, b1, b2, b3)
+                    bad = model.fused_lead_decode(b0 | b1 << 8 | b2 << 16 | b3 << 24, C.byref(cp))
+                    ok = all((bs[j] & 0xC0) == 0x80 for j in range(1, k + 1))
+                    assert bad == (0 if ok else 1), bs
+                    if ok:
+                        want = b0 & (0x3F >> k)
+                        for j in range(1, k + 1):
+                            want = (want << 6) | (bs[j] & 0x3F)
+                        assert cp.value == want, (bs, hex(cp.value), hex(want))
+                    n += 1
+    assert n == 64 * 256 * 144

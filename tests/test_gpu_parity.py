@@ -718,6 +718,95 @@ def test_utf8_ingest(gpu, oracle):
     assert batch.split_offsets_utf8_csr(np.zeros(0, np.uint8), np.zeros(1, np.int64))[1].size == 0
 
 
+def test_utf8_code_point_mask_without_a_utf32_copy(gpu, oracle):
+    """latok_split_mask_utf8_batch on batches beyond the small-batch size: the byte-space tile kernel + the mask packed at the
+    lead bytes (api.cpp mask_utf8_via_bytes, compact_kernels.hip k_lead_compress) must give what the reference gives for the
+    decoded str (latok.c:53-55,79 reads code points): mask and code-point row offsets against the oracle through the UTF-32 path,
+    host and device pointers, ASCII-only text, empty strings at both ends, a mask buffer that is too small, run-time rule tables.
+    Malformed bytes: whatever the staged decoder's rule (one char per lead byte) gives -- batches the byte-space model treats
+    differently are detected on the device and take the decoder."""
+    from conftest import RULE_SETS, oracle_rule_bits
+    from latok_amd import _lib, batch
+    rng = random.Random(2718)
+    alpha = ALPHABETS["mixed"] + list("é日🤓ü\u3000Жδ") + ["http://é", "a@日", ".@ü", "#日"]
+    sets = [
+        ["", ""] + random_strings(rng, 6000, 0, 120, alpha) + ["", "x", ""],
+        random_strings(rng, 3, 60000, 90000, alpha) + random_strings(rng, 2000, 0, 60, alpha),
+        random_strings(rng, 5000, 0, 150, list("abc XYZ,.#@:/ 19\t")),                     # ASCII only
+        ["日" * 100000, "é" * 70000, "🤓" * 50000, "a" * 3 + "日" * 4093 + " b"],          # long runs, every sequence length
+    ]
+    for i, texts in enumerate(sets):
+        blobs = [t.encode("utf-8", "surrogatepass") for t in texts]
+        u8, boff = batch.pack_utf8(blobs)
+        assert u8.size > 262144
+        cps, row = pack(texts)
+        want = oracle.split_batch(cps, row, want_values=False)[1]
+        got, got_row = batch.split_mask_utf8_csr(u8, boff)
+        assert np.array_equal(got_row, row), i
+        assert np.array_equal(got, want), i
+        # device pointers, the mask buffer exactly as large as the code points need (fewer words than the bytes have)
+        words = (int(row[-1]) + 63) // 64
+        d = {k: gpu.latok_dev_alloc(n + 64) for k, n in (("u8", u8.nbytes), ("boff", boff.nbytes), ("mask", words * 8), ("row", row.nbytes))}
+        try:
+            _lib.check(gpu.latok_memcpy_h2d(d["u8"], u8.ctypes.data, u8.nbytes))
+            _lib.check(gpu.latok_memcpy_h2d(d["boff"], boff.ctypes.data, boff.nbytes))
+            _lib.check(gpu.latok_memset_dev(d["mask"], 0xEE, words * 8))
+            tcp = C.c_int64(0)
+            _lib.check(gpu.latok_split_mask_utf8_batch(d["u8"], d["boff"], len(texts), -1, d["mask"], words, d["row"], C.byref(tcp),
+                                                       _lib.DEVICE_PTRS, None))
+            assert tcp.value == int(row[-1])
+            m2, r2 = np.empty(words, np.uint64), np.empty_like(row)
+            _lib.check(gpu.latok_memcpy_d2h(m2.ctypes.data, d["mask"], m2.nbytes))
+            _lib.check(gpu.latok_memcpy_d2h(r2.ctypes.data, d["row"], r2.nbytes))
+            assert np.array_equal(m2, want) and np.array_equal(r2, row), i
+            if words > 1:      # too small by one word: refused, the needed size is reported
+                rc = gpu.latok_split_mask_utf8_batch(d["u8"], d["boff"], len(texts), -1, d["mask"], words - 1, d["row"], C.byref(tcp),
+                                                     _lib.DEVICE_PTRS, None)
+                assert rc == _lib.ERR_INVALID and b"mask_cap_words" in gpu.latok_last_error() and tcp.value == int(row[-1])
+        finally:
+            for p_ in d.values():
+                gpu.latok_dev_free(p_)
+    # run-time rule tables
+    texts = sets[0]
+    u8, boff = batch.pack_utf8([t.encode("utf-8", "surrogatepass") for t in texts])
+    for name in ("sym_everywhere", "all_columns"):
+        batch.set_rules(*RULE_SETS[name])
+        try:
+            got, _ = batch.split_mask_utf8_csr(u8, boff)
+        finally:
+            batch.reset_rules()
+        assert np.array_equal(got, oracle_rule_bits(oracle, texts, RULE_SETS[name])), name
+    # malformed bytes: strings of chunks (truncated sequences, lone leads, stray continuation bytes ...); every third batch also
+    # holds what the byte-space model treats differently (a run of > 3 continuation bytes, a string that starts with one)
+    chunks = [b"a", b"b", b"Z", b" ", b" ", b".", b"@", b"#", b":", b"/", b"\t", b"1", b"\xc3\xa9", b"\xe3\x81\x82", b"\xe6\x97\xa5",
+              b"\xf0\x9f\xa4\x93", b"\xe3\x80\x80", b"\xe3\x81", b"\xc3", b"\xf0\x9f", b"\xf0\x9f\xa4", b"a\x80", b".\x80", b"@\xbf\x80",
+              b"\xc3\xa9\x80", b"\xff", b"\xf8\x80\x80\x80", b"\xe3\x81\x82\x80", b"\xd0\x96", b"http://", b"\xed\xa0\x80"]
+    odd_chunks = [b"\x80\x80\x80\x80", b"\xf0\x9f\xa4\x93\x80", b"\x80"]
+    for it in range(6):
+        blobs = []
+        for s_ in range(6000):
+            parts = [rng.choice(chunks) for _ in range(rng.randint(0, 60))]
+            if it % 3 == 2 and s_ % 500 == 7:
+                parts.insert(0 if s_ % 1000 == 7 else len(parts) // 2, rng.choice(odd_chunks))
+            blobs.append(b"".join(parts))
+        u8, boff = batch.pack_utf8(blobs)
+        assert u8.size > 262144
+        cps, row = batch.utf8_decode_csr(u8, boff)               # the staged decoder: one code point per lead byte
+        is_lead = (u8 & 0xC0) != 0x80
+        assert cps.size == int(is_lead.sum())
+        got, got_row = batch.split_mask_utf8_csr(u8, boff)
+        assert np.array_equal(got_row, row), it
+        assert np.array_equal(got, batch.split_mask_batch(cps, row)), it
+    # a sequence cut short by the END OF THE BATCH is U+FFFD too (the staged decoder used to complete it with its own padding)
+    for tail in (b"\xc3", b"\xe6\x97", b"\xf0\x9f\xa4", b"x\xf0"):
+        blobs = [b"filler words, a #tag and http://x.y/z "] * 8000 + [b"end " + tail]
+        u8, boff = batch.pack_utf8(blobs)
+        cps, row = batch.utf8_decode_csr(u8, boff)
+        assert cps[-1] == 0xFFFD and row[-1] == cps.size == int(((u8 & 0xC0) != 0x80).sum()), tail
+        got, got_row = batch.split_mask_utf8_csr(u8, boff)
+        assert np.array_equal(got_row, row) and np.array_equal(got, batch.split_mask_batch(cps, row)), tail
+
+
 def test_edge_aligned_patterns(gpu, oracle):
     """Rule triggers, spaces, string starts / ends and empty strings placed exactly around word (64) and tile (4096)
     boundaries of the packed buffer, where the cross-lane / cross-tile carries of the kernel live."""

@@ -32,10 +32,11 @@ for _ in range(10):
 lib.latok_sync()
 raw.latok_diag_stamps(out, 1)
 names = ["tiles", "-", "phase 1 (loads + classify)", "B words (+row_off)", "LDS reads + bitslice + rules",
-         "forward + wave scan", "summary", "backward", "output store", "(share of 4) ds reads", "(share of 4) slicing"]
+         "forward + wave scan", "summary", "backward", "output store", "(share of 4) ds reads", "(share of 4) slicing", "(of phase 1) until the bytes arrive", "(of phase 1) owner before the tile",
+         "(of phase 1) the four rows"]
 tiles = out[0] or 1
 tot = sum(out[i] for i in range(1, 9))
 print(f"byte mode on C3 text, stamped build: {tiles} stamped tiles, {n8 / total:.2f} bytes per char")
-for i in range(1, 11):
+for i in range(1, 14):
     print(f"  {names[i]:34s} {out[i] / tiles:9.0f} clk  {100.0 * out[i] / tot:5.1f} %")
 print(f"  total per tile {tot / tiles:.0f} clk (s_memtime ticks)")

@@ -74,7 +74,188 @@ WORKLOADS = {
     "C5": (_lib.CORPUS_ASCII, 0x1A70C0E0, 1_000_000, 1_000_000, 10_000, "10K documents x 1M chars, split over the ranks (BASELINE configs[4])"),
 }
 SCALING = {"C2": "weak", "C3": "weak", "C4": "strong", "C5": "strong"}
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_summary.json", "r02_pmc_summary.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")]
+
+
+# ---- host-side facts about a GPU, read from sysfs without touching the HIP runtime ------------------------------------------
+def kfd_gpu_nodes(sysfs="/sys"):
+    """The GPUs in KFD topology order (= HIP device order when no *_VISIBLE_DEVICES filter is set): for each the DRM render
+    minor, from which the PCI device directory (NUMA node, local CPUs, clocks, power) is reached."""
+    import glob
+    nodes = []
+    for d in sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")), key=lambda x: int(os.path.basename(x))):
+        props = {}
+        try:
+            with open(os.path.join(d, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0 and "drm_render_minor" in props:
+            nodes.append({"kfd_node": int(os.path.basename(d)), "render_minor": int(props["drm_render_minor"])})
+    return nodes
+
+
+def gpu_device_dir(device, sysfs="/sys"):
+    nodes = kfd_gpu_nodes(sysfs)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis:      # a launcher narrowed the devices: index into its list (numeric entries only)
+        try:
+            order = [int(x) for x in vis.split(",") if x.strip() != ""]
+            nodes = [nodes[i] for i in order if 0 <= i < len(nodes)]
+        except ValueError:
+            return None
+    if device < 0 or device >= len(nodes):
+        return None
+    path = os.path.join(sysfs, "class/drm", "renderD%d" % nodes[device]["render_minor"], "device")
+    return path if os.path.isdir(path) else None
+
+
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def format_cpulist(cpus):
+    out, run = [], []
+    for c in sorted(cpus) + [None]:
+        if run and (c is None or c != run[-1] + 1):
+            out.append(str(run[0]) if len(run) == 1 else "%d-%d" % (run[0], run[-1]))
+            run = []
+        if c is not None:
+            run.append(c)
+    return ",".join(out)
+
+
+def gpu_numa(device, sysfs="/sys"):
+    """{numa_node, cpus} of the PCI device behind HIP device `device` (None when sysfs does not say)."""
+    d = gpu_device_dir(device, sysfs)
+    if not d:
+        return None
+    try:
+        with open(os.path.join(d, "numa_node")) as f:
+            node = int(f.read().strip())
+        with open(os.path.join(d, "local_cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None
+    return {"numa_node": node, "cpus": cpus}
+
+
+def pin_to_gpu_node(device, sysfs="/sys", setaffinity=None, getaffinity=None):
+    """Pin the calling process to the CPUs of the NUMA node its GPU hangs on (a rank issues 3 launches per 0.09 ms step: on a
+    two-socket node a launch thread on the far socket pays the inter-socket hop on every doorbell and every completion poll).
+    Called before the first HIP call, so that the runtime's own threads inherit the mask.  Returns what it did, for the line."""
+    getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
+    setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
+    info = {"device": device, "numa_node": None, "pinned": False}
+    try:
+        allowed = set(getaffinity())
+    except (AttributeError, OSError):
+        return info
+    info["cpus_allowed"] = len(allowed)
+    nm = gpu_numa(device, sysfs)
+    if nm is None:
+        return info
+    info["numa_node"] = nm["numa_node"]
+    want = allowed & nm["cpus"]
+    if nm["numa_node"] < 0 or not want or want == allowed:      # one node, or nothing to narrow
+        return info
+    try:
+        setaffinity(want)
+        info["pinned"] = True
+        info["cpus_allowed"] = len(want)
+        info["cpus"] = format_cpulist(want)
+    except OSError:
+        pass
+    return info
+
+
+def gpu_sensors(device, sysfs="/sys"):
+    """sclk / mclk (MHz, the level marked active in pp_dpm_*), socket power (W) and busy % of a GPU from sysfs; {} when unreadable.
+    Sampled before and after the timed region and during the sustained run: box-to-box and run-to-run differences of the
+    dominant kernel (88-110 us within one profile in round 3) then have a clock next to them."""
+    d = gpu_device_dir(device, sysfs)
+    out = {}
+    if not d:
+        return out
+
+    def active_mhz(name):
+        try:
+            with open(os.path.join(d, name)) as f:
+                lines = f.read().strip().splitlines()
+        except OSError:
+            return None
+        cur = [ln for ln in lines if ln.rstrip().endswith("*")] or lines[-1:]
+        for tok in cur[0].replace("*", " ").split():
+            t = tok.lower()
+            if t.endswith("mhz"):
+                try:
+                    return int(float(t[:-3]))
+                except ValueError:
+                    pass
+        return None
+
+    for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+        v = active_mhz(name)
+        if v is not None:
+            out[key] = v
+    import glob
+    for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+        for name, key, scale in (("power1_average", "power_w", 1e-6), ("power1_input", "power_w", 1e-6), ("temp1_input", "temp_c", 1e-3),
+                                 ("freq1_input", "sclk_hwmon_mhz", 1e-6)):
+            if key in out:
+                continue
+            try:
+                with open(os.path.join(hw, name)) as f:
+                    out[key] = round(int(f.read().strip()) * scale, 1)
+            except (OSError, ValueError):
+                pass
+    try:
+        with open(os.path.join(d, "gpu_busy_percent")) as f:
+            out["busy_pct"] = int(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+class SensorWatch:
+    """polls gpu_sensors from a side thread while a measurement runs (the sustained run: >= 1 s)"""
+
+    def __init__(self, device, period_s=0.1):
+        self.device, self.period, self.samples, self._stop, self._t = device, period_s, [], threading.Event(), None
+
+    def __enter__(self):
+        def loop():
+            while not self._stop.is_set():
+                s = gpu_sensors(self.device)
+                if s:
+                    self.samples.append(s)
+                self._stop.wait(self.period)
+        self._t = threading.Thread(target=loop, name="bench-sensors", daemon=True)
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join()
+        return False
+
+    def summary(self):
+        if not self.samples:
+            return None
+        out = {"samples": len(self.samples)}
+        for k in ("sclk_mhz", "mclk_mhz", "power_w", "temp_c", "sclk_hwmon_mhz"):
+            v = [s[k] for s in self.samples if k in s]
+            if v:
+                out[k] = {"min": min(v), "max": max(v), "mean": round(sum(v) / len(v), 1)}
+        return out
 
 
 def shard_string_ids(n_per_gpu: int, rank: int):
@@ -210,21 +391,30 @@ def cpu_fused_allcores(workload, cps, row, utf8_bytes, repeats=3):
                       f"{tn:.2f} s ({t1:.2f} s on 1 thread)"}
 
 
-def pmc_traffic(workload: str, total_chars: int):
-    """HBM bytes per k_tiles_main launch from the committed PMC passes of the same workload and size (profiles/, collected
-    with rocprofv3 --pmc as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
-    a counter pass cannot run inside this process, so the figure is null for a workload / size that has none."""
+def pmc_traffic(workload: str, total_chars: int, in_flight: int):
+    """(HBM bytes per k_tiles_main launch, where the figure comes from) out of the committed PMC passes of the same workload, size
+    AND launch scheme (profiles/, collected with rocprofv3 --pmc as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE
+    passes, gfx950 corrections); a counter pass cannot run inside this process, so the figure is null for a workload / size that
+    has none.  A pass of the same scheme (batches in flight) is preferred; one of the other scheme is named as such."""
+    best = None
     for path in PMC_SUMMARIES:
         try:
             with open(path) as f:
                 pmc = json.load(f)
-            for rec in pmc.get("runs", []):
-                if (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
-                        and rec.get("total_chars") == total_chars):
-                    return rec.get("hbm_bytes_per_launch")
         except Exception:
-            pass
-    return None
+            continue
+        for rec in pmc.get("runs", []):
+            if not (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
+                    and rec.get("total_chars") == total_chars):
+                continue
+            same = int(rec.get("in_flight", 1)) == in_flight
+            src = {"file": os.path.relpath(path, ROOT), "command": rec.get("command", "python3 bench.py --workload %s --in-flight 1" % workload),
+                   "in_flight": int(rec.get("in_flight", 1)), "distinct_inputs": rec.get("distinct_inputs"),
+                   "same_launch_scheme_as_this_line": same, "launches_averaged": rec.get("launches")}
+            if same:
+                return rec.get("hbm_bytes_per_launch"), src
+            best = best or (rec.get("hbm_bytes_per_launch"), src)
+    return best if best else (None, None)
 
 
 class RealApi:
@@ -251,16 +441,17 @@ class Shard:
     """One rank's work: an independent contiguous string-id range of the corpus, resident in ITS device's HBM.  Every
     method must run on the host thread whose current context is the rank's (in-process mode: the rank's own thread)."""
 
-    def __init__(self, api, args, rank, world):
-        self.api, self.lib, self.args, self.rank, self.world = api, api.lib, args, rank, world
+    def __init__(self, api, args, rank, world, device=0):
+        self.api, self.lib, self.args, self.rank, self.world, self.device = api, api.lib, args, rank, world, device
         model, seed, lo, hi, n_default, _ = WORKLOADS[args.workload]
         if SCALING[args.workload] == "weak":
             self.sid0, self.n_str = shard_string_ids(args.strings or n_default, rank)
         else:
             self.sid0, self.n_str = split_string_ids(args.strings or n_default, rank, world)
         self.total = self.utf8 = 0
-        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = None
+        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = self.d_row2 = self.d_cps2 = None
         self.flow = args.in_flight >= 2     # (0 = decided in build() by the size of the rank's batch)
+        self.distinct = False
 
     def build(self):
         """the shard directly in HBM: offsets on the host (8 B/string), code points generated on the device"""
@@ -286,6 +477,17 @@ class Shard:
         chk(lib.latok_utf8_bytes(self.d_cps, self.total, C.byref(u), _lib.DEVICE_PTRS))
         self.utf8 = int(u.value)
         chk(lib.latok_reserve(self.total, self.n_str))
+        if self.flow and not self.args.shared_input:
+            # the two batches in flight read two COPIES of the shard at different addresses (as two different batches would):
+            # nothing one batch fetched can be an L2 / MALL hit for the other
+            self.d_row2 = lib.latok_dev_alloc(row.nbytes)
+            self.d_cps2 = lib.latok_dev_alloc(self.total * 4)
+            if not (self.d_row2 and self.d_cps2):
+                raise RuntimeError(self.api.last_error())
+            chk(lib.latok_memcpy_h2d(self.d_row2, row.ctypes.data, row.nbytes))
+            chk(lib.latok_corpus_fill_device(seed, model, self.sid0, self.n_str, self.d_row2, self.d_cps2, None))
+            chk(lib.latok_bench_set_second_input(self.d_cps2, self.d_row2))
+            self.distinct = True
 
     def warmup(self, n):
         if n > 0:
@@ -387,10 +589,13 @@ class Shard:
         return nbytes / (ms.value / 20 / 1e3) / 1e9 if ms.value > 0 else None
 
     def free(self):
-        for p in (self.d_row, self.d_cps, self.d_bits, self.d_bits2):
+        if self.distinct:
+            self.lib.latok_bench_set_second_input(None, None)
+            self.distinct = False
+        for p in (self.d_row, self.d_cps, self.d_bits, self.d_bits2, self.d_row2, self.d_cps2):
             if p:
                 self.lib.latok_dev_free(p)
-        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = None
+        self.d_row = self.d_cps = self.d_bits = self.d_bits2 = self.d_row2 = self.d_cps2 = None
 
     def alg_read(self):
         return 4 * self.total + 8 * (self.n_str + 1)   # 4 B/code point + 8 B/string row offset
@@ -406,8 +611,11 @@ def measure_shard(sh, args, gate, phase):
     sh.warmup_flow(args.warmup)
     n_settle = sh.settle(args.settle_s)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
+    dev = getattr(sh, "device", 0)
+    sens_before = gpu_sensors(dev)
     with phase():
         rec = sh.timed(args.steps, None if args.take_turns else gate)
+    rec["sensors"] = {"before_timed_region": sens_before, "after_timed_region": gpu_sensors(dev)}
     serial = None
     if sh.flow:   # the same K steps one batch at a time (what `value` was before the batch flow), beside the headline
         chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
@@ -421,11 +629,13 @@ def measure_shard(sh, args, gate, phase):
     with phase():
         rec["kernel_flow_ms"] = sh.kernel_in_flow(args.steps)
     rec.update(rank=sh.rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
-               sustained=None, measured_read=None)
+               sustained=None, measured_read=None, distinct_inputs=sh.distinct, flow=sh.flow)
     chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
     if sh.rank == 0:   # outside the timed region, the other ranks are done
         if args.sustain_s > 0 and rec["ms_events"] > 0:
-            rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+            with SensorWatch(dev) as watch:
+                rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+            rec["sensors"]["during_sustained_run"] = watch.summary()
         rec["measured_read"] = sh.stream_read()
     sh.free()
     return rec
@@ -455,9 +665,11 @@ def run_in_process(api, args, devices):
     def body(rank):
         ctx = None
         try:
+            pin = pin_to_gpu_node(devices[rank]) if args.pin else {"device": devices[rank], "numa_node": None, "pinned": False}
             ctx = api.context(devices[rank])
             ctx.make_current()
-            results[rank] = measure_shard(Shard(api, args, rank, world), args, gate, phase)
+            results[rank] = measure_shard(Shard(api, args, rank, world, devices[rank]), args, gate, phase)
+            results[rank]["host"] = pin
         except BaseException as exc:
             errors.append((rank, exc))
             api.lib.latok_gate_break(gate)   # the other ranks fail at their next wait instead of sitting out the timeout
@@ -487,8 +699,9 @@ def run_under_launcher(api, args, rank, world, local_rank):
     the per-rank records only -- gloo by default (nothing here needs RCCL: no collective on the data path)."""
     import torch.distributed as dist
     tdev = None   # the reductions run on host tensors
-    n_dev = max(1, api.device_count())
+    n_dev = max(1, len(kfd_gpu_nodes()) or 1) if args.device < 0 and args.pin else max(1, api.device_count())
     device = args.device if args.device >= 0 else local_rank % n_dev   # a launcher may narrow HIP_VISIBLE_DEVICES per rank
+    pin = pin_to_gpu_node(device) if args.pin else {"device": device, "numa_node": None, "pinned": False}   # (before the first HIP call below)
     dist.init_process_group(backend="gloo")
 
     class _Barrier:
@@ -509,14 +722,17 @@ def run_under_launcher(api, args, rank, world, local_rank):
     ctx = api.context(device)
     ctx.make_current()
     try:
-        sh = Shard(api, args, rank, world)
+        sh = Shard(api, args, rank, world, device)
         sh.build()
         sh.warmup(args.warmup)
         sh.warmup_flow(args.warmup)
         n_settle = sh.settle(args.settle_s)
         dist.barrier()
+        sens_before = gpu_sensors(device)
         with _Barrier("timed"):
             rec = sh.timed(args.steps, None)
+        rec["sensors"] = {"before_timed_region": sens_before, "after_timed_region": gpu_sensors(device)}
+        rec["host"] = pin
         serial = None
         if sh.flow:
             dist.barrier()
@@ -530,11 +746,13 @@ def run_under_launcher(api, args, rank, world, local_rank):
         with _Barrier("kernel-flow"):
             rec["kernel_flow_ms"] = sh.kernel_in_flow(args.steps)
         rec.update(rank=rank, n_str=sh.n_str, total=sh.total, utf8=sh.utf8, alg_read=sh.alg_read(), kernel_ms=k_ms, n_fix=n_fix,
-                   sustained=None, measured_read=None)
+                   sustained=None, measured_read=None, distinct_inputs=sh.distinct, flow=sh.flow)
         dist.barrier()
         if rank == 0:
             if args.sustain_s > 0 and rec["ms_events"] > 0:
-                rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+                with SensorWatch(device) as watch:
+                    rec["sustained"] = sh.sustained(args.sustain_s, rec["ms_events"] / args.steps)
+                rec["sensors"]["during_sustained_run"] = watch.summary()
             rec["measured_read"] = sh.stream_read()
         sh.free()
         gathered = [None] * world
@@ -572,6 +790,7 @@ def build_line(args, recs, mode, devices, same_start):
                   "ms_per_rank": [x["ms_events"] / K for x in sr],
                   "what": "the same K steps with ONE batch in flight (index -> tiles -> resolve back to back on one stream): "
                           "`value` of rounds 1-3 before the batch flow"}
+    traffic, traffic_src = pmc_traffic(args.workload, recs[0]["total"], 2 if flow else 1)
     fracs = [r["alg_read"] / (r["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs]
     worst = min(range(world), key=lambda i: fracs[i])
     r0 = recs[0]
@@ -581,6 +800,9 @@ def build_line(args, recs, mode, devices, same_start):
         "metric": "input UTF-8 GB/s tokenized (fused feature+split-mask path)",
         "value": value, "unit": "GB/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "warmup_effective": {"passes_rank0": args.warmup * (2 if flow else 1) + (r0.get("settle_steps") or 0),
+                             "what": "every untimed pass before the timed region on rank 0: W one-batch passes" +
+                                     (" + W passes through the flow" if flow else "") + " + the settle passes below (`warmup` is the flag's value)"},
         "warmup_settle": {"seconds": args.settle_s, "steps_rank0": r0.get("settle_steps"),
                           "why": "after the W warm-up steps, untimed passes until the GPU has been under load for this long: a GPU that "
                                  "idled while the shard was built reaches its steady clocks only after tens of ms (outside the timed region)"},
@@ -593,9 +815,13 @@ def build_line(args, recs, mode, devices, same_start):
                    "sharding": f"{world} x independent contiguous string-id shards, no collective on the data path",
                    "launch": mode, "devices": devices},
         "in_flight": 2 if flow else 1,
+        "distinct_inputs": bool(flow and all(r.get("distinct_inputs") for r in recs)),
+        "ranks": [{"rank": r["rank"], **(r.get("host") or {})} for r in recs],
+        "sensors_rank0": r0.get("sensors"),
         "in_flight_note": ("batch flow (latok_flow_split_mask): step i+1 is submitted while step i runs, on a second stream with its own "
                            "workspace and its own output bitmask; every step launches all three kernels and is complete when the "
-                           "clock stops; `serial` = the same K steps one at a time") if flow else "one batch at a time",
+                           "clock stops; with `distinct_inputs` the odd steps read a second copy of the shard at another address, so the two "
+                           "batches in flight share no input lines in L2 / MALL; `serial` = the same K steps one at a time") if flow else "one batch at a time",
         "serial": serial,
         "timing": ("host monotonic clock, inputs resident in HBM: every rank's region = [gate ->] clock -> K pipeline passes -> "
                    "stream(s) synchronise -> clock inside one library call; value = bytes of all ranks x K / "
@@ -611,7 +837,7 @@ def build_line(args, recs, mode, devices, same_start):
         "sustained": r0["sustained"],
         "fix_tiles_rank0": r0["n_fix"], "tiles_rank0": (r0["total"] + _lib.TILE_CHARS - 1) // _lib.TILE_CHARS,
         "roofline": {"bound": "hbm", "kernel": "k_tiles_main", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": fracs[worst], "traffic": pmc_traffic(args.workload, recs[worst]["total"]),
+                     "unit": "GB/s", "frac": fracs[worst], "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": recs[worst]["alg_read"], "kernel_ms": recs[worst]["kernel_ms"],
                      "kernel_timing": f"{K} back-to-back launches between one HIP event pair on the launch stream, per rank; "
                                       "frac / achieved = the SLOWEST rank's",
@@ -676,6 +902,11 @@ def parse_args(argv=None):
                          "shards of C4 / C5 from 4 / 3 GPUs on), 1 for N > 1 host threads in one process (--launch threads)")
     ap.add_argument("--settle-s", type=float, default=0.05,
                     help="untimed passes after the W warm-up steps until the GPU has been busy this long (clock settling; 0 = off)")
+    ap.add_argument("--shared-input", action="store_true",
+                    help="batch flow: both batches in flight read the SAME input buffer (rounds 3's form); default: each slot reads "
+                         "its own copy of the shard at another address")
+    ap.add_argument("--no-pin", dest="pin", action="store_false",
+                    help="do not pin a rank to the CPUs of its GPU's NUMA node (default: pinned, before the first HIP call)")
     ap.add_argument("--take-turns", action="store_true",
                     help="rehearsal on shared GPU(s): the ranks run their timed regions one after the other, so each rank's "
                          "time is what a GPU of its own would give; the line is marked as a rehearsal and carries no `value`")
@@ -728,6 +959,8 @@ def child_main(args, api):
     record goes to stdout as one line for the parent."""
     rank, world = args.child_rank, args.gpus
     devices = [int(x) for x in args.devices.split(",")]
+    # first of all, before anything can start the HIP runtime (and its helper threads): onto the cores next to this rank's GPU
+    pin = pin_to_gpu_node(devices[rank]) if args.pin else {"device": devices[rank], "numa_node": None, "pinned": False}
     lib = api.lib
     gate = C.c_void_p()
     name = args.child_gate.encode()
@@ -747,7 +980,8 @@ def child_main(args, api):
         ctx = api.context(devices[rank])
         ctx.make_current()
         phase = (lambda: _FileLock(args.child_lock)) if args.take_turns else _NoLock
-        rec = measure_shard(Shard(api, args, rank, world), args, gate, phase)
+        rec = measure_shard(Shard(api, args, rank, world, devices[rank]), args, gate, phase)
+        rec["host"] = pin
         lib.latok_ctx_set_current(None)
         ctx.destroy()
         print("LATOK_BENCH_REC " + json.dumps(rec), flush=True)
@@ -759,7 +993,7 @@ def child_main(args, api):
         lib.latok_gate_detach_shared(gate)
 
 
-def run_processes(args, devices, argv, spawn=None):
+def run_processes(args, devices, argv):
     """N > 1 without a launcher, one child process per GPU.  The parent has NOT touched a GPU (nor loaded the library) when
     it spawns them -- a process that has initialised the GPU must not start other programs on this pool -- and never does
     afterwards either, except for host-only calls (CPU baseline, unlinking the gate)."""
@@ -773,16 +1007,28 @@ def run_processes(args, devices, argv, spawn=None):
     cmd0 = [sys.executable, os.path.abspath(__file__)] + base + ["--devices", ",".join(map(str, devices)), "--child-gate", gate_name,
                                                                    "--child-lock", lock.name, "--no-cpu-baseline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    spawn = spawn or (lambda cmd: subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
-    procs = [spawn(cmd0 + ["--child-rank", str(r)]) for r in range(world)]
+    # Every child writes into FILES of its own: with pipes drained one child after the other, a rank that fills its pipe (HIP
+    # warnings, AMD_LOG_LEVEL, a long traceback) blocks in write() before it reaches the gate and takes every other rank into
+    # the gate's timeout, with a misleading "gate" error on top.
+    files = [(tempfile.TemporaryFile(mode="w+", prefix="latok_bench_out_"), tempfile.TemporaryFile(mode="w+", prefix="latok_bench_err_"))
+             for _ in range(world)]
+    procs = [subprocess.Popen(cmd0 + ["--child-rank", str(r)], stdout=files[r][0], stderr=files[r][1], text=True, env=env)
+             for r in range(world)]
     outs, deadline = [], time.time() + CHILD_TIMEOUT_S
-    for p in procs:
+    for r, p in enumerate(procs):
+        note = ""
         try:
-            outs.append(p.communicate(timeout=max(1.0, deadline - time.time())))
+            p.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
             p.kill()                       # (this child, by its own handle: never by pattern)
-            so, se = p.communicate()
-            outs.append((so, (se or "") + f"\nbench.py: rank killed after {CHILD_TIMEOUT_S:.0f} s"))
+            p.wait()
+            note = f"\nbench.py: rank killed after {CHILD_TIMEOUT_S:.0f} s"
+        texts = []
+        for f in files[r]:
+            f.seek(0)
+            texts.append(f.read())
+            f.close()
+        outs.append((texts[0], texts[1] + note))
     try:
         os.unlink(lock.name)
     except OSError:

@@ -360,6 +360,11 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
                                       uint64_t* mask_a_dev, uint64_t* mask_b_dev, int iters, latok_gate* gate,
                                       float* ms_events_out, int64_t* t0_ns_out, int64_t* t1_ns_out);
 
+/* A second, equal copy of the batch at another address for the two flow measurements (this one and latok_bench_tiles_flow): the
+ * odd steps then read cps_b_dev / row_off_b_dev instead, so that the two batches in flight share no input lines in L2 / MALL -- as
+ * two different batches of a real flow would not.  NULL, NULL: back to one shared input.  State of the current context. */
+int latok_bench_set_second_input(const uint32_t* cps_b_dev, const int64_t* row_off_b_dev);
+
 /* The dominant kernel alone in the flow's launch scheme: `iters` launches of k_tiles_main (planned for 7/8 of the CUs, as every
  * batch of a flow is) alternating between the two slot streams, nothing else launched; ms_out = host wall time from the first
  * launch to the end of the last (streams polled).  The launches overlap, so ms_out / iters is the kernel's average cost per

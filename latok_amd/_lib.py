@@ -83,6 +83,7 @@ SIGNATURES = {
     "latok_gate_detach_shared": (ci, [vp]),
     "latok_gate_unlink_shared": (ci, [C.c_char_p]),
     "latok_bench_split_mask_gated": (ci, [vp, vp, i64, i64, vp, ci, vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)]),
+    "latok_bench_set_second_input": (ci, [vp, vp]),
     "latok_bench_tiles_flow": (ci, [vp, vp, i64, i64, vp, vp, ci, C.POINTER(C.c_float)]),
     "latok_flow_split_mask": (ci, [vp, vp, i64, i64, vp]),
     "latok_flow_split_mask_kind": (ci, [vp, ci, vp, i64, i64, vp]),

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -196,6 +197,8 @@ struct Ctx {
     bool flow_ready = false;
     unsigned long long flow_seq = 0;     // batches submitted so far
     latok::FlowHazards flow_held;        // memory ranges of the batches in flight, per slot (flow_hazards.h)
+    const uint32_t* bench_cps_b = nullptr;   // latok_bench_set_second_input: what the odd steps of the flow measurements read
+    const int64_t* bench_row_b = nullptr;
     hipEvent_t turn_event = nullptr;     // recorded behind the last kernel of every call (StreamTurn)
     hipStream_t turn_stream = nullptr;
     bool turn_stream_valid = false;
@@ -518,6 +521,8 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
         f.chain_ready = false;
     }
     g.flow_held.clear();
+    g.bench_cps_b = nullptr;
+    g.bench_row_b = nullptr;
     g.flow_ready = false;
     g.flow_seq = 0;
     if (g.s_h2d) (void)hipStreamDestroy(g.s_h2d);
@@ -2345,7 +2350,9 @@ struct latok_gate {
     std::atomic<int> arrived{0};
     std::atomic<unsigned> phase{0};
     std::atomic<bool> broken{false};
+    std::atomic<unsigned> ready{0};      // shared gates: kGateReady once the creator has finished setting the object up
 };
+constexpr unsigned kGateReady = 0x6A7E0001u;
 extern "C" {
 
 int latok_gate_create(int parties, latok_gate** gate_out) {
@@ -2369,11 +2376,30 @@ static int gate_map_shared(const char* name, bool create, int parties, latok_gat
         shm_unlink(name);
         return fail(LATOK_ERR_NOMEM, "gate: ftruncate failed: %s", strerror(errno));
     }
+    if (!create) {
+        // the creator may be between shm_open and ftruncate (a zero-length object: touching the mapping would be SIGBUS) or
+        // before its placement-new: attach only to an object of full size whose `ready` word says it is set up
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size < (off_t)sizeof(latok_gate)) {
+            close(fd);
+            return fail(LATOK_ERR_INVALID, "gate: %s is not ready yet", name);
+        }
+    }
     void* p = mmap(nullptr, sizeof(latok_gate), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (p == MAP_FAILED) return fail(LATOK_ERR_NOMEM, "gate: mmap failed: %s", strerror(errno));
-    latok_gate* g = create ? new (p) latok_gate : reinterpret_cast<latok_gate*>(p);
-    if (create) g->parties = parties;
+    latok_gate* g;
+    if (create) {
+        g = new (p) latok_gate;
+        g->parties = parties;
+        g->ready.store(kGateReady, std::memory_order_release);      // last: everything above is visible to whoever sees it
+    } else {
+        g = reinterpret_cast<latok_gate*>(p);
+        if (g->ready.load(std::memory_order_acquire) != kGateReady) {
+            munmap(p, sizeof(latok_gate));
+            return fail(LATOK_ERR_INVALID, "gate: %s is not ready yet", name);
+        }
+    }
     *gate_out = g;
     return LATOK_OK;
 }
@@ -2514,8 +2540,12 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
     const int64_t t0 = mono_ns();
     HIP_TRY(hipEventRecord(g.ev[0], g.flow[g.flow_seq % (unsigned)g.flow_slots].st));   // the stream of the first submission
     int last_slot = 0;
+    const uint32_t* cps_b = g.bench_cps_b ? g.bench_cps_b : cps_dev;     // (latok_bench_set_second_input: a copy at another address)
+    const int64_t* row_b = g.bench_row_b ? g.bench_row_b : row_off_dev;
     for (int i = 0; i < iters; ++i)
-        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev, &last_slot))) break;
+        if ((rc = flow_submit(g, (i & 1) ? cps_b : cps_dev, 4, (i & 1) ? row_b : row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev,
+                              &last_slot)))
+            break;
     if (!rc) {
         hipError_t e = hipEventRecord(g.ev[1], g.flow[last_slot].st);   // ... of the last one
         if (e != hipSuccess) rc = fail(LATOK_ERR_HIP, "timed region failed: %s", hipGetErrorString(e));
@@ -2534,6 +2564,15 @@ int latok_bench_split_mask_flow_gated(const uint32_t* cps_dev, const int64_t* ro
     return LATOK_OK;
 }
 
+int latok_bench_set_second_input(const uint32_t* cps_b_dev, const int64_t* row_off_b_dev) {
+    LATOK_ENTER();
+    if ((cps_b_dev == nullptr) != (row_off_b_dev == nullptr)) return fail(LATOK_ERR_INVALID, "both pointers or neither");
+    if (((uintptr_t)cps_b_dev & 15) != 0) return fail(LATOK_ERR_INVALID, "device cps pointer must be 16-byte aligned");
+    g.bench_cps_b = cps_b_dev;
+    g.bench_row_b = row_off_b_dev;
+    return LATOK_OK;
+}
+
 int latok_bench_tiles_flow(const uint32_t* cps_dev, const int64_t* row_off_dev, int64_t n_str, int64_t total, uint64_t* mask_a_dev,
                            uint64_t* mask_b_dev, int iters, float* ms_out) {
     LATOK_ENTER();
@@ -2543,14 +2582,18 @@ int latok_bench_tiles_flow(const uint32_t* cps_dev, const int64_t* row_off_dev, 
     if ((rc = resolve_total_device(row_off_dev, n_str, &total, g.stream))) return rc;
     if (total <= 0) { *ms_out = 0.f; return LATOK_OK; }
     // one whole pass per slot first: workspaces sized, the per-tile string index of the batch in place in BOTH slots
+    const uint32_t* cps_b = g.bench_cps_b ? g.bench_cps_b : cps_dev;
+    const int64_t* row_b = g.bench_row_b ? g.bench_row_b : row_off_dev;
+    int slot_of[2] = {0, 1};
     for (int i = 0; i < 2; ++i)
-        if ((rc = flow_submit(g, cps_dev, 4, row_off_dev, n_str, total, i ? mask_b_dev : mask_a_dev))) return rc;
+        if ((rc = flow_submit(g, i ? cps_b : cps_dev, 4, i ? row_b : row_off_dev, n_str, total, i ? mask_b_dev : mask_a_dev, &slot_of[i]))) return rc;
     if ((rc = flow_drain(g))) return rc;
     const int64_t t0 = mono_ns();
     for (int i = 0; i < iters && !rc; ++i) {
-        Ctx::FlowSlot& f = g.flow[i % g.flow_slots];
-        rc = run_pipeline(g, cps_dev, row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev, nullptr, latok::kModeBits, f.st, nullptr, nullptr,
-                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, &f);
+        Ctx::FlowSlot& f = g.flow[slot_of[i & 1]];
+        rc = run_pipeline(g, (i & 1) ? cps_b : cps_dev, (i & 1) ? row_b : row_off_dev, n_str, total, (i & 1) ? mask_b_dev : mask_a_dev, nullptr,
+                          latok::kModeBits, f.st, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, nullptr,
+                          latok::DoneSignal{nullptr, 0, nullptr}, &f);
     }
     const int rc_drain = flow_drain(g);
     const int64_t t1 = mono_ns();

@@ -36,6 +36,7 @@ class FakeLib:
         self.timed = []                      # (device, thread, t0, t1) of the headline region of every rank
         self.timed_serial = []               # ... of the `serial` region behind it (batch flow on)
         self.flow_calls = 0
+        self.second_inputs = []              # (device, cps_b, row_b) of every latok_bench_set_second_input
 
     def __getattr__(self, name):            # gate functions, corpus offsets: the real thing
         return getattr(self.real, name)
@@ -116,6 +117,11 @@ class FakeLib:
             self.flow_calls += 1
         return self._region(iters, gate, ms, t0, t1, self.timed)
 
+    def latok_bench_set_second_input(self, cps_b, row_b):
+        with self.lock:
+            self.second_inputs.append((self._dev(), cps_b, row_b))
+        return 0
+
     def latok_bench_tiles_flow(self, cps, row, n_str, total, bits_a, bits_b, iters, ms):
         ms._obj.value = 0.8 * self.ms_per_pass * iters
         return 0
@@ -183,8 +189,15 @@ def test_in_process_launch_runs_every_rank_on_its_own_context(n, monkeypatch):
     assert len({c.thread for c in api.contexts}) == n and all(c.destroyed for c in api.contexts)
     assert not api.lib.live
     # disjoint contiguous shards of the corpus: rank r owns string ids [r * 2000, (r + 1) * 2000) on device r
-    assert sorted(api.lib.fills) == [(r, r * 2000, 2000) for r in range(n)]
+    # (filled twice: the two batches in flight read two copies of the shard at different addresses, installed and removed again)
+    assert sorted(api.lib.fills) == sorted([(r, r * 2000, 2000) for r in range(n)] * 2)
+    assert line["distinct_inputs"] is True
+    for r in range(n):
+        mine = [x for x in api.lib.second_inputs if x[0] == r]
+        assert len(mine) == 2 and mine[0][1] and mine[0][2] and mine[0][1] != mine[0][2] and mine[1][1:] == (None, None)
     assert line["config"]["strings_total"] == 2000 * n and line["config"]["strings_per_gpu"] == 2000
+    assert line["warmup_effective"]["passes_rank0"] == 2 and [x["rank"] for x in line["ranks"]] == list(range(n))
+    assert line["roofline"]["traffic_source"] is None or "file" in line["roofline"]["traffic_source"]
     # the gate: all timed regions overlap (started together), so the job took about one rank's time, not n of them
     t0s, t1s = [t[2] for t in api.lib.timed], [t[3] for t in api.lib.timed]
     assert max(t0s) < min(t1s)
@@ -224,7 +237,7 @@ def test_strong_scaling_workload_cuts_the_whole_batch(monkeypatch):
     api = FakeApi(n_dev=4)
     line = _run(["--gpus", "4", "--workload", "C4", "--steps", "2", "--warmup", "0", "--strings", "1001", "--no-cpu-baseline",
                  "--sustain-s", "0"], api)
-    fills = sorted(api.lib.fills, key=lambda f: f[1])
+    fills = sorted(set(api.lib.fills), key=lambda f: f[1])      # (each shard is filled twice: the flow's two input copies)
     assert fills[0][1] == 0 and sum(f[2] for f in fills) == 1001
     assert all(fills[i][1] + fills[i][2] == fills[i + 1][1] for i in range(3))
     assert line["scaling"] == "strong" and line["config"]["strings_total"] == 1001
@@ -320,3 +333,72 @@ def test_process_per_gpu_take_turns_and_failure():
     p = _run_procs(["--gpus", "2", "--devices", "0,11"])
     assert p.returncode != 0 and "rank 1 (device 11)" in p.stderr and "not present" in p.stderr
     assert time.time() - t < 60
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: list of (kfd node, render minor, numa node, local cpulist); plus one CPU-only KFD node in front (as on real hosts)"""
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+    put(os.path.join(root, "class/kfd/kfd/topology/nodes/0/properties"), "cpu_cores_count 96\nsimd_count 0\ndrm_render_minor 0\n")
+    for node, minor, numa, cpus in gpus:
+        put(os.path.join(root, f"class/kfd/kfd/topology/nodes/{node}/properties"), f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {minor}\n")
+        dev = os.path.join(root, f"class/drm/renderD{minor}/device")
+        put(os.path.join(dev, "numa_node"), f"{numa}\n")
+        put(os.path.join(dev, "local_cpulist"), cpus + "\n")
+        put(os.path.join(dev, "pp_dpm_sclk"), "0: 132Mhz\n1: 2100Mhz *\n2: 2400Mhz\n")
+        put(os.path.join(dev, "pp_dpm_mclk"), "0: 900Mhz\n1: 2000Mhz *\n")
+        put(os.path.join(dev, "hwmon/hwmon3/power1_average"), "612000000\n")
+        put(os.path.join(dev, "gpu_busy_percent"), "97\n")
+
+
+def test_rank_is_pinned_to_the_cpus_of_its_gpus_numa_node(tmp_path, monkeypatch):
+    """bench.pin_to_gpu_node: HIP device -> KFD topology order -> DRM render node -> numa_node / local_cpulist, all from sysfs (no
+    HIP call: the pin happens before the runtime starts), on a fake two-socket host with 8 GPUs."""
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    root = str(tmp_path)
+    gpus = [(2 + i, 128 + i, 0 if i < 4 else 1, "0-47,96-143" if i < 4 else "48-95,144-191") for i in range(8)]
+    _fake_sysfs(root, gpus)
+    assert [g["render_minor"] for g in bench.kfd_gpu_nodes(root)] == [128 + i for i in range(8)]
+    everything = set(range(192))
+    for dev in range(8):
+        got = {}
+        info = bench.pin_to_gpu_node(dev, sysfs=root, setaffinity=lambda cpus: got.update(cpus=set(cpus)), getaffinity=lambda: everything)
+        want = set(range(0, 48)) | set(range(96, 144)) if dev < 4 else set(range(48, 96)) | set(range(144, 192))
+        assert info["pinned"] and info["numa_node"] == (0 if dev < 4 else 1) and info["cpus_allowed"] == 96 and got["cpus"] == want
+    # a cgroup that already narrowed the CPUs: only the intersection; nothing left of it: no pin
+    got = {}
+    info = bench.pin_to_gpu_node(5, sysfs=root, setaffinity=lambda cpus: got.update(cpus=set(cpus)), getaffinity=lambda: set(range(40, 56)))
+    assert info["pinned"] and got["cpus"] == set(range(48, 56)) and info["cpus"] == "48-55"
+    info = bench.pin_to_gpu_node(5, sysfs=root, setaffinity=lambda cpus: got.update(bad=True), getaffinity=lambda: set(range(0, 16)))
+    assert not info["pinned"] and "bad" not in got and info["numa_node"] == 1
+    # one NUMA node (or numa_node = -1), a device sysfs does not know, a launcher's HIP_VISIBLE_DEVICES
+    _fake_sysfs(root + "/one", [(1, 128, -1, "0-15")])
+    assert not bench.pin_to_gpu_node(0, sysfs=root + "/one", setaffinity=lambda c: got.update(bad=True), getaffinity=lambda: set(range(16)))["pinned"]
+    assert bench.pin_to_gpu_node(9, sysfs=root, setaffinity=lambda c: got.update(bad=True), getaffinity=lambda: everything)["numa_node"] is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,1")
+    assert bench.pin_to_gpu_node(0, sysfs=root, setaffinity=lambda c: None, getaffinity=lambda: everything)["numa_node"] == 1
+    assert bench.pin_to_gpu_node(1, sysfs=root, setaffinity=lambda c: None, getaffinity=lambda: everything)["numa_node"] == 0
+    assert "bad" not in got
+    # the clocks / power sample of the same device
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    s = bench.gpu_sensors(3, sysfs=root)
+    assert s == {"sclk_mhz": 2100, "mclk_mhz": 2000, "power_w": 612.0, "busy_pct": 97}
+    assert bench.gpu_sensors(0, sysfs=str(tmp_path / "nothing")) == {}
+
+
+def test_bench_line_names_numa_node_and_sensors_of_every_rank(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = []
+    monkeypatch.setattr(bench, "pin_to_gpu_node", lambda device, **kw: seen.append(device) or {"device": device, "numa_node": device // 4, "pinned": True,
+                                                                                                    "cpus_allowed": 96})
+    monkeypatch.setattr(bench, "gpu_sensors", lambda device, **kw: {"sclk_mhz": 2400 - device, "mclk_mhz": 2000, "power_w": 600.0})
+    line = _run(["--gpus", "8"] + BASE, FakeApi(n_dev=8))
+    assert sorted(seen) == list(range(8))
+    assert [(x["rank"], x["device"], x["numa_node"], x["pinned"]) for x in line["ranks"]] == [(r, r, r // 4, True) for r in range(8)]
+    assert line["sensors_rank0"]["before_timed_region"]["sclk_mhz"] == 2400 and line["sensors_rank0"]["after_timed_region"]["power_w"] == 600.0
+    seen.clear()
+    line = _run(["--gpus", "2", "--no-pin"] + BASE, FakeApi(n_dev=2))
+    assert seen == [] and [x["pinned"] for x in line["ranks"]] == [False, False]

@@ -130,7 +130,7 @@ def test_two_rank_gloo_bench_main_under_a_launcher(take_turns):
     assert rc0 == rc1 == 0 and out1.strip() == ""          # ONE line, from rank 0
     line = json.loads(out0)
     assert dev0 == dev1 == [0]                              # LOCAL_RANK mod visible device count
-    assert fills0 == [(0, 0, 1500)] and fills1 == [(0, 1500, 1500)]
+    assert sorted(set(fills0)) == [(0, 0, 1500)] and sorted(set(fills1)) == [(0, 1500, 1500)]   # (twice each: the flow reads two copies)
     assert line["n_gpus"] == 2 and line["config"]["strings_total"] == 3000 and len(line["ms_per_rank"]) == 2
     assert "launcher" in line["config"]["launch"]
     (a0, b0), (a1, b1) = timed0[0][2:], timed1[0][2:]       # CLOCK_MONOTONIC is one clock for every process of the host

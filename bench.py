@@ -391,12 +391,13 @@ def cpu_fused_allcores(workload, cps, row, utf8_bytes, repeats=3):
                       f"{tn:.2f} s ({t1:.2f} s on 1 thread)"}
 
 
-def pmc_traffic(workload: str, total_chars: int, in_flight: int):
+def pmc_traffic(workload: str, total_chars: int, in_flight: int, distinct: bool):
     """(HBM bytes per k_tiles_main launch, where the figure comes from) out of the committed PMC passes of the same workload, size
     AND launch scheme (profiles/, collected with rocprofv3 --pmc as MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE
     passes, gfx950 corrections); a counter pass cannot run inside this process, so the figure is null for a workload / size that
-    has none.  A pass of the same scheme (batches in flight) is preferred; one of the other scheme is named as such."""
-    best = None
+    has none.  The pass of the line's own command (batches in flight, one or two input copies) is preferred; any other is named
+    as what it is."""
+    best, best_score = None, -1
     for path in PMC_SUMMARIES:
         try:
             with open(path) as f:
@@ -407,13 +408,16 @@ def pmc_traffic(workload: str, total_chars: int, in_flight: int):
             if not (rec.get("label") == "bench" and rec.get("workload") == workload and rec.get("kernel") == "k_tiles_main"
                     and rec.get("total_chars") == total_chars):
                 continue
-            same = int(rec.get("in_flight", 1)) == in_flight
-            src = {"file": os.path.relpath(path, ROOT), "command": rec.get("command", "python3 bench.py --workload %s --in-flight 1" % workload),
-                   "in_flight": int(rec.get("in_flight", 1)), "distinct_inputs": rec.get("distinct_inputs"),
-                   "same_launch_scheme_as_this_line": same, "launches_averaged": rec.get("launches")}
-            if same:
-                return rec.get("hbm_bytes_per_launch"), src
-            best = best or (rec.get("hbm_bytes_per_launch"), src)
+            same_flow = int(rec.get("in_flight", 1)) == in_flight
+            same_inputs = in_flight < 2 or bool(rec.get("distinct_inputs", 0)) == bool(distinct)
+            score = 2 * same_flow + (same_flow and same_inputs)
+            if score > best_score:
+                best_score = score
+                best = (rec.get("hbm_bytes_per_launch"),
+                        {"file": os.path.relpath(path, ROOT), "command": rec.get("command"), "in_flight": int(rec.get("in_flight", 1)),
+                         "distinct_inputs": bool(rec.get("distinct_inputs", 0)) if "distinct_inputs" in rec else None,
+                         "same_command_as_this_line": bool(same_flow and same_inputs), "launches_averaged": rec.get("launches"),
+                         "note": "a counter pass runs the dispatches one after the other: bytes per launch, not the overlap, are what it shows"})
     return best if best else (None, None)
 
 
@@ -790,7 +794,7 @@ def build_line(args, recs, mode, devices, same_start):
                   "ms_per_rank": [x["ms_events"] / K for x in sr],
                   "what": "the same K steps with ONE batch in flight (index -> tiles -> resolve back to back on one stream): "
                           "`value` of rounds 1-3 before the batch flow"}
-    traffic, traffic_src = pmc_traffic(args.workload, recs[0]["total"], 2 if flow else 1)
+    traffic, traffic_src = pmc_traffic(args.workload, recs[0]["total"], 2 if flow else 1, bool(flow and all(r.get("distinct_inputs") for r in recs)))
     fracs = [r["alg_read"] / (r["kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS for r in recs]
     worst = min(range(world), key=lambda i: fracs[i])
     r0 = recs[0]

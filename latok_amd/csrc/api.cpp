@@ -170,6 +170,8 @@ struct Ctx {
     std::vector<int64_t> hd_row, hd_pos;
     unsigned done_ctr_seen = 0;
     DevBuf u_bytes, u_boff, u_cnt, u_row, u_pref;   // UTF-8 ingest: uploaded bytes / byte offsets, per-string cp counts, cp offsets
+    DevBuf u_lead, u_bspace, u_cpbits, u_cpspace;   // code-point results from byte space (cp_masks_via_bytes): lead-byte mask, byte-space
+                                                    // SPACE plane, the packed code-point masks
     DevBuf codes;              // featurize: rule code of every char (SplitParams::codes_out)
     // chunked host pipeline (compact_host_pipelined): copy streams, events and double buffers
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
@@ -193,7 +195,7 @@ struct Ctx {
     };
     static constexpr int kFlowSlots = 4;
     FlowSlot flow[kFlowSlots];
-    int flow_slots = 2;                  // slots in use (LATOK_FLOW_SLOTS, A/B)
+    int flow_slots = 2;                  // slots in use
     bool flow_ready = false;
     unsigned long long flow_seq = 0;     // batches submitted so far
     latok::FlowHazards flow_held;        // memory ranges of the batches in flight, per slot (flow_hazards.h)
@@ -313,11 +315,8 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     // 48: 87-90, 64: 87-91, 128 (two kernels side by side on half the chip each): 89.  A segment's tiles go round-robin over
     // the workgroup's 12 waves, so a plan whose last round holds only a wave or two (216 CUs: 145 tiles = 12 rounds + 1 tile:
     // 93-96 us) wastes what the free CUs gain: of the candidate shares the first whose last round is at least half full is taken.
-    // LATOK_AB_SPARE_CUS=k (A/B): k CUs left free instead (also for the blocking calls); LATOK_AB_SEG_TILES: segment length given.
-    static const int spare_cus = [] { const char* e = getenv("LATOK_AB_SPARE_CUS"); return e ? atoi(e) : -1; }();
     int n_cu_eff = g.n_cu;
-    if (spare_cus >= 0) n_cu_eff = g.n_cu - spare_cus;
-    else if (slot && g.n_cu >= 64) {
+    if (slot && g.n_cu >= 64) {
         const int cand[3] = {g.n_cu * 7 / 8, g.n_cu * 13 / 16, g.n_cu * 3 / 4};
         int best = cand[0], best_fill = -1;
         for (int c = 0; c < 3; ++c) {
@@ -333,11 +332,6 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     }
     if (n_cu_eff < 8) n_cu_eff = g.n_cu < 8 ? g.n_cu : 8;
     latok::plan_segments(n_tiles, n_cu_eff, &P.seg_tiles, &P.n_segs);
-    static const int ab_seg = [] { const char* e = getenv("LATOK_AB_SEG_TILES"); return e ? atoi(e) : 0; }();
-    if (ab_seg >= latok::kWPB && ab_seg <= latok::kSegMax && n_tiles > ab_seg) {   // experiment knob: segment length given
-        P.seg_tiles = ab_seg;
-        P.n_segs = (n_tiles + ab_seg - 1) / ab_seg;
-    }
     // a small UTF-32 batch: one segment, and (below) one launch for the three stages
     const bool one_launch = stages == 7 && !d_u8 && !tiles_begin && !tiles_end && n_tiles <= latok::kOneSegTiles &&
                             (mode == latok::kModeBits || mode == latok::kModeRules) && one_segment_enabled();
@@ -488,7 +482,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.rules_on = false;
     for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
                       &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
-                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl, &g.codes})
+                      &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.u_lead, &g.u_bspace, &g.u_cpbits, &g.u_cpspace, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl, &g.codes})
         b->release();
     for (auto& e : g.ev) {
         if (e) (void)hipEventDestroy(e);
@@ -851,7 +845,9 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
                                   const int64_t* d_row, int64_t n_str, int64_t total, void* d_counts, void* d_items, int8_t* d_feat,
                                   int64_t cap, int64_t* p_tot, volatile int64_t* h_tot, hipStream_t st,
                                   latok::DoneSignal done = latok::DoneSignal{nullptr, 0, nullptr},
-                                  Ctx::FlowSlot* slot = nullptr) {   // slot: the workspaces of a batch-flow slot (offsets / spans only)
+                                  Ctx::FlowSlot* slot = nullptr,     // slot: the workspaces of a batch-flow slot (offsets / spans only)
+                                  const uint64_t* pre_bits = nullptr, const uint64_t* pre_space = nullptr) {   // the two bitmasks are
+                                  // already there (code-point masks packed from byte space: cp_masks_via_bytes): only the string index is launched
     int rc;
     DevBuf& w_bits = slot ? slot->bits : g.bits;
     DevBuf& w_space = slot ? slot->space : g.space;
@@ -883,8 +879,8 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
     if ((rc = w_scalar.ensure(64))) return rc;
     unsigned epoch = 0;
     if ((rc = next_scan_epoch(sc, latok::count_blocks(words), st, &epoch))) return rc;
-    uint64_t* d_bits = (uint64_t*)w_bits.p;
-    uint64_t* d_space = spans ? (uint64_t*)w_space.p : nullptr;
+    uint64_t* d_bits = pre_bits ? const_cast<uint64_t*>(pre_bits) : (uint64_t*)w_bits.p;
+    uint64_t* d_space = spans ? (pre_bits ? const_cast<uint64_t*>(pre_space) : (uint64_t*)w_space.p) : nullptr;
     uint64_t* d_kept = spans ? (uint64_t*)w_kept.p : nullptr;
     const uint64_t* d_item_mask = spans ? d_kept : d_bits;
     int64_t* d_rank = (int64_t*)w_bases.p;
@@ -901,7 +897,8 @@ static int enqueue_compaction_dev(Ctx& g, bool spans, bool feats, bool o32, cons
         HIP_TRY(hipMemsetAsync(d_codes + tail0, 0, code_bytes - tail0, st));
     }
     if ((rc = run_pipeline(g, d_cps, d_row, n_str, total, d_bits, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, 7, d_codes, latok::DoneSignal{nullptr, 0, nullptr}, slot)))
+                           nullptr, nullptr, d_space, d_tile_first, d_u8, unit_kind, pre_bits ? 1 : 7, d_codes,
+                           latok::DoneSignal{nullptr, 0, nullptr}, slot)))
         return rc;
     if (h_tot) {   // pinned pair of the context's own calls: cleared by the host
         h_tot[0] = 0;
@@ -1133,6 +1130,11 @@ static bool host_decode_small(const uint8_t* u8, const int64_t* boff, int64_t n_
     return true;
 }
 
+static int cp_masks_via_bytes(Ctx& g, const uint8_t* d_u8, const int64_t* d_boff, int64_t n_str, int64_t total_bytes, uint64_t* d_out,
+                              uint64_t* d_out_space, int64_t cap_words, int64_t* d_cp_row, hipStream_t st, int64_t* total_cps_out,
+                              int* fallback_out);
+static int utf8_on_device(Ctx& g, const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes, bool dev, hipStream_t st,
+                          const uint8_t** d_u8, const int64_t** d_boff);
 static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t* row_off, int64_t n_str, int64_t total, void* counts_out,
                           void* items_out, int64_t items_cap, int64_t* n_items_out, int flags, void* stream, int8_t* features_out,
                           const uint8_t* utf8, bool byte_space, int unit_kind);
@@ -1195,6 +1197,7 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
     const uint32_t* d_cps = cps;
     const int64_t* d_row = row_off;
     const uint8_t* d_u8 = nullptr;   // byte space: the tile kernel reads the UTF-8 bytes itself, results are byte offsets
+    const uint64_t *pre_bits = nullptr, *pre_space = nullptr;   // code-point masks packed from byte space (UTF-8 in code-point units)
     const size_t unit_bytes = (utf8 && byte_space) ? (unit_kind ? (size_t)unit_kind : 1) : 4;
     if (!dev && !(utf8 && !byte_space)) {
         // host pointers, fixed-width units or UTF-8 in byte space: checked here; large batches take the chunked pipeline
@@ -1230,16 +1233,49 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
             d_row = (const int64_t*)g.u_boff.p;
         }
         d_cps = nullptr;
-    } else if (utf8) {   // row_off = byte offsets, total = bytes: decode on the device first; results are in code-point units
-        BytesRoute br;
-        if ((rc = decode_utf8_to_workspace(g, utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
-        if (br.d_u8) {   // no multi-byte char in the batch: byte space == code-point space, skip the decode
-            d_u8 = br.d_u8;
-            d_row = br.d_boff;
-            d_cps = nullptr;
-        } else {
-            d_cps = (const uint32_t*)g.h_cps.p;
-            d_row = (const int64_t*)g.u_row.p;
+    } else if (utf8) {   // row_off = byte offsets, total = bytes; results are in code-point units
+        int64_t tb = total;
+        if (dev) {
+            if ((rc = resolve_total_device(row_off, n_str, &tb, st))) return rc;
+        } else if ((rc = check_csr_host(row_off, n_str, &tb))) {
+            return rc;
+        }
+        bool done_via_bytes = false;
+        if (!feats && n_str > 0 && tb > kSmallChars && (!dev || ((uintptr_t)utf8 & 15) == 0)) {
+            // large batches: the byte-space kernel + the masks packed at the lead bytes (no UTF-32 copy of the batch); the compaction
+            // then runs on the code-point masks
+            const uint8_t* b8;
+            const int64_t* boff;
+            if ((rc = utf8_on_device(g, utf8, row_off, n_str, tb, dev, st, &b8, &boff))) return rc;
+            const int64_t words_b = (tb + 63) / 64;
+            if ((rc = g.u_cpbits.ensure((size_t)words_b * 8 + 8)) || (spans && (rc = g.u_cpspace.ensure((size_t)words_b * 8 + 8))) ||
+                (rc = g.u_row.ensure((size_t)(n_str + 1) * 8)))
+                return rc;
+            int fallback = 0;
+            int64_t total_cps = 0;
+            if ((rc = cp_masks_via_bytes(g, b8, boff, n_str, tb, (uint64_t*)g.u_cpbits.p, spans ? (uint64_t*)g.u_cpspace.p : nullptr, words_b,
+                                         (int64_t*)g.u_row.p, st, &total_cps, &fallback)))
+                return rc;
+            if (!fallback) {
+                pre_bits = (const uint64_t*)g.u_cpbits.p;
+                pre_space = spans ? (const uint64_t*)g.u_cpspace.p : nullptr;
+                d_cps = nullptr;
+                d_row = (const int64_t*)g.u_row.p;
+                total = total_cps;
+                done_via_bytes = true;
+            }
+        }
+        if (!done_via_bytes) {   // small batches, featurize (re-reads code points), malformed input: decode on the device first
+            BytesRoute br;
+            if ((rc = decode_utf8_to_workspace(g, utf8, row_off, n_str, total, dev, st, &total, feats ? nullptr : &br))) return rc;
+            if (br.d_u8) {   // no multi-byte char in the batch: byte space == code-point space, skip the decode
+                d_u8 = br.d_u8;
+                d_row = br.d_boff;
+                d_cps = nullptr;
+            } else {
+                d_cps = (const uint32_t*)g.h_cps.p;
+                d_row = (const int64_t*)g.u_row.p;
+            }
         }
     } else if (dev) {
         if ((rc = resolve_total_device(row_off, n_str, &total, st))) return rc;
@@ -1342,7 +1378,7 @@ static int compact_common(Ctx& g, bool spans, const uint32_t* cps, const int64_t
             done = latok::DoneSignal{(unsigned long long*)(p_tot + 2), seq, (unsigned*)g.done_ctr.p};
         }
         if ((rc = enqueue_compaction_dev(g, spans, feats, o32, d_cps, d_u8, unit_kind, d_row, n_str, total, d_counts, d_items, d_feat,
-                                         cap, p_tot, h_tot, st, done)))
+                                         cap, p_tot, h_tot, st, done, nullptr, pre_bits, pre_space)))
             return rc;
         polled = done.word && wait_completion_word((const unsigned long long*)(h_tot + 2), seq);
     }
@@ -1411,47 +1447,33 @@ int latok_utf8_decode_batch(const uint8_t* utf8, const int64_t* byte_off, int64_
     return LATOK_OK;
 }
 
-// Code-point boundary mask of a UTF-8 batch WITHOUT a UTF-32 copy of it (the reference reads code points, latok.c:53-55,79; a
-// UTF-8 caller has bytes): the byte-space tile kernel on the bytes, which also leaves the lead-byte mask and the lead counts
-// per word and per tile; one scan of the tile counts (k_scan_chained); then k_lead_compress packs the boundary bits at lead bytes and
-// turns the byte offsets into code-point offsets.  HBM traffic: the bytes once + ~5 bits per byte of masks and ranks, against
-// 1 + 4 + 4 bytes per char through the staged decoder.  Nothing waits for the host between the launches; the code-point total,
-// the capacity check and the malformed-input flag are read after one synchronisation.  *fallback_out = 1: the batch holds a
-// continuation byte that the byte-space model and the decoder treat differently (malformed UTF-8): the caller takes the decoder.
-static int mask_utf8_via_bytes(Ctx& g, const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes, bool dev,
-                               uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out, int64_t* total_cps_out,
-                               hipStream_t st, int* fallback_out) {
+// Code-point results of a UTF-8 batch WITHOUT a UTF-32 copy of it (the reference reads code points, latok.c:53-55,79; a UTF-8
+// caller has bytes): the byte-space tile kernel on the bytes, which also leaves the lead-byte mask and the lead counts per word
+// and per tile; one scan of the tile counts (k_scan_chained); then k_lead_compress packs the boundary bits at lead bytes (and,
+// for token spans, the SPACE plane) and turns the byte offsets into code-point offsets.  HBM traffic: the bytes once + ~5 bits per
+// byte of masks and ranks, against 1 + 4 + 4 bytes per char through the staged decoder.  Everything is on the device; nothing
+// waits for the host between the launches; the code-point total, the capacity check and the malformed-input flag are read
+// after one synchronisation.  *fallback_out = 1: the batch holds a continuation byte that the byte-space model and the
+// decoder treat differently (malformed UTF-8): the caller takes the decoder.
+//   d_out / d_out_space: where the packed masks go (cap_words words each; d_out_space NULL: boundaries only), d_cp_row [n_str + 1]
+static int cp_masks_via_bytes(Ctx& g, const uint8_t* d_u8, const int64_t* d_boff, int64_t n_str, int64_t total_bytes, uint64_t* d_out,
+                              uint64_t* d_out_space, int64_t cap_words, int64_t* d_cp_row, hipStream_t st, int64_t* total_cps_out,
+                              int* fallback_out) {
     int rc;
     *fallback_out = 0;
-    const uint8_t* d_u8 = utf8;
-    const int64_t* d_boff = byte_off;
-    if (!dev) {
-        if ((rc = g.u_bytes.ensure((size_t)total_bytes + 16))) return rc;
-        if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
-        HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
-        d_u8 = (const uint8_t*)g.u_bytes.p;
-        d_boff = (const int64_t*)g.u_boff.p;
-    }
     const int64_t words_b = (total_bytes + 63) / 64, c_tiles = (words_b + 63) / 64;
-    const int64_t out_words = mask_cap_words < words_b ? mask_cap_words : words_b;   // (a batch has at most one char per byte)
-    if ((rc = g.bits.ensure((size_t)words_b * 8 + 8)) || (rc = g.space.ensure((size_t)words_b * 8 + 8)) ||
+    if ((rc = g.bits.ensure((size_t)words_b * 8 + 8)) || (rc = g.u_lead.ensure((size_t)words_b * 8 + 8)) ||
+        (d_out_space && (rc = g.u_bspace.ensure((size_t)words_b * 8 + 8))) ||
         (rc = g.wcnt.ensure((size_t)c_tiles * 8 + 8)) || (rc = g.bases.ensure((size_t)c_tiles * 8 + 8)) ||
         (rc = g.wpref.ensure((size_t)words_b * 2 + 8)) || (rc = g.scalar.ensure(64)) || (rc = g.pin_tot.ensure(64)))
         return rc;
-    uint64_t* d_out = mask_bits_out;
-    int64_t* d_cp_row = cp_row_off_out;
-    if (!dev) {
-        if ((rc = g.h_out.ensure((size_t)out_words * 8 + 8)) || (rc = g.u_row.ensure((size_t)(n_str + 1) * 8))) return rc;
-        d_out = (uint64_t*)g.h_out.p;
-        d_cp_row = (int64_t*)g.u_row.p;
-    }
     unsigned epoch = 0;
     if ((rc = next_scan_epoch(scan_state(g, nullptr), latok::count_blocks(words_b), st, &epoch))) return rc;
     uint64_t* d_bmask = (uint64_t*)g.bits.p;
-    uint64_t* d_lead = (uint64_t*)g.space.p;
+    uint64_t* d_lead = (uint64_t*)g.u_lead.p;
+    uint64_t* d_bspace = d_out_space ? (uint64_t*)g.u_bspace.p : nullptr;
     if ((rc = run_pipeline(g, nullptr, d_boff, n_str, total_bytes, d_bmask, nullptr, latok::kModeBits, st, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, d_u8, 0, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, nullptr, d_lead,
+                           nullptr, d_bspace, nullptr, d_u8, 0, 7, nullptr, latok::DoneSignal{nullptr, 0, nullptr}, nullptr, d_lead,
                            (uint16_t*)g.wpref.p, (int64_t*)g.wcnt.p)))
         return rc;
     volatile int64_t* h_tot = (volatile int64_t*)g.pin_tot.h;
@@ -1462,13 +1484,49 @@ static int mask_utf8_via_bytes(Ctx& g, const uint8_t* utf8, const int64_t* byte_
     int* d_err = (int*)(p_tot + 1);
     HIP_TRY(latok::launch_tile_scan((const int64_t*)g.wcnt.p, c_tiles, (int64_t*)g.bases.p, (unsigned long long*)g.chain.p, (unsigned*)g.chain_ctl.p,
                                     epoch, (int64_t*)g.scalar.p, p_tot, d_err + 1, st));
-    HIP_TRY(latok::launch_lead_compress(d_bmask, d_lead, (const int64_t*)g.bases.p, (const int64_t*)g.wcnt.p, (const uint16_t*)g.wpref.p,
-                                        words_b, total_bytes, d_boff, n_str, (const int64_t*)g.scalar.p, d_out, out_words, d_cp_row,
-                                        (int*)(p_tot + 3), st));
+    HIP_TRY(latok::launch_lead_compress(d_bmask, d_bspace, d_lead, (const int64_t*)g.bases.p, (const int64_t*)g.wcnt.p,
+                                        (const uint16_t*)g.wpref.p, words_b, total_bytes, d_boff, n_str, (const int64_t*)g.scalar.p, d_out,
+                                        d_out_space, cap_words, d_cp_row, (int*)(p_tot + 3), st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (h_tot[1] != 0) return fail(LATOK_ERR_HIP, "internal: the chained scan did not complete (flag %lld)", (long long)h_tot[1]);
+    if (h_tot[1] != 0) { g.chain_ready = false; return fail(LATOK_ERR_HIP, "internal: the chained scan did not complete (flag %lld)", (long long)h_tot[1]); }
     if (h_tot[3] != 0) { *fallback_out = 1; return LATOK_OK; }
-    const int64_t total_cps = h_tot[0];
+    *total_cps_out = h_tot[0];
+    return LATOK_OK;
+}
+// bytes + byte offsets on the device, from the caller's pointers (uploaded when they are host pointers)
+static int utf8_on_device(Ctx& g, const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes, bool dev, hipStream_t st,
+                          const uint8_t** d_u8, const int64_t** d_boff) {
+    int rc;
+    *d_u8 = utf8;
+    *d_boff = byte_off;
+    if (dev) return LATOK_OK;
+    if ((rc = g.u_bytes.ensure((size_t)total_bytes + 16))) return rc;
+    if ((rc = g.u_boff.ensure((size_t)(n_str + 1) * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(g.u_bytes.p, utf8, (size_t)total_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(g.u_boff.p, byte_off, (size_t)(n_str + 1) * 8, hipMemcpyHostToDevice, st));
+    *d_u8 = (const uint8_t*)g.u_bytes.p;
+    *d_boff = (const int64_t*)g.u_boff.p;
+    return LATOK_OK;
+}
+static int mask_utf8_via_bytes(Ctx& g, const uint8_t* utf8, const int64_t* byte_off, int64_t n_str, int64_t total_bytes, bool dev,
+                               uint64_t* mask_bits_out, int64_t mask_cap_words, int64_t* cp_row_off_out, int64_t* total_cps_out,
+                               hipStream_t st, int* fallback_out) {
+    int rc;
+    const uint8_t* d_u8;
+    const int64_t* d_boff;
+    if ((rc = utf8_on_device(g, utf8, byte_off, n_str, total_bytes, dev, st, &d_u8, &d_boff))) return rc;
+    const int64_t words_b = (total_bytes + 63) / 64;
+    const int64_t out_words = mask_cap_words < words_b ? mask_cap_words : words_b;   // (a batch has at most one char per byte)
+    uint64_t* d_out = mask_bits_out;
+    int64_t* d_cp_row = cp_row_off_out;
+    if (!dev) {
+        if ((rc = g.h_out.ensure((size_t)out_words * 8 + 8)) || (rc = g.u_row.ensure((size_t)(n_str + 1) * 8))) return rc;
+        d_out = (uint64_t*)g.h_out.p;
+        d_cp_row = (int64_t*)g.u_row.p;
+    }
+    int64_t total_cps = 0;
+    if ((rc = cp_masks_via_bytes(g, d_u8, d_boff, n_str, total_bytes, d_out, nullptr, out_words, d_cp_row, st, &total_cps, fallback_out))) return rc;
+    if (*fallback_out) return LATOK_OK;
     *total_cps_out = total_cps;
     const int64_t words = (total_cps + 63) / 64;
     if (words > mask_cap_words) return fail(LATOK_ERR_INVALID, "mask_cap_words too small: need %lld", (long long)words);
@@ -2042,10 +2100,7 @@ extern "C" int latok_debug_host_decode_utf8(const uint8_t* utf8, const int64_t* 
 // than the launch it hides.)
 static int flow_setup(Ctx& g) {
     if (g.flow_ready) return LATOK_OK;
-    const char* e = getenv("LATOK_FLOW_SLOTS");
-    g.flow_slots = e ? atoi(e) : 2;
-    if (g.flow_slots < 1) g.flow_slots = 1;
-    if (g.flow_slots > Ctx::kFlowSlots) g.flow_slots = Ctx::kFlowSlots;
+    g.flow_slots = 2;   // (3 and 4 slots measured: nothing over 2, profiles/r03_ab_flow_slots.txt)
     for (int i = 0; i < g.flow_slots; ++i) {
         Ctx::FlowSlot& f = g.flow[i];
         if (!f.st) HIP_TRY(hipStreamCreateWithFlags(&f.st, hipStreamNonBlocking));
@@ -2057,8 +2112,8 @@ static int flow_drain(Ctx& g) {
     if (!g.flow_ready) return LATOK_OK;
     // The streams are POLLED for up to 2 ms before the call blocks on them: a blocking wait comes back ~15 us after the last
     // kernel has ended (the runtime's wake-up), which is 1.5 % of a 20-batch flow on C2 (same-box A/B, K = 20: 89.1-90.7 ->
-    // 86.1-88.7 us per batch).  LATOK_FLOW_DRAIN=0: block at once.
-    static const int drain_poll = [] { const char* e = getenv("LATOK_FLOW_DRAIN"); return e ? atoi(e) : 1; }();
+    // 86.1-88.7 us per batch).
+    constexpr bool drain_poll = true;
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < g.flow_slots; ++i) {
         bool done = false;

@@ -267,10 +267,8 @@ __device__ __forceinline__ void counts_scatter_block(
     // what the form needs (it was 8 KB per wave for every form: 4 workgroups per CU).  Measured on C2, same box: int32 offsets
     // 0.174 -> 0.165 ms and int32 spans 0.233 -> 0.222 at 7 - 8 workgroups per CU, but int64 spans 0.247 -> 0.256 (twice
     // the store stream per token): that form keeps the footprint that holds it at 4.
-#ifndef LATOK_AB_SPAN64_BUF
-#define LATOK_AB_SPAN64_BUF 6656   // int64 spans: 5 workgroups per CU (4: C3 +2.5 %; 7: C2 +4 %)
-#endif
-    constexpr int kBufBytes = KIND == 0 ? kCodes * (int)sizeof(OUT) : (sizeof(OUT) == 8 ? LATOK_AB_SPAN64_BUF : kCodes * 2 + 64 * 48);
+    constexpr int kSpan64Buf = 6656;   // int64 spans: 5 workgroups per CU (4: C3 +2.5 %; 7: C2 +4 %)
+    constexpr int kBufBytes = KIND == 0 ? kCodes * (int)sizeof(OUT) : (sizeof(OUT) == 8 ? kSpan64Buf : kCodes * 2 + 64 * 48);
     __shared__ __attribute__((aligned(16))) uint8_t buf_s[kScatterWaves][kBufBytes];
     __shared__ long long smax_s[kScatterWaves][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -396,10 +394,6 @@ __device__ __forceinline__ void counts_scatter_block(
         uint64_t* r = rows + 6 * lane;
         r[0] = xb; r[1] = nn; r[2] = xb1; r[3] = nn1; r[4] = Bw; r[5] = (uint64_t)lo_in;
     }
-#ifdef LATOK_AB_SCATTER_SETUP_ONLY
-    if (rows[0] == 0x123456789abcull) out[0] = 1;   // ablation (timing only): stop before the item loop
-    return;
-#endif
     for (int win0 = 0; win0 < n_wave; win0 += kCodes) {
         while (rest && k < win0 + kCodes) {
             const int b = __builtin_ctzll(rest);
@@ -451,11 +445,7 @@ __device__ __forceinline__ void counts_scatter_block(
                     out2 v;
                     v.x = (OUT)(a2 - lo);
                     v.y = (OUT)(e2 - lo);
-#ifdef LATOK_AB_SCATTER_NO_STORE
-                    if (v.x == (OUT)0x12345678 && v.y == (OUT)0x1abcdef0) out[0] = 1;   // ablation (timing only)
-#else
                     __builtin_nontemporal_store(v, reinterpret_cast<out2*>(out) + base_out + win0 + j);
-#endif
                 }
             }
         }
@@ -485,24 +475,27 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
 //   cp mask        = the boundary bits at the lead positions, packed: per word pext(boundaries, leads), appended at the word's
 //                    rank = leads before it (tile_rank from k_scan_chained over the tile counts + the word's prefix);
 //   cp_row_off[s]  = number of leads before byte_off[s].
-// One wave per tile of 64 words; the compressed chunks of the tile's words meet in LDS (a chunk straddles at most two output
-// words) and leave as whole words.  Every output word is written exactly once, by the tile that holds the lead of its LAST
-// bit (the batch's final, partial word: by the last tile with a lead): the bits of such a word that belong to earlier tiles
-// are recomputed from the words in front of the tile (the 63 leads before a tile lie in its previous 4 words in well-formed
-// text; the look-back goes on for as long as malformed input makes it).  No atomics on global memory, no cleared output
-// (two global atomics per tile cost 40 of 110 us on C3).  Role 2 (the workgroups behind): one thread per row offset.
+// One workgroup per 16 tiles of 64 words; the packed chunks of its words meet in one LDS window (a chunk straddles at most two
+// output words) and leave as whole words.  Every output word is written exactly once, by the workgroup that holds the lead of
+// its LAST bit (the batch's final, partial word: by the last workgroup with a lead): the bits of a workgroup's first word that
+// belong to earlier ones are recomputed by its first wave from the words in front of it.  No atomics on global memory, no
+// cleared output (two global atomics per tile cost 40 of 110 us on C3); the kernel is bound by the pext (~190 VALU per word
+// and mask: one wave per tile with a look-back pext of its own ran 106 us on C3).  Role 2 (the workgroups behind): one thread
+// per row offset.
 // *odd is raised when the byte-space model and the decoder's model of MALFORMED input differ: a continuation byte with no lead
 // byte within the 3 bytes before it, or at the start of a string (the host then takes the staged decoder instead).
-__global__ __launch_bounds__(256) void k_lead_compress(const uint64_t* __restrict__ bmask, const uint64_t* __restrict__ lead,
-                                                       const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt,
-                                                       const uint16_t* __restrict__ word_pref, int64_t n_words, int64_t total_bytes,
-                                                       const int64_t* __restrict__ byte_off, int64_t n_str,
-                                                       const int64_t* __restrict__ total_cps_dev, uint64_t* __restrict__ out_mask,
-                                                       int64_t cap_words, int64_t* __restrict__ cp_row_off, int* __restrict__ odd,
-                                                       unsigned n_tile_blocks) {
+constexpr int kCompressWaves = 16;                         // tiles per workgroup
+constexpr int kCompressWords = kCompressWaves * 64;        // input words per workgroup = output words it can own (+ 1)
+template <bool TWO>   // TWO: a second byte-space mask (the SPACE plane, for token spans) is packed the same way into out_mask2
+__global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
+    const uint64_t* __restrict__ bmask, const uint64_t* __restrict__ bmask2, uint64_t* __restrict__ out_mask2,
+    const uint64_t* __restrict__ lead, const int64_t* __restrict__ tile_rank, const int64_t* __restrict__ tile_cnt,
+    const uint16_t* __restrict__ word_pref, int64_t n_words, int64_t total_bytes, const int64_t* __restrict__ byte_off, int64_t n_str,
+    const int64_t* __restrict__ total_cps_dev, uint64_t* __restrict__ out_mask, int64_t cap_words, int64_t* __restrict__ cp_row_off,
+    int* __restrict__ odd, unsigned n_tile_blocks) {
     if (blockIdx.x >= n_tile_blocks) {   // role 2: code-point offset of every string (and of the end of the batch)
         const int64_t total_cps = *total_cps_dev;
-        const int64_t s = (int64_t)(blockIdx.x - n_tile_blocks) * 256 + threadIdx.x;
+        const int64_t s = (int64_t)(blockIdx.x - n_tile_blocks) * (kCompressWaves * 64) + threadIdx.x;
         if (s > n_str) return;
         const int64_t b = byte_off[s];
         if (b >= total_bytes) { cp_row_off[s] = total_cps; return; }
@@ -512,29 +505,41 @@ __global__ __launch_bounds__(256) void k_lead_compress(const uint64_t* __restric
         if (s < n_str && byte_off[s + 1] > b && !((mw >> (b & 63)) & 1ull)) *odd = 1;   // a string begins with a continuation byte
         return;
     }
-    __shared__ unsigned long long win_s[4][66];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t w0 = t * 64;
-    if (w0 >= n_words) return;                                      // whole wave
-    const int64_t w = w0 + lane;
+    // The workgroup takes kCompressWaves consecutive tiles; their packed chunks meet in ONE window in LDS, so only the
+    // workgroup's first output word needs bits from in front of it (and only its last, partial one is left to the next).
+    __shared__ unsigned long long win_s[TWO ? 2 : 1][kCompressWords + 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t n_tiles = (n_words + 63) >> 6;
+    const int64_t T0 = (int64_t)blockIdx.x * kCompressWaves;
+    const int64_t T1 = min(T0 + kCompressWaves, n_tiles) - 1;      // the workgroup's last tile
+    const int64_t t = min(T0 + (tid >> 6), T1);
+    const int64_t w = T0 * 64 + tid;
     const bool in = w < n_words;
-    // everything the wave needs from memory is requested here, in one round trip, by unconditional loads at clamped addresses
+    // everything the thread needs from memory is requested here, in one round trip, by unconditional loads at clamped addresses
     // (a predicated load is a branch, and hipcc waits for everything in flight at it)
     const int64_t total_cps = *total_cps_dev;
     const int64_t wc = in ? w : n_words - 1;
-    uint64_t m = lead[wc];
-    uint64_t x = bmask[wc];
-    const uint64_t m_before = lead[wc > 0 ? wc - 1 : 0];            // (the word before mine: every lane loads its own, coalesced)
-    const int64_t wk = w0 - 1 - lane > 0 ? w0 - 1 - lane : 0;       // look-back: lane k takes the k-th word in front of the tile
-    uint64_t mb = lead[wk], xb = bmask[wk];
-    const int n_wave = (int)tile_cnt[t];
-    const int64_t pos0 = tile_rank[t];                              // code-point index of the tile's first lead
+    lk_u64 m = lead[wc];
+    lk_u64 x = bmask[wc];
+    lk_u64 x2 = TWO ? bmask2[wc] : 0ull;
+    const uint64_t m_before = lead[wc > 0 ? wc - 1 : 0];           // (the word before mine: every thread loads its own, coalesced)
+    const int64_t my_pos0 = tile_rank[t];                          // code-point index of my tile's first lead
     const int pref = (int)word_pref[wc];
-    unsigned long long* win = win_s[wave];
-    win[lane] = 0ull;
-    if (lane < 2) win[64 + lane] = 0ull;
-    if (!in) { m = 0ull; x = 0ull; }
+    const int64_t pos0 = tile_rank[T0];                            // ... of the workgroup's
+    const int64_t end = tile_rank[T1] + tile_cnt[T1];              // one past the workgroup's last code point
+    // the look-back (first wave): lane k takes the k-th word in front of the workgroup
+    const int64_t wk = T0 * 64 - 1 - lane > 0 ? T0 * 64 - 1 - lane : 0;
+    lk_u64 mb = 0, xb = 0, xb2 = 0;
+    if (tid < 64) { mb = lead[wk]; xb = bmask[wk]; xb2 = TWO ? bmask2[wk] : 0ull; }
+    unsigned long long* win = win_s[0];
+    unsigned long long* win2 = win_s[TWO ? 1 : 0];
+    win[tid] = 0ull;
+    if (tid < 2) win[kCompressWords + tid] = 0ull;
+    if (TWO) {
+        win2[tid] = 0ull;
+        if (tid < 2) win2[kCompressWords + tid] = 0ull;
+    }
+    if (!in) { m = 0ull; x = 0ull; x2 = 0ull; }
     // continuation bytes without a lead byte in the 3 bytes before them (malformed input)
     {
         const uint64_t C = in ? (~m & valid_mask(w, total_bytes)) : 0ull;
@@ -542,63 +547,92 @@ __global__ __launch_bounds__(256) void k_lead_compress(const uint64_t* __restric
         const uint64_t run = C & ((C << 1) | (Cp >> 63)) & ((C << 2) | (Cp >> 62)) & ((C << 3) | (Cp >> 61));
         if (run) *odd = 1;
     }
-    if ((total_cps + 63) / 64 > cap_words) return;                  // the caller's mask is too small: nothing is written
-    if (n_wave == 0) return;
-    const int64_t ow0 = pos0 >> 6;                                  // first output word the tile has bits in
-    const int64_t end = pos0 + n_wave;                              // one past the tile's last code point
-    // words I own: those whose last bit is mine, + the batch's final partial word if its last lead is mine
-    const int64_t own_end = end == total_cps ? (end + 63) >> 6 : end >> 6;   // one past my last owned word
-    if (own_end <= ow0) return;                                     // all my bits lie in a word a later tile owns
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (x) {                                                        // (a word without boundaries adds nothing)
-        const uint64_t c = lk_pext64(x, m);
-        const int64_t pos = pos0 + pref;
+    if ((total_cps + 63) / 64 > cap_words) return;                 // the caller's mask is too small: nothing is written (uniform)
+    const int64_t ow0 = pos0 >> 6;                                 // first output word the workgroup has bits in
+    // words the workgroup owns: those whose last bit is its own, + the batch's final partial word if its last lead is
+    const int64_t own_end = end == total_cps ? (end + 63) >> 6 : end >> 6;
+    if (end == pos0 || own_end <= ow0) return;                     // no lead at all / all bits lie in a word a later one owns (uniform)
+    __syncthreads();
+    {
+        const int64_t pos = my_pos0 + pref;
         const int rel = (int)((pos >> 6) - ow0), sh = (int)(pos & 63);
-        atomicOr(&win[rel], c << sh);
-        if (sh && (c >> (64 - sh))) atomicOr(&win[rel + 1], c >> (64 - sh));
-    }
-    // the bits of my first word that belong to earlier tiles: the `need` leads in front of the tile, nearest word first
-    int need = (int)(pos0 & 63);
-    for (int64_t back = 0; need > 0; back += 64) {                  // wave-uniform; one round unless the input is malformed
-        if (back > 0) {
-            const int64_t wj = w0 - 1 - back - lane;
-            mb = wj >= 0 ? lead[wj] : 0ull;
-            xb = wj >= 0 ? bmask[wj] : 0ull;
-        } else if (w0 - 1 - lane < 0) {
-            mb = 0ull;
-            xb = 0ull;
+        if (TWO) {
+            if (x | x2) {
+                lk_pext64x2(&x, &x2, m);
+                if (x) {
+                    atomicOr(&win[rel], x << sh);
+                    if (sh && (x >> (64 - sh))) atomicOr(&win[rel + 1], x >> (64 - sh));
+                }
+                if (x2) {
+                    atomicOr(&win2[rel], x2 << sh);
+                    if (sh && (x2 >> (64 - sh))) atomicOr(&win2[rel + 1], x2 >> (64 - sh));
+                }
+            }
+        } else if (x) {                                            // (a word without boundaries adds nothing)
+            const lk_u64 c = lk_pext64(x, m);
+            atomicOr(&win[rel], c << sh);
+            if (sh && (c >> (64 - sh))) atomicOr(&win[rel + 1], c >> (64 - sh));
         }
-        const int cnt = __popcll(mb);
-        int inc = cnt;
+    }
+    if (tid < 64) {
+        // the bits of the first word that belong to earlier workgroups: the `need` leads in front of this one, nearest word first
+        // (the 63 leads before a tile lie in its previous 4 words in well-formed text; the look-back goes on for as long as
+        // malformed input makes it)
+        int need = (int)(pos0 & 63);
+        for (int64_t back = 0; need > 0; back += 64) {             // wave-uniform; one round unless the input is malformed
+            const int64_t wj = T0 * 64 - 1 - back - lane;
+            if (back > 0) {
+                mb = wj >= 0 ? lead[wj] : 0ull;
+                xb = wj >= 0 ? bmask[wj] : 0ull;
+                xb2 = (TWO && wj >= 0) ? bmask2[wj] : 0ull;
+            } else if (wj < 0) {
+                mb = 0ull; xb = 0ull; xb2 = 0ull;
+            }
+            const int cnt = __popcll(mb);
+            int inc = cnt;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d);
+                if (lane >= d) inc += o;
+            }
+            const int before = inc - cnt;                           // leads between my word and the workgroup's first
+            if (cnt > 0 && before < need) {
+                const int take = min(cnt, need - before);           // my top `take` leads
+                lk_u64 c = xb, c2 = xb2;
+                if (TWO) lk_pext64x2(&c, &c2, mb); else c = lk_pext64(c, mb);
+                c >>= (cnt - take);
+                if (c) atomicOr(&win[0], c << (need - before - take));
+                if (TWO) {
+                    c2 >>= (cnt - take);
+                    if (c2) atomicOr(&win2[0], c2 << (need - before - take));
+                }
+            }
+            need -= __shfl(inc, 63);
+            if (T0 * 64 - 1 - back - 63 <= 0) break;                // the batch begins here (cannot happen with need > 0: ranks are exact)
         }
-        const int before = inc - cnt;                               // leads between my word and the tile
-        if (cnt > 0 && before < need) {
-            const int take = min(cnt, need - before);               // my top `take` leads
-            const uint64_t c = lk_pext64(xb, mb) >> (cnt - take);
-            if (c) atomicOr(&win[0], c << (need - before - take));
-        }
-        need -= __shfl(inc, 63);
-        if (w0 - 1 - back - 63 <= 0) break;                         // the batch begins here (cannot happen with need > 0: ranks are exact)
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int n_out = (int)(own_end - ow0);                         // 1..65
-    for (int j = lane; j < n_out; j += 64) out_mask[ow0 + j] = win[j];
+    __syncthreads();
+    const int n_out = (int)(own_end - ow0);                         // 1 .. kCompressWords + 1
+    for (int j = tid; j < n_out; j += kCompressWaves * 64) {
+        out_mask[ow0 + j] = win[j];
+        if (TWO) out_mask2[ow0 + j] = win2[j];
+    }
 }
 
-hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* lead, const int64_t* tile_rank, const int64_t* tile_cnt,
-                                const uint16_t* word_pref, int64_t n_words, int64_t total_bytes, const int64_t* byte_off, int64_t n_str,
-                                const int64_t* total_cps_dev, uint64_t* out_mask, int64_t cap_words, int64_t* cp_row_off, int* odd,
-                                hipStream_t st) {
+hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* bmask2, const uint64_t* lead, const int64_t* tile_rank,
+                                const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words, int64_t total_bytes,
+                                const int64_t* byte_off, int64_t n_str, const int64_t* total_cps_dev, uint64_t* out_mask,
+                                uint64_t* out_mask2, int64_t cap_words, int64_t* cp_row_off, int* odd, hipStream_t st) {
     const int64_t n_tiles = (n_words + 63) / 64;
-    const unsigned nb_tiles = (unsigned)((n_tiles + 3) / 4), nb_rows = (unsigned)((n_str + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_lead_compress, dim3(nb_tiles + nb_rows), dim3(256), 0, st, bmask, lead, tile_rank, tile_cnt, word_pref, n_words,
-                       total_bytes, byte_off, n_str, total_cps_dev, out_mask, cap_words, cp_row_off, odd, nb_tiles);
+    const unsigned nb_tiles = (unsigned)((n_tiles + kCompressWaves - 1) / kCompressWaves);
+    const unsigned nb_rows = (unsigned)((n_str + 1 + kCompressWaves * 64 - 1) / (kCompressWaves * 64));
+    const dim3 grid(nb_tiles + nb_rows), block(kCompressWaves * 64);
+    if (bmask2)
+        hipLaunchKernelGGL(k_lead_compress<true>, grid, block, 0, st, bmask, bmask2, out_mask2, lead, tile_rank, tile_cnt, word_pref, n_words,
+                           total_bytes, byte_off, n_str, total_cps_dev, out_mask, cap_words, cp_row_off, odd, nb_tiles);
+    else
+        hipLaunchKernelGGL(k_lead_compress<false>, grid, block, 0, st, bmask, bmask2, out_mask2, lead, tile_rank, tile_cnt, word_pref, n_words,
+                           total_bytes, byte_off, n_str, total_cps_dev, out_mask, cap_words, cp_row_off, odd, nb_tiles);
     return hipGetLastError();
 }
 

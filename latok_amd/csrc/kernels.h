@@ -188,10 +188,11 @@ hipError_t launch_counts_scatter(int kind, bool out32, const uint64_t* bits, con
                                  int64_t total, const int64_t* row_off, int64_t n_str, const int64_t* tile_first, void* out,
                                  const int64_t* n_items_dev, int64_t cap, void* counts, int* err, hipStream_t st, DoneSignal done = DoneSignal{nullptr, 0, nullptr});
 // code-point boundary mask + code-point row offsets from the byte-space mask and the lead-byte mask of a UTF-8 batch
-hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* lead, const int64_t* tile_rank, const int64_t* tile_cnt,
-                                const uint16_t* word_pref, int64_t n_words, int64_t total_bytes, const int64_t* byte_off, int64_t n_str,
-                                const int64_t* total_cps_dev, uint64_t* out_mask, int64_t cap_words, int64_t* cp_row_off, int* odd,
-                                hipStream_t st);
+// (bmask2 / out_mask2: optionally a second mask -- the SPACE plane -- packed the same way, for token spans in code-point units)
+hipError_t launch_lead_compress(const uint64_t* bmask, const uint64_t* bmask2, const uint64_t* lead, const int64_t* tile_rank,
+                                const int64_t* tile_cnt, const uint16_t* word_pref, int64_t n_words, int64_t total_bytes,
+                                const int64_t* byte_off, int64_t n_str, const int64_t* total_cps_dev, uint64_t* out_mask,
+                                uint64_t* out_mask2, int64_t cap_words, int64_t* cp_row_off, int* odd, hipStream_t st);
 hipError_t launch_tile_scan(const int64_t* tile_cnt, int64_t n_tiles, int64_t* tile_rank, unsigned long long* chain, unsigned* ticket,
                             unsigned epoch, int64_t* total_dev, int64_t* total_host, int* err, hipStream_t st);
 int64_t utf8_blocks(int64_t total_bytes);   // 4 KiB blocks of the chunk-parallel UTF-8 decoder

@@ -181,6 +181,7 @@ constexpr int kSliceCopyBytes = kSliceHiOff + 1024;      // {lo[256], pad, hi[25
 constexpr int kSliceLutBytes = 8 * kSliceCopyBytes;      // copy j = entries << j
 static_assert(kSliceLutBytes + 256 <= kTablesLdsBytes, "the Latin-1 tables live where the Unicode tables would");
 
+constexpr int kSlicePin = 2;   // groups of 8 chars whose lookups are requested together (slice_lut64)
 __device__ __forceinline__ void slice_lut64(const uint32_t (&d)[16], const uint8_t* lut, lk_u64 (&plane)[8]) {
     uint32_t lo[8], hi[8];
 #pragma unroll
@@ -196,14 +197,11 @@ __device__ __forceinline__ void slice_lut64(const uint32_t (&d)[16], const uint8
         }
         lo[g] = l;
         hi[g] = h;
-#ifndef LATOK_AB_SLICE_PIN
-#define LATOK_AB_SLICE_PIN 2
-#endif
-        // pin the words every LATOK_AB_SLICE_PIN groups: without it the compiler requests all 128 lookups first (one result
+        // pin the words every kSlicePin groups: without it the compiler requests all 128 lookups first (one result
         // register each, spills) and ORs them afterwards
-        if ((g + 1) % LATOK_AB_SLICE_PIN == 0) {
+        if ((g + 1) % kSlicePin == 0) {
 #pragma unroll
-            for (int q = g + 1 - LATOK_AB_SLICE_PIN; q <= g; ++q) asm volatile("" : "+v"(lo[q]), "+v"(hi[q]));
+            for (int q = g + 1 - kSlicePin; q <= g; ++q) asm volatile("" : "+v"(lo[q]), "+v"(hi[q]));
         }
     }
     lk_planes_from_groups(lo, hi, plane);
@@ -393,11 +391,9 @@ __device__ __forceinline__ uint32_t bytes_halo_load(const uint8_t* __restrict__ 
     return hb;
 }
 
-#ifndef LATOK_AB_CPS_PREFETCH
-#define LATOK_AB_CPS_PREFETCH 2
-#endif
+constexpr int kCpsPrefetchRows = 2;   // rows (1 KiB) of the wave's next UTF-32 tile requested before phase 2 of the current one
 struct CpsPrefetch {
-    u32x4 v[LATOK_AB_CPS_PREFETCH > 0 ? LATOK_AB_CPS_PREFETCH : 1];
+    u32x4 v[kCpsPrefetchRows];
     bool valid;
 };
 
@@ -789,15 +785,6 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
         }
     }
     LATOK_STAMP(4);
-#ifdef LATOK_AB_NO_BLOCK
-    if (mode_writes_bits(MODE)) {   // ablation: no block mask at all (wrong results, timing only)
-        const lk_u64 o = loc.raw | loc.sym | B;
-        if (write_summary && lane == 0) *summ_l = make_int4(0, 0, 0, 0);
-        if (!DEFER && base < total) P.bits_out[base >> 6] = o;
-        wave_lds_sync();
-        return o;
-    }
-#endif
     lk_fwd fw = lk_forward(loc.start, loc.S, B);
 
     // forward: inclusive (max,+) scan of the per-word queue transfer functions over the 64 lanes
@@ -841,9 +828,6 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
                              (tail_sym << 29) | (no_patch << 30);
             *summ_l = make_int4(tile_fn.a, tile_fn.b, head, geom);   // LDS; the segment publishes them in one burst
-#ifdef LATOK_AB_SUMM_PER_TILE
-            P.summ[t] = *summ_l;
-#endif
         }
     }
 
@@ -949,7 +933,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
 // (a vmcnt(0) on every path in front of the requests; the pass that inserts waits otherwise drains the queue at the first
 // register it loses track of, and the prefetch silently does nothing).  Measured on C2, same box, twice: kernel 96.1-96.3 ->
 // 94.4-94.5 us with R = 2 (R = 1: 93.9-94.1, R = 4: 95-99), step 106.6-107.3 -> 105.0-105.1; C3 / C4 / C5 within their noise
-// (profiles/r03_ab_headline_prefetch.txt).  -DLATOK_AB_CPS_PREFETCH=0: off.
+// (profiles/r03_ab_headline_prefetch.txt).
 
 template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
@@ -973,11 +957,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
 
     // small loads first, so that their latency flies together with the 16 KiB of code points: the start offsets of
     // the next 64 strings and the three halo characters
-#ifdef LATOK_AB_NO_RO
-    int64_t ro = INT64_MAX;
-#else
     int64_t ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
-#endif
     uint32_t halo_cp = 0xFFFFFFFFu;   // out of range -> class 0
     if (MODE != kModeBlockMask && !mode_is_bytes(MODE) && lane < 3) {
         const int64_t hp = lane == 0 ? t0 - 1 : t0 + kTile + (lane - 1);
@@ -1048,18 +1028,13 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-#ifdef LATOK_AB_PLAIN_LOADS
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = src[64 * i];
-#else
-        constexpr int R = LATOK_AB_CPS_PREFETCH;
+        constexpr int R = kCpsPrefetchRows;
         const bool pre = R > 0 && pf && pf->valid;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (i < R && pre) v[i] = pf->v[i < R ? i : 0];
             else v[i] = __builtin_nontemporal_load(src + 64 * i);
         }
-#endif
         LATOK_STAMP(1);
         uint32_t* codes = P.codes_out ? reinterpret_cast<uint32_t*>(P.codes_out + t0) + lane : nullptr;   // wave-uniform
 #pragma unroll
@@ -1091,7 +1066,6 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     if (lane == 0) L.bw[64] = 0;
     LATOK_STAMP(2);
     wave_lds_sync();
-#ifndef LATOK_AB_NO_BW
     for (;;) {
         const int64_t rel = ro - t0;
         if (rel >= 0 && rel < kTile + 64) atomicOr(&L.bw[rel >> 6], 1ull << (rel & 63));
@@ -1101,25 +1075,18 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         ro = idx0 + lane <= P.n_str ? P.row_off[idx0 + lane] : INT64_MAX;
     }
     wave_lds_sync();
-#endif
     LATOK_STAMP(3);
-#if LATOK_AB_CPS_PREFETCH > 0
     if (MODE == kModeBits && pf) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load of this tile has been consumed -- said on every path
         pf->valid = false;
-#ifdef LATOK_AB_CPS_PREFETCH_ASCII_ONLY
-        const bool want = !tile_not_ascii;    // non-ASCII tiles (two LDS lookups per char in phase 1) measured slower with it
-#else
         const bool want = true;
-#endif
         if (want && t_next >= 0 && (t_next + 1) * kTile <= total) {
             const u32x4* nsrc = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
 #pragma unroll
-            for (int i = 0; i < LATOK_AB_CPS_PREFETCH; ++i) pf->v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
+            for (int i = 0; i < kCpsPrefetchRows; ++i) pf->v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
             pf->valid = true;
         }
     }
-#endif
 
     return tile_phase2<MODE, DEFER, SMALL>(P, L, t, q_in, tail_zero, write_summary, summ_l, lane, raw_stage, ascii_tile
 #ifdef LATOK_STAMPS
@@ -1276,15 +1243,10 @@ constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsT
 // Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
 // per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
 // buffers of waves 12..15 sit behind the rest of the map, so that every other offset is the same for all kernels.
-#ifndef LATOK_AB_LATIN1_WPB
-#define LATOK_AB_LATIN1_WPB 16
-#endif
-#ifndef LATOK_AB_UCS2_WPB
-#define LATOK_AB_UCS2_WPB 16
-#endif
+constexpr int kNarrowWPB = 16;   // Latin-1 / UCS-2 tile kernels: 4 waves per SIMD (<= 128 VGPRs)
 constexpr int tile_wpb(int mode) {
-    return mode_base(mode) == kModeLatin1 && !mode_rules(mode) ? LATOK_AB_LATIN1_WPB
-         : (mode_base(mode) == kModeUcs2 && !mode_rules(mode) ? LATOK_AB_UCS2_WPB : kWPB);   // (the rule interpreter needs > 128 VGPRs)
+    return mode_base(mode) == kModeLatin1 && !mode_rules(mode) ? kNarrowWPB
+         : (mode_base(mode) == kModeUcs2 && !mode_rules(mode) ? kNarrowWPB : kWPB);   // (the rule interpreter needs > 128 VGPRs)
 }
 constexpr int lds_total_tiles(int mode) { return lds_total(mode) + (tile_wpb(mode) > kWPB ? (tile_wpb(mode) - kWPB) * kWaveLdsBytes : 0); }
 static_assert(lds_total_tiles(kModeLatin1) <= 160 * 1024 && lds_total_tiles(kModeUcs2) <= 160 * 1024, "LDS budget of one CU");
@@ -1389,11 +1351,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) {
             if (j < slot) {
                 const int64_t w = (T0 + k_first + j * WPB) * 64 + lane;
-#ifdef LATOK_AB_SC1_STORES
-                if (w < n_words) __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.bits_out) + w, obuf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
                 if (w < n_words) P.bits_out[w] = obuf[j];
-#endif
             }
         }
         slot = 0;
@@ -1404,15 +1362,11 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         for (int j = 0; j < 8; ++j) obuf[j] = (j == slot) ? w : obuf[j];
         if (++slot == 8) flush();
     };
-#if LATOK_AB_CPS_PREFETCH > 0
     CpsPrefetch pf;
     pf.valid = false;
-#endif
     for (int k = wave, j = 0; k < n_seg; k += WPB, ++j) {
         const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG
-#if LATOK_AB_CPS_PREFETCH > 0
                                                                       , MODE == kModeBits && !FAST_TAIL ? &pf : nullptr, k + WPB < n_seg ? T0 + k + WPB : (int64_t)-1
-#endif
                                                                       );
         if (kDefer) put(w, k);
 #ifdef LATOK_STAMPS
@@ -1427,9 +1381,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
         Hd64 h = hd_identity();
         if (tid < n_seg) {
             const int4 s = sm[tid];
-#ifndef LATOK_AB_SUMM_PER_TILE
             P.summ[T0 + tid] = s;            // coalesced: 16 B per thread, one burst per segment
-#endif
             f = fn_of(s);
             h.h = s.z; h.c = s.w & 1;
         }
@@ -1740,13 +1692,7 @@ __device__ __forceinline__ void flush_records(const uint8_t* win, int n_rec, uin
     const int n_vec = (n_bytes - head) >> 4;
     for (int i = lane; i < n_vec; i += 64) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(src + head + 16 * i);
-#ifdef LATOK_AB_FEAT_NO_FLUSH
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u) dst[0] = 1;   // ablation (timing only): nothing is written
-#elif defined(LATOK_AB_FEAT_PLAIN_FLUSH)
-        *reinterpret_cast<u32x4*>(dst + head + 16 * i) = v;
-#else
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + head + 16 * i));
-#endif
     }
     const int tail0 = head + 16 * n_vec;
     if (lane < n_bytes - tail0) dst[tail0 + lane] = src[tail0 + lane];
@@ -1945,10 +1891,6 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         }
     }
 
-#ifdef LATOK_AB_FEAT_PREAMBLE_ONLY
-    if (C.v[0] == 0x12345678u && H.v[1] == 0x9abcdef0u) P.features[0] = 1;   // ablation (timing only): keep the preamble alive, stop here
-    return;
-#endif
     // ---- per-word values both forms below need --------------------------------------------------------------------
     const lk_u64 nn = ~LK_PLANE_GET(F, 5) & valid;             // non-SPACE chars of my word
     // the next word's masks (from lane + 1)
@@ -1969,13 +1911,11 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // ~70 64-bit shuffles per token make it the slower form for evenly filled tiles, hence the choice per tile.
     const int maxc = wave_max(lk_popc(x), 0);
     // threshold swept on C2 (word-major 9 % faster) and C3 (token-major 15 % faster): fullest word > 1.5 x steps of 64 tokens
-#ifndef LATOK_AB_FEAT_THRESH
-#define LATOK_AB_FEAT_THRESH 5
-#endif
+    constexpr int kFeatFormThresh = 5;
     // The word-major walk below runs as long as the fullest word (maxc steps of ~160 instructions with the span records), once
     // per window round; the token-major form takes ceil(n_wave / 64) steps of ~300 whatever the spread.
     const int wm_rounds = (n_wave + kFeatRound - 1) / kFeatRound;
-    if (maxc * 2 * wm_rounds > ((n_wave + 63) >> 6) * LATOK_AB_FEAT_THRESH) {
+    if (maxc * 2 * wm_rounds > ((n_wave + 63) >> 6) * kFeatFormThresh) {
         uint8_t* fwin = L.stage;
         uint16_t* codes = reinterpret_cast<uint16_t*>(L.stage + kFeatRoundTm * kFeatRec + 16);   // behind the feature records
         lk_u64 trest = x;
@@ -2069,11 +2009,7 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
     // planes only), then the part of the one token that may reach from the low half into the high half, then the tokens that
     // start in chars 32..63 (high halves only).  Ranks grow in that order, so the records land at consecutive slots.
     uint8_t* win = L.stage;
-#ifdef LATOK_AB_FEAT_NO_SUMS
-    uint32_t rest_lo = 0, rest_hi = 0;   // ablation (timing only): no token walks for the sums
-#else
     uint32_t rest_lo = (uint32_t)x, rest_hi = (uint32_t)(x >> 32);
-#endif
     const uint32_t xb_lo = (uint32_t)xb, xb_hi = (uint32_t)(xb >> 32);
     const uint32_t valid_lo = (uint32_t)valid, valid_hi = (uint32_t)(valid >> 32);
     FeatSums S_str;                       // low-half sums of the straddling token
@@ -2134,9 +2070,6 @@ __device__ __forceinline__ void feature_tile(const FeatParams& P, const TileLds&
         wave_lds_sync();
     }
 
-#ifdef LATOK_AB_FEAT_NO_SPANS
-    return;   // ablation (timing only): no span records
-#endif
     // ---- the span records of the same tokens: {raw start, raw end, stripped start, stripped end}, string relative --------
     // (reference featurize: LaToken.start_idx / end_idx = the raw span, .text = text[stripped]; default_tokenizer.py:173-191)
     OUT* swin = reinterpret_cast<OUT*>(L.stage);
@@ -2534,16 +2467,9 @@ void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs) {
     const int64_t per_cu = (n_tiles + n_cu - 1) / n_cu;
     const int64_t rounds = per_cu > kSegMax ? (per_cu + kSegMax - 1) / kSegMax : 1;
     int64_t s = (n_tiles + (int64_t)n_cu * rounds - 1) / ((int64_t)n_cu * rounds);
-    // A segment's tiles go round-robin over the workgroup's kWPB waves: a length that is not a multiple of kWPB ends in a
-    // round with most waves idle (C2 on 256 CUs: 123 tiles = ten rounds + one with 3 of 12 waves).  Long segments are
-    // rounded up to whole rounds -- a few CUs fewer, every wave busy to the end (C2: 132 tiles on 237 CUs, kernel -3 %);
-    // short ones (< 8 rounds) keep the exact split: there the CUs matter more than the last round.
-    static const int ab_plan = [] { const char* e = getenv("LATOK_AB_PLAN"); return e ? atoi(e) : 0; }();
-    if (ab_plan == 1 && s >= 8 * kWPB) s = (s + kWPB - 1) / kWPB * kWPB;
-    if (ab_plan == 2 && s >= 8 * kWPB) {   // nearest multiple, as long as the segments still fit one round of workgroups on the chip
-        const int64_t dn = s / kWPB * kWPB, up = dn + kWPB;
-        s = (s - dn <= up - s && (n_tiles + dn - 1) / dn <= (int64_t)n_cu + 24) ? dn : up;
-    }
+    // (A segment's tiles go round-robin over the workgroup's kWPB waves, so a length that is not a multiple of kWPB ends in a
+    // round with most waves idle.  Rounding long segments to whole rounds was measured for the blocking calls and not kept;
+    // the flow picks, among three CU shares, one whose last round is at least half full: api.cpp run_pipeline.)
     if (s < kWPB) s = kWPB;
     if (s > kSegMax) s = kSegMax;
     *seg_tiles = (int)s;
@@ -2557,13 +2483,6 @@ static inline int grid_for(const SplitParams& P, int n_cu) {
 
 hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
-#ifdef LATOK_AB_COOP
-    if (mode == kModeBits) {   // experiment: what a cooperative launch of the same kernel costs
-        SplitParams Pc = P;
-        void* args[] = {&Pc};
-        return hipLaunchCooperativeKernel((const void*)(k_tiles_main<kModeBits>), grid, block, args, 0, st);
-    }
-#endif
     const bool fast_tail = P.n_tiles <= kFastTailTiles;
     if (mode == kModeBits && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeBits, true>), grid, block, 0, st, P);
     else if (mode == kModeRules && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeRules, true>), grid, block, 0, st, P);

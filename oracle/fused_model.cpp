@@ -420,7 +420,13 @@ extern "C" void fused_ascii_codes(const uint8_t* bytes64, uint8_t* planes_codes_
 }
 
 // test hook: lane_math.h lk_pext64 (code-point results from byte-space masks: compact_kernels.hip, k_lead_compress)
-extern "C" unsigned long long fused_pext64(unsigned long long x, unsigned long long m) { return lk_pext64(x, m); }
+extern "C" unsigned long long fused_pext64(unsigned long long x, unsigned long long m) {
+    lk_u64 a = x, b = ~x;                       // the two-word form must give the same (checked here for x and its complement)
+    lk_pext64x2(&a, &b, m);
+    const lk_u64 want = lk_pext64(x, m);
+    if (a != want || b != lk_pext64(~x, m)) return ~want;
+    return want;
+}
 
 // test hook: lane_math.h lk_lead_entry_of + lk_lead_hi_lo (the byte-space kernel's table-driven decode of multi-byte chars):
 // W = 4 bytes from a lead byte >= 0xC0 on; returns 1 when the sequence is cut short, else 0 with *cp = (hi << 7) | lo

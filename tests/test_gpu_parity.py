@@ -744,6 +744,15 @@ def test_utf8_code_point_mask_without_a_utf32_copy(gpu, oracle):
         got, got_row = batch.split_mask_utf8_csr(u8, boff)
         assert np.array_equal(got_row, row), i
         assert np.array_equal(got, want), i
+        # offsets and token spans in code-point units take the same road (the compaction runs on the packed masks)
+        for dtype in (np.int64, np.int32):
+            c1, o1 = batch.split_offsets_utf8_csr(u8, boff, dtype=dtype)
+            c2, o2 = batch.split_offsets_csr(cps, row, dtype=dtype)
+            assert np.array_equal(c1, c2) and np.array_equal(o1, o2), (i, dtype)
+            t1, s1 = batch.token_spans_utf8_csr(u8, boff, dtype=dtype)
+            t2, s2 = batch.token_spans_csr(cps, row, dtype=dtype)
+            assert np.array_equal(t1, t2) and np.array_equal(s1, s2), (i, dtype)
+        assert np.array_equal(o1, np.concatenate([np.nonzero(bits_to_bool(want, int(row[-1]))[row[k]:row[k + 1]])[0] for k in range(len(texts))]))
         # device pointers, the mask buffer exactly as large as the code points need (fewer words than the bytes have)
         words = (int(row[-1]) + 63) // 64
         d = {k: gpu.latok_dev_alloc(n + 64) for k, n in (("u8", u8.nbytes), ("boff", boff.nbytes), ("mask", words * 8), ("row", row.nbytes))}
@@ -797,6 +806,12 @@ def test_utf8_code_point_mask_without_a_utf32_copy(gpu, oracle):
         got, got_row = batch.split_mask_utf8_csr(u8, boff)
         assert np.array_equal(got_row, row), it
         assert np.array_equal(got, batch.split_mask_batch(cps, row)), it
+        c1, o1 = batch.split_offsets_utf8_csr(u8, boff, dtype=np.int32)
+        c2, o2 = batch.split_offsets_csr(cps, row, dtype=np.int32)
+        assert np.array_equal(c1, c2) and np.array_equal(o1, o2), it
+        t1, s1 = batch.token_spans_utf8_csr(u8, boff)
+        t2, s2 = batch.token_spans_csr(cps, row)
+        assert np.array_equal(t1, t2) and np.array_equal(s1, s2), it
     # a sequence cut short by the END OF THE BATCH is U+FFFD too (the staged decoder used to complete it with its own padding)
     for tail in (b"\xc3", b"\xe6\x97", b"\xf0\x9f\xa4", b"x\xf0"):
         blobs = [b"filler words, a #tag and http://x.y/z "] * 8000 + [b"end " + tail]

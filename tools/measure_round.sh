@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-3 measurement batch (run on the GPU box through gpurun).  Everything lands under gpurun_out/final3/ ; what is to
-# be judged is copied into profiles/ afterwards (tools/collect_r03.sh).  A step killed at its limit ends the batch.
-#   tools/final_measure_r03.sh [part]     part = bench | paths | pmc | all (default all)
+# A round's measurement batch (run on the GPU box through gpurun).  Everything lands under gpurun_out/measure_<tag>/ ; what is to
+# be judged is copied into profiles/ afterwards (tools/collect_round.sh <tag>).  A step killed at its limit ends the batch.
+#   tools/measure_round.sh <tag> [part]     tag = r04 ...; part = bench | paths | pathstats | pmc | all (default all)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/final3b
+TAG=${1:?round tag, e.g. r04}; shift
+O=$R/gpurun_out/measure_$TAG
 mkdir -p $O
 cd $R
 PART=${1:-all}
@@ -26,6 +27,7 @@ step bench_c3 300 python3 bench.py --workload C3 --steps 20 --warmup 3 --no-cpu-
 step bench_c4 400 python3 bench.py --workload C4 --steps 5 --warmup 2 --no-cpu-baseline
 step bench_c5 400 python3 bench.py --workload C5 --steps 5 --warmup 2 --no-cpu-baseline
 step bench_c2_serial 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --in-flight 1 --no-cpu-baseline
+step bench_c2_shared_input 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --shared-input --no-cpu-baseline
 step bench_n2_turns 300 python3 bench.py --gpus 2 --devices 0,0 --take-turns --steps 20 --warmup 5
 step bench_n2_shared 300 python3 bench.py --gpus 2 --devices 0,0 --steps 20 --warmup 5 --no-cpu-baseline
 step bench_n4_c5_strong_turns 400 python3 bench.py --gpus 4 --devices 0,0,0,0 --take-turns --workload C5 --strings 400 --steps 5 --warmup 2 --no-cpu-baseline
@@ -46,22 +48,22 @@ cp /tmp/prof_b/b_kernel_stats.csv $O/kernel_stats_bench_c2.csv 2>/dev/null || fi
 # (2) the default command (batch flow): tile kernels that overlap another one listed apart
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_bf -o b -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_c2_flow_under_rocprof.json 2>/dev/null
 echo "rocprof bench (default, flow) rc=$?" | tee -a $LOG
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_bf -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (default: batch flow, two batches in flight); round 3" --split-overlap > $O/kernel_stats_bench_c2_flow.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_bf -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline (default: batch flow, two batches in flight); round $TAG" --split-overlap > $O/kernel_stats_bench_c2_flow.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
 echo "rocprof paths c2 rc=$?" | tee -a $LOG
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round 3" > $O/paths_kernel_stats.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round $TAG" > $O/paths_kernel_stats.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p3 -o paths -- python3 $R/tools/path_bench.py --workload C3 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
 echo "rocprof paths c3 rc=$?" | tee -a $LOG
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round 3" > $O/paths_kernel_stats_c3.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round $TAG" > $O/paths_kernel_stats_c3.txt
 cd $R
 fi
 if [ "$PART" = "pathstats" ]; then
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_p /tmp/prof_p3
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o paths -- python3 $R/tools/path_bench.py --workload C2 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round 3" > $O/paths_kernel_stats.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C2 --iters 5 --paths <the blocking paths> (1 MI355X, C2 = 1 M ASCII strings; the flow paths are left out: overlapped launches carry queue time in their duration); round $TAG" > $O/paths_kernel_stats.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_p3 -o paths -- python3 $R/tools/path_bench.py --workload C3 --iters 5 --paths mask,offsets,offsets32,spans,spans32,features,features32,utf8_mask,utf8_offsets,utf8_spans,bytes_mask,bytes_offsets,bytes_spans,rules_mask,kind_mask,kind_offsets,kind_offsets32,kind_spans,kind_spans32 > /dev/null 2>&1
-python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round 3" > $O/paths_kernel_stats_c3.txt
+python3 $R/tools/rocpd_stats.py $(find /tmp/prof_p3 -name '*results.db' | head -1) "rocprofv3 --kernel-trace --stats -- python3 tools/path_bench.py --workload C3 --iters 5 --paths <the blocking paths> (1 MI355X, C3 = 1 M mixed-Unicode strings); round $TAG" > $O/paths_kernel_stats_c3.txt
 cd $R
 fi
 if [ "$PART" = "pmc" ] || [ "$PART" = "all" ]; then
@@ -83,6 +85,8 @@ pmc c3 300 $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline --su
 pmc c4 500 $R/bench.py --workload C4 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
 pmc c5 500 $R/bench.py --workload C5 --steps 3 --warmup 1 --no-cpu-baseline --sustain-s 0 --in-flight 1
 pmc c2_flow 300 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0
+pmc c2_flow_shared 300 $R/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0 --shared-input
+pmc c3_flow 300 $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline --sustain-s 0
 pmc paths 300 $R/tools/path_bench.py --workload C2 --iters 3 --paths bytes_mask,kind_mask,offsets32,spans32,features32
 pmc paths_c3 300 $R/tools/path_bench.py --workload C3 --iters 3 --paths bytes_mask,utf8_mask,kind_mask
 cd $R

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build profiles/r02_pmc_summary.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one counter per pass, as
+"""Build profiles/<round>_pmc_summary.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (one counter per pass, as
 MI355X_MICROARCH.md prescribes: the two do not fit one pass).  usage:
     pmc_traffic_summary.py out.json  label:workload:total_chars:n_strings:fetch.csv:write.csv:"command"  [...]
 Per kernel of each run: average FETCH_SIZE / WRITE_SIZE (KiB) per launch and the HBM bytes derived from them with the
@@ -33,6 +33,8 @@ def main():
            "runs": []}
     for spec in sys.argv[2:]:
         label, workload, total_chars, n_str, fcsv, wcsv, command = spec.split(":", 6)
+        label, *extras = label.split("|")          # "bench|in_flight=2|distinct_inputs=1": what bench.py's traffic_source matches on
+        meta = {k: int(v) for k, v in (e.split("=") for e in extras)}
         f, w = averages(fcsv, "FETCH_SIZE"), averages(wcsv, "WRITE_SIZE")
         for k in sorted(set(f) | set(w)):
             fk, nf = f.get(k, (0.0, 0))
@@ -41,7 +43,7 @@ def main():
             out["runs"].append({"label": label, "workload": workload, "total_chars": int(total_chars), "n_strings": int(n_str),
                                 "kernel": short(k).split("<")[0], "kernel_full": short(k), "launches_averaged": [nf, nw],
                                 "FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk, "hbm_read_bytes_per_launch": rd,
-                                "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "command": command})
+                                "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "command": command, "launches": min(nf, nw), **meta})
     with open(sys.argv[1], "w") as fo:
         json.dump(out, fo, indent=1)
     for r in out["runs"]:

@@ -611,32 +611,6 @@ __device__ __forceinline__ void bytes_word_context(const TileLds& L, int lane, l
     }
     hb->prev = *own_code;
 }
-// the general byte-space rules of one word, from the staging buffer (cold: tiles with a stray continuation byte behind an
-// ASCII rule char)
-__device__ __attribute__((noinline)) void bytes_rules_general_cold(const uint8_t* stage, const uint8_t* halo, const lk_u64* bw, int lane,
-                                                                   lk_local* out, lk_u64* space_out) {
-    TileLds L;
-    L.stage = const_cast<uint8_t*>(stage);
-    L.halo = const_cast<uint8_t*>(halo);
-    L.bw = const_cast<lk_u64*>(bw);
-    uint32_t d[16];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4 q = *reinterpret_cast<const uint4*>(stage + 80u * lane + 16u * k);
-        d[4 * k + 0] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
-    }
-    lk_u64 plane[8];
-    lk_bitslice64(d, plane);
-    const lk_u64 C = lk_take_cont_plane(plane);
-    lk_halo_bytes hb;
-    bool next_has_cont;
-    uint32_t own_code;
-    int own_left;
-    bytes_word_context(L, lane, &hb, &next_has_cont, &own_code, &own_left);
-    lk_smear_planes<0x37u>(plane, C, own_code, own_left);
-    *out = lk_rules_bytes_general(plane, C, hb, bw[lane], space_out);
-}
-
 // Phase 2 of a tile (lane = one 64-char word): everything after the code bytes, the halo codes and the string-start
 // words are in the wave's LDS buffer L.  (A separate function because a producer / consumer variant of the kernel ran
 // the two phases in different waves; see DESIGN.md, negative results.)
@@ -770,12 +744,11 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
                 loc = lk_rules_bytes_fast(plane, C, hb, B, &space_plane);
             } else {
                 // a continuation byte right after '#' '$' '^' '@' ':' '/' '.' somewhere in the tile (malformed UTF-8): the
-                // general form, as a real call so that its registers stay out of the loop (it starts again from the staging bytes)
-                lk_local tmp;
-                lk_u64 sp;
-                bytes_rules_general_cold(L.stage, L.halo, L.bw, lane, &tmp, &sp);
-                loc = tmp;
-                space_plane = sp;
+                // general form.  (Inlined: round 3 had it as a __noinline__ call for the sake of the hot loop's registers, which
+                // cost a 240-byte scratch frame; without the write-combining buffer the kernel holds both forms in 168 VGPRs, 0 B scratch.)
+                lk_smear_planes<0x37u>(plane, C, own_code, own_left);
+                hb.prev = own_code;
+                loc = lk_rules_bytes_general(plane, C, hb, B, &space_plane);
             }
         } else if (mode_rules(MODE)) {
             loc = lk_rules_generic(plane, h, B, Bn, P.rules, MODE == kModeValuesRules ? &counts : nullptr);

@@ -620,13 +620,13 @@ def measure_shard(sh, args, gate, phase):
     sh.build()
     sh.warmup(args.warmup)
     sh.warmup_flow(args.warmup)
-    n_settle = sh.settle(args.settle_s)
-    chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
     dev = getattr(sh, "device", 0)
-    sens_before = gpu_sensors(dev)
+    sens_before = gpu_sensors(dev)                       # (before the settle passes: nothing may sit between them and the timed region --
+    n_settle = sh.settle(args.settle_s)                  # a few ms of sysfs reads there would let the clocks drop again)
+    chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))      # every shard is resident and warm before anyone's clock starts
     with phase():
         rec = sh.timed(args.steps, None if args.take_turns else gate)
-    rec["sensors"] = {"before_timed_region": sens_before, "after_timed_region": gpu_sensors(dev)}
+    rec["sensors"] = {"before_settle_passes": sens_before, "after_timed_region": gpu_sensors(dev)}
     serial = None
     if sh.flow:   # the same K steps one batch at a time (what `value` was before the batch flow), beside the headline
         chk(lib.latok_gate_wait(gate, GATE_TIMEOUT_S))
@@ -737,12 +737,12 @@ def run_under_launcher(api, args, rank, world, local_rank):
         sh.build()
         sh.warmup(args.warmup)
         sh.warmup_flow(args.warmup)
+        sens_before = gpu_sensors(device)
         n_settle = sh.settle(args.settle_s)
         dist.barrier()
-        sens_before = gpu_sensors(device)
         with _Barrier("timed"):
             rec = sh.timed(args.steps, None)
-        rec["sensors"] = {"before_timed_region": sens_before, "after_timed_region": gpu_sensors(device)}
+        rec["sensors"] = {"before_settle_passes": sens_before, "after_timed_region": gpu_sensors(device)}
         rec["host"] = pin
         serial = None
         if sh.flow:

@@ -398,7 +398,7 @@ def test_bench_line_names_numa_node_and_sensors_of_every_rank(monkeypatch):
     line = _run(["--gpus", "8"] + BASE, FakeApi(n_dev=8))
     assert sorted(seen) == list(range(8))
     assert [(x["rank"], x["device"], x["numa_node"], x["pinned"]) for x in line["ranks"]] == [(r, r, r // 4, True) for r in range(8)]
-    assert line["sensors_rank0"]["before_timed_region"]["sclk_mhz"] == 2400 and line["sensors_rank0"]["after_timed_region"]["power_w"] == 600.0
+    assert line["sensors_rank0"]["before_settle_passes"]["sclk_mhz"] == 2400 and line["sensors_rank0"]["after_timed_region"]["power_w"] == 600.0
     seen.clear()
     line = _run(["--gpus", "2", "--no-pin"] + BASE, FakeApi(n_dev=2))
     assert seen == [] and [x["pinned"] for x in line["ranks"]] == [False, False]

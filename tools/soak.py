@@ -32,6 +32,8 @@ REGIMES = [
     # at most one tile: the single-launch path of small host batches (k_small_batch: offsets, spans, featurize sums)
     ("mixed", (1, 40), (0, 100)), ("words", (1, 8), (0, 500)), ("bmp", (1, 30), (0, 130)), ("starts", (1, 500), (0, 8)),
     ("rare_space_at", (1, 2), (1000, 2040)),
+    # beyond the small-batch size in UTF-8 bytes: code-point results from byte space (no UTF-32 copy), the chunk-parallel paths
+    ("mixed", (2500, 6000), (0, 200)), ("bmp", (1500, 4000), (0, 300)), ("words", (3, 8), (60000, 120000)),
 ]
 
 
@@ -261,6 +263,15 @@ def main():
                 assert np.array_equal(bo, np.concatenate(exp_b)), "byte offsets differ: " + tag
                 cb, crow = batch.split_mask_utf8_csr(u8, boff)
                 assert np.array_equal(crow, row) and np.array_equal(cb, bits), "code-point UTF-8 path differs: " + tag
+                # offsets and token spans in code-point units (large batches: the compaction runs on masks packed from byte space)
+                cc, co = batch.split_offsets_utf8_csr(u8, boff, dtype=dt)
+                assert np.array_equal(cc, counts) and np.array_equal(co, offs), "code-point UTF-8 offsets differ: " + tag
+                tc, ts = batch.token_spans_utf8_csr(u8, boff, dtype=dt)
+                if ws is not None:
+                    assert np.array_equal(tc, wc) and np.array_equal(ts, ws), "code-point UTF-8 token spans differ: " + tag
+                else:
+                    gc2, gs2 = batch.token_spans_csr(cps, row, dtype=dt)      # (the UTF-32 path: checked against the oracle on the smaller batches)
+                    assert np.array_equal(tc, gc2) and np.array_equal(ts, gs2), "code-point UTF-8 token spans differ from the UTF-32 path: " + tag
                 if rules is not None:
                     # run-time rule tables in byte space (k_tiles_main<kModeBytesRules>) and through the code-point UTF-8 path
                     rflags = np.zeros(u8.size, bool)

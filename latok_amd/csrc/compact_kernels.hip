@@ -479,8 +479,9 @@ __global__ __launch_bounds__(scatter_waves(KIND) * 64) void k_counts_scatter(
 // output words) and leave as whole words.  Every output word is written exactly once, by the workgroup that holds the lead of
 // its LAST bit (the batch's final, partial word: by the last workgroup with a lead): the bits of a workgroup's first word that
 // belong to earlier ones are recomputed by its first wave from the words in front of it.  No atomics on global memory, no
-// cleared output (two global atomics per tile cost 40 of 110 us on C3); the kernel is bound by the pext (~190 VALU per word
-// and mask: one wave per tile with a look-back pext of its own ran 106 us on C3).  Role 2 (the workgroups behind): one thread
+// cleared output (two global atomics per tile cost 40 of 110 us on C3); the kernel is bound by the pext: through a 256-byte table
+// of 4-bit pexts in LDS (~100 VALU per word; the five-round arithmetic compress: ~256, 80 us on C3; one wave per tile with a
+// look-back pext of its own: 106 us).  Role 2 (the workgroups behind): one thread
 // per row offset.
 // *odd is raised when the byte-space model and the decoder's model of MALFORMED input differ: a continuation byte with no lead
 // byte within the 3 bytes before it, or at the start of a string (the host then takes the staged decoder instead).
@@ -508,7 +509,9 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
     // The workgroup takes kCompressWaves consecutive tiles; their packed chunks meet in ONE window in LDS, so only the
     // workgroup's first output word needs bits from in front of it (and only its last, partial one is left to the next).
     __shared__ unsigned long long win_s[TWO ? 2 : 1][kCompressWords + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t pext_tab[256];       // lk_pext4_entry: 4-bit pexts (lane_math.h)
     const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 256) pext_tab[tid] = lk_pext4_entry((uint32_t)tid);
     const int64_t n_tiles = (n_words + 63) >> 6;
     const int64_t T0 = (int64_t)blockIdx.x * kCompressWaves;
     const int64_t T1 = min(T0 + kCompressWaves, n_tiles) - 1;      // the workgroup's last tile
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
         const int rel = (int)((pos >> 6) - ow0), sh = (int)(pos & 63);
         if (TWO) {
             if (x | x2) {
-                lk_pext64x2(&x, &x2, m);
+                lk_pext64_lut<true>(&x, &x2, m, pext_tab);
                 if (x) {
                     atomicOr(&win[rel], x << sh);
                     if (sh && (x >> (64 - sh))) atomicOr(&win[rel + 1], x >> (64 - sh));
@@ -569,7 +572,8 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
                 }
             }
         } else if (x) {                                            // (a word without boundaries adds nothing)
-            const lk_u64 c = lk_pext64(x, m);
+            lk_u64 c = x, unused = 0;
+            lk_pext64_lut<false>(&c, &unused, m, pext_tab);
             atomicOr(&win[rel], c << sh);
             if (sh && (c >> (64 - sh))) atomicOr(&win[rel + 1], c >> (64 - sh));
         }
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
             if (cnt > 0 && before < need) {
                 const int take = min(cnt, need - before);           // my top `take` leads
                 lk_u64 c = xb, c2 = xb2;
-                if (TWO) lk_pext64x2(&c, &c2, mb); else c = lk_pext64(c, mb);
+                lk_pext64_lut<TWO>(&c, &c2, mb, pext_tab);
                 c >>= (cnt - take);
                 if (c) atomicOr(&win[0], c << (need - before - take));
                 if (TWO) {

@@ -73,7 +73,7 @@ LATOK_HD lk_w lk_w_shr(lk_w x, uint32_t in) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Parallel bit extract (x86 pext; Hacker's Delight 7-4 "compress"): the bits of x at the set positions of m, packed at the
-// bottom in order.  Code-point results from a byte-space mask: m = the lead bytes of a 64-byte word, x = boundary bits at lead
+// bottom in order.  (This arithmetic form is the definition the table form below is tested against; the kernel uses the table.)  Code-point results from a byte-space mask: m = the lead bytes of a 64-byte word, x = boundary bits at lead
 // bytes -> boundary bits of the word's chars (compact_kernels.hip: k_lead_compress).  On 32-bit halves: five rounds each.
 // ---------------------------------------------------------------------------------------------------------------
 LATOK_HD uint32_t lk_pext32(uint32_t x, uint32_t m) {
@@ -100,36 +100,45 @@ LATOK_HD lk_u64 lk_pext64(lk_u64 x, lk_u64 m) {
     const uint32_t lo = lk_pext32((uint32_t)x, (uint32_t)m), hi = lk_pext32((uint32_t)(x >> 32), (uint32_t)(m >> 32));
     return (lk_u64)lo | ((lk_u64)hi << __builtin_popcount((uint32_t)m));   // (a shift by 32 is fine on 64 bits)
 }
-// two words through the same mask: the mask's own work (13 of the 17 instructions of a round) is done once
-LATOK_HD void lk_pext32x2(uint32_t* x1, uint32_t* x2, uint32_t m) {
-    uint32_t a = *x1 & m, b = *x2 & m;
-    uint32_t mk = ~m << 1;
+// The same through a 256-byte table of 4-bit pexts (k_lead_compress keeps it in LDS: 64 dwords = one per bank, so the byte reads of
+// a wave never conflict): entry (m4 << 4 | x4) = pext4(x4, m4) | popcount(m4) << 4.  Per nibble one lookup, a shift-or and an add
+// (the eight table indices of a 32-bit half come out of six mask / shift instructions): ~100 VALU per 64-bit word against ~256
+// for the five-round compress -- the kernel is bound by exactly this.  A second word through the same mask shares the positions.
+LATOK_HD uint8_t lk_pext4_entry(uint32_t i) {
+    const uint32_t m = i >> 4, x = i & 15u;
+    uint32_t out = 0, k = 0;
+    for (uint32_t b = 0; b < 4; ++b)
+        if ((m >> b) & 1u) { out |= ((x >> b) & 1u) << k; ++k; }
+    return (uint8_t)(out | (k << 4));
+}
+template <bool TWO>
+LATOK_HD void lk_pext32_lut(uint32_t x, uint32_t x2, uint32_t m, const uint8_t* tab, uint32_t* out, uint32_t* out2, uint32_t* n_out) {
+    // byte k of ie / io = table index of nibble 2k / 2k + 1
+    const uint32_t mh = (m & 0x0F0F0F0Fu) << 4, mo = m & 0xF0F0F0F0u;
+    const uint32_t ie = mh | (x & 0x0F0F0F0Fu), io = mo | ((x >> 4) & 0x0F0F0F0Fu);
+    const uint32_t ie2 = TWO ? (mh | (x2 & 0x0F0F0F0Fu)) : 0u, io2 = TWO ? (mo | ((x2 >> 4) & 0x0F0F0F0Fu)) : 0u;
+    uint32_t acc = 0, acc2 = 0, pos = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 5; ++i) {
-        uint32_t mp = mk ^ (mk << 1);
-        mp ^= mp << 2;
-        mp ^= mp << 4;
-        mp ^= mp << 8;
-        mp ^= mp << 16;
-        const uint32_t mv = mp & m;
-        m = (m ^ mv) | (mv >> (1 << i));
-        const uint32_t ta = a & mv, tb = b & mv;
-        a = (a ^ ta) | (ta >> (1 << i));
-        b = (b ^ tb) | (tb >> (1 << i));
-        mk &= ~mp;
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t sh = 8u * (uint32_t)(k >> 1);
+        const uint32_t e = tab[((k & 1) ? io : ie) >> sh & 0xFFu];
+        acc |= (e & 15u) << pos;
+        if (TWO) acc2 |= ((uint32_t)tab[((k & 1) ? io2 : ie2) >> sh & 0xFFu] & 15u) << pos;
+        pos += e >> 4;
     }
-    *x1 = a;
-    *x2 = b;
+    *out = acc;
+    if (TWO) *out2 = acc2;
+    *n_out = pos;
 }
-LATOK_HD void lk_pext64x2(lk_u64* x1, lk_u64* x2, lk_u64 m) {
-    uint32_t a0 = (uint32_t)*x1, b0 = (uint32_t)*x2, a1 = (uint32_t)(*x1 >> 32), b1 = (uint32_t)(*x2 >> 32);
-    lk_pext32x2(&a0, &b0, (uint32_t)m);
-    lk_pext32x2(&a1, &b1, (uint32_t)(m >> 32));
-    const int n = __builtin_popcount((uint32_t)m);
-    *x1 = (lk_u64)a0 | ((lk_u64)a1 << n);
-    *x2 = (lk_u64)b0 | ((lk_u64)b1 << n);
+template <bool TWO>
+LATOK_HD void lk_pext64_lut(lk_u64* x1, lk_u64* x2, lk_u64 m, const uint8_t* tab) {
+    uint32_t a0, a1, b0 = 0, b1 = 0, n0, n1;
+    lk_pext32_lut<TWO>((uint32_t)*x1, TWO ? (uint32_t)*x2 : 0u, (uint32_t)m, tab, &a0, &b0, &n0);
+    lk_pext32_lut<TWO>((uint32_t)(*x1 >> 32), TWO ? (uint32_t)(*x2 >> 32) : 0u, (uint32_t)(m >> 32), tab, &a1, &b1, &n1);
+    *x1 = (lk_u64)a0 | ((lk_u64)a1 << n0);
+    if (TWO) *x2 = (lk_u64)b0 | ((lk_u64)b1 << n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

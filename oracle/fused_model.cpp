@@ -421,10 +421,14 @@ extern "C" void fused_ascii_codes(const uint8_t* bytes64, uint8_t* planes_codes_
 
 // test hook: lane_math.h lk_pext64 (code-point results from byte-space masks: compact_kernels.hip, k_lead_compress)
 extern "C" unsigned long long fused_pext64(unsigned long long x, unsigned long long m) {
-    lk_u64 a = x, b = ~x;                       // the two-word form must give the same (checked here for x and its complement)
-    lk_pext64x2(&a, &b, m);
-    const lk_u64 want = lk_pext64(x, m);
-    if (a != want || b != lk_pext64(~x, m)) return ~want;
+    const lk_u64 want = lk_pext64(x, m), b = lk_pext64(~x, m);
+    static uint8_t tab[256];                    // the table form (k_lead_compress: 4-bit pexts from LDS) must agree as well
+    static bool tab_ready = false;
+    if (!tab_ready) { for (uint32_t i = 0; i < 256; ++i) tab[i] = lk_pext4_entry(i); tab_ready = true; }
+    lk_u64 c = x, d = ~x, e = x, unused = 0;
+    lk_pext64_lut<true>(&c, &d, m, tab);
+    lk_pext64_lut<false>(&e, &unused, m, tab);
+    if (c != want || d != b || e != want) return ~want;
     return want;
 }
 

@@ -710,9 +710,17 @@ def run_under_launcher(api, args, rank, world, local_rank):
     the per-rank records only -- gloo by default (nothing here needs RCCL: no collective on the data path)."""
     import torch.distributed as dist
     tdev = None   # the reductions run on host tensors
-    n_dev = max(1, len(kfd_gpu_nodes()) or 1) if args.device < 0 and args.pin else max(1, api.device_count())
+    # The rank's device, if possible without a HIP call (so that the pin below comes before the runtime starts): the GPUs sysfs lists,
+    # unless a launcher narrowed the visible devices or sysfs says nothing -- then the runtime is asked (counting devices does not
+    # initialise one).  Never guess: a wrong count would put several ranks on one GPU.
+    n_sys = len(kfd_gpu_nodes())
+    narrowed = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"))
+    n_dev = n_sys if (args.device < 0 and args.pin and n_sys > 0 and not narrowed) else max(1, api.device_count())
     device = args.device if args.device >= 0 else local_rank % n_dev   # a launcher may narrow HIP_VISIBLE_DEVICES per rank
     pin = pin_to_gpu_node(device) if args.pin else {"device": device, "numa_node": None, "pinned": False}   # (before the first HIP call below)
+    n_hip = api.device_count()
+    if args.device < 0 and n_hip > 0 and n_dev != n_hip:     # sysfs and the runtime disagree: the runtime decides
+        device = local_rank % n_hip
     dist.init_process_group(backend="gloo")
 
     class _Barrier:

@@ -404,6 +404,10 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
                                              ) {
     const int64_t total = P.total;
     const uint8_t* __restrict__ u8 = P.u8;
+    // halo bytes: lane 0 holds the dword before the tile (t0 is a multiple of 4096 and u8 is 16-byte aligned; byte j of it
+    // = byte t0 - 4 + j), lanes 1..11 the 11 bytes after the tile (0 where the batch has ended).  Requested BEFORE the rows: loads
+    // come back in order, and the decision below wants the halo and row 0 only.
+    uint32_t hb = bytes_halo_load(u8, t0, total, lane);
     // the tile: 4 x 16 bytes per lane (row i covers bytes 1024 i + 16 lane ..)
     u32x4 v[4];
     if (t0 + kTile <= total) {
@@ -420,9 +424,6 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
             v[i].x = d[0]; v[i].y = d[1]; v[i].z = d[2]; v[i].w = d[3];
         }
     }
-    // halo bytes: lane 0 holds the dword before the tile (t0 is a multiple of 4096 and u8 is 16-byte aligned; byte j of it
-    // = byte t0 - 4 + j), lanes 1..11 the 11 bytes after the tile (0 where the batch has ended)
-    uint32_t hb = bytes_halo_load(u8, t0, total, lane);
     // All-ASCII tiles take their own road, which needs all four rows; a tile whose row 0 already holds a multi-byte char does not
     // wait for the others to find that out.  (Requesting row 0 and the halo bytes of the wave's NEXT tile during phase 2 was
     // measured on top of this: C3 0.505 -> 0.515 ms, C2 0.073 -> 0.077; the 16 extra bytes of scratch cost more than the wait.)

@@ -156,6 +156,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     // tables
     DevBuf t1, t1rule, t2code, t2cls, cw;
+    DevBuf tb6, tb6rule;   // byte space: its own class table, split codes / rule codes (build_byte_tables)
     // runtime rule tables (latok_set_rules); off = the built-in default_tokenizer.py tables
     bool rules_on = false;
     lk_rule_tables rules;
@@ -347,6 +348,10 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     const uint8_t* tables = (const uint8_t*)((latok::mode_rules(mode) || d_codes) ? g.t1rule.p : g.t1.p);
     P.t1 = tables;
     P.t2 = tables + latok::kStage1Pad;
+    if (latok::mode_base(mode) == latok::kModeBytes) {   // (byte space classifies through its own table, cut at 6 bits)
+        P.t1 = (const uint8_t*)(latok::mode_rules(mode) ? g.tb6rule.p : g.tb6.p);
+        P.t2 = P.t1 + latok::kB6Stage1Bytes;
+    }
     if (latok::mode_rules(mode)) P.rules = g.rules;
     else memset(&P.rules, 0, sizeof(P.rules));
     P.bits_out = d_bits;
@@ -480,7 +485,7 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.pin_tot.release();
     g.done_ctr.release();
     g.rules_on = false;
-    for (DevBuf* b : {&g.t1, &g.t1rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
+    for (DevBuf* b : {&g.t1, &g.t1rule, &g.tb6, &g.tb6rule, &g.t2code, &g.t2cls, &g.cw, &g.summ, &g.seg_agg, &g.fix_count, &g.h_cps, &g.h_row, &g.h_out,
                       &g.bits, &g.space, &g.kept, &g.wcnt, &g.wpref, &g.counts, &g.bases, &g.scan_tot, &g.tile_first, &g.u_bytes,
                       &g.u_boff, &g.u_cnt, &g.u_row, &g.u_pref, &g.u_lead, &g.u_bspace, &g.u_cpbits, &g.u_cpspace, &g.scalar, &g.h_aux, &g.chain, &g.chain_ctl, &g.codes})
         b->release();
@@ -528,6 +533,49 @@ static void ctx_release(Ctx& g) {   // caller holds g.mu (or owns g exclusively)
     g.device = -1;
 }
 
+// Byte space's class table (split_code.h: LK_B6_*): the generated two-stage table (blocks of 128 code points, uint8 block ids) cut
+// again at 64 code points -- stage 1 by cp >> 6 = every UTF-8 byte of the char but the last, as the uint16 OFFSET of a 64-entry
+// stage-2 block, which the last byte's payload indexes.  blob = [stage 1, kB6Stage1Bytes | stage 2, kB6Stage2Bytes]; code[] =
+// kClassCode or kClassRuleCode.  What the kernel relies on beyond the lookup itself is checked here: ASCII is blocks 0 and 1,
+// back to back (its bytes are looked up without stage 1), and the last stage-1 entry (cp >= 0x110000) is a block of zeros.
+static int build_byte_tables(const unsigned char* code, std::vector<uint8_t>& blob) {
+    blob.assign(latok::kB6TablesBytes, 0);
+    uint16_t* s1 = reinterpret_cast<uint16_t*>(blob.data());
+    uint8_t* s2 = blob.data() + latok::kB6Stage1Bytes;
+    int n_blocks = 0;
+    for (int hi = 0; hi < latok::kB6Stage1Len; ++hi) {
+        uint8_t v[64];
+        const uint32_t cp0 = (uint32_t)hi << LK_B6_SHIFT;
+        const uint32_t b7 = kStage1[cp0 >= 0x110000u ? LATOK_TBL_STAGE1_LEN - 1 : (cp0 >> LATOK_TBL_SHIFT)];
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t in = cp0 >= 0x110000u ? 0u : ((cp0 + j) & ((1u << LATOK_TBL_SHIFT) - 1u));
+            v[j] = code[kStage2[(b7 << LATOK_TBL_SHIFT) | in]];
+        }
+        int b = 0;
+        while (b < n_blocks && memcmp(s2 + 64 * b, v, 64) != 0) ++b;
+        if (b == n_blocks) {
+            if (n_blocks == latok::kB6MaxBlocks) return fail(LATOK_ERR_INVALID, "internal: more than %d distinct 64-char class blocks", latok::kB6MaxBlocks);
+            memcpy(s2 + 64 * n_blocks++, v, 64);
+        }
+        s1[hi] = (uint16_t)(64 * b);
+    }
+    bool last_zero = true;
+    for (int j = 0; j < 64; ++j) last_zero = last_zero && s2[s1[latok::kB6Stage1Len - 1] + j] == 0;
+    if (s1[0] != 0 || s1[1] != 64 || !last_zero) return fail(LATOK_ERR_INVALID, "internal: byte-space class table layout");
+    return LATOK_OK;
+}
+
+/* test hook (not part of the ABI; needs no device): the byte-space class table as the kernels get it -- rule_codes 0: split
+ * codes, 1: rule codes.  Writes kB6TablesBytes into out (cap_bytes >= that) and returns the offset of stage 2 inside it. */
+extern "C" int latok_debug_byte_tables(int rule_codes, void* out, int64_t cap_bytes) {
+    std::vector<uint8_t> blob;
+    const int rc = build_byte_tables(rule_codes ? kClassRuleCode : kClassCode, blob);
+    if (rc) return rc;
+    if (!out || cap_bytes < (int64_t)blob.size()) return fail(LATOK_ERR_INVALID, "need %zu bytes", blob.size());
+    memcpy(out, blob.data(), blob.size());
+    return latok::kB6Stage1Bytes;
+}
+
 static int ctx_init_body(Ctx& g, int device) {
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -550,6 +598,15 @@ static int ctx_init_body(Ctx& g, int device) {
     if ((rc = g.t1rule.ensure(t1.size() + t2rule.size()))) return rc;   // same with rule codes (runtime rule tables)
     HIP_TRY(hipMemcpy(g.t1rule.p, t1.data(), t1.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy((char*)g.t1rule.p + t1.size(), t2rule.data(), t2rule.size(), hipMemcpyHostToDevice));
+    {
+        std::vector<uint8_t> blob;
+        if ((rc = build_byte_tables(kClassCode, blob))) return rc;
+        if ((rc = g.tb6.ensure(blob.size()))) return rc;
+        HIP_TRY(hipMemcpy(g.tb6.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+        if ((rc = build_byte_tables(kClassRuleCode, blob))) return rc;
+        if ((rc = g.tb6rule.ensure(blob.size()))) return rc;
+        HIP_TRY(hipMemcpy(g.tb6rule.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
     if ((rc = g.t2cls.ensure(sizeof(kStage2)))) return rc;
     if ((rc = g.cw.ensure(sizeof(kClassWord)))) return rc;
     if ((rc = g.scalar.ensure(64))) return rc;

@@ -15,6 +15,13 @@ constexpr int kStage1Len = 8705;         // 0x110000 >> 7, + 1 entry for cp >= 0
 constexpr int kStage1Pad = 8720;         // padded to 16 B
 constexpr int kStage2Len = 255 * 128;    // 32640, multiple of 16
 constexpr int kTablesLdsBytes = kStage1Pad + kStage2Len;   // 41360
+// byte space (kModeBytes): [stage 1: uint16 block offsets, by cp >> 6 | stage 2: 64-entry blocks] (split_code.h: LK_B6_*)
+constexpr int kB6Stage1Len = LK_B6_STAGE1_LEN;                       // 17409
+constexpr int kB6Stage1Bytes = (kB6Stage1Len * 2 + 1023) / 1024 * 1024;   // 35840: whole 1 KiB pieces (one wave instruction of the on-demand copy each)
+constexpr int kB6MaxBlocks = 400;                                    // distinct 64-char blocks: 354 (split codes) / 394 (rule codes)
+constexpr int kB6Stage2Bytes = kB6MaxBlocks * 64;                    // 25600, whole 1 KiB pieces as well
+constexpr int kB6TablesBytes = kB6Stage1Bytes + kB6Stage2Bytes;
+static_assert(kB6Stage1Bytes % 1024 == 0 && kB6Stage2Bytes % 1024 == 0 && kB6Stage1Bytes <= kTablesLdsBytes, "byte space keeps its stage 1 where the other modes keep both stages");
 constexpr int kStageBytes = 64 * 80;     // 64 rows of 64 code bytes + 16 B pad (conflict-free ds_read_b128)
 constexpr int kWaveLdsBytes = kStageBytes + 16 + 65 * 8 + 8;  // staging + halo + string-start words = 5664
 
@@ -93,8 +100,8 @@ struct SplitParams {
     int64_t n_str, total, n_tiles;
     int seg_tiles;              // tiles per segment (kWPB..kSegMax, see plan_segments)
     int64_t n_segs;             // ceil(n_tiles / seg_tiles)
-    const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes)
-    const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes)
+    const uint8_t* t1;          // stage-1 table in global memory (kStage1Pad bytes; kModeBytes: kB6Stage1Bytes of uint16 block offsets)
+    const uint8_t* t2;          // stage-2 split codes in global memory (kStage2Len bytes; kModeBytes: kB6Stage2Bytes), behind t1
     uint64_t* bits_out;         // kModeBits
     uint8_t* values_out;        // kModeValues / kModeBlockMask
     uint64_t* space_out;        // optional (kModeBits): SPACE plane as a bitmask, same layout as bits_out (token spans)

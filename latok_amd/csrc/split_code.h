@@ -24,6 +24,10 @@
 // Byte space (UTF-8 input): the staging byte of a CONTINUATION byte holds this marker -- bit 7 without SYMBOL, which no
 // split code and no rule code has -- so that the continuation plane of a word falls out of the bit-slicing (plane 7 & ~plane 1)
 #define LK_CODE_CONT 0x80u
+// Byte space has its own two-stage class table, cut where UTF-8 cuts a char: stage 1 by cp >> 6 (uint16: offset of a 64-entry
+// stage-2 block), stage 2 by the last byte's payload (lane_math.h: lk_lead_index; api.cpp builds it from the generated tables)
+#define LK_B6_SHIFT 6
+#define LK_B6_STAGE1_LEN ((0x110000 >> LK_B6_SHIFT) + 1)   /* 17409; the last entry = the block of cp >= 0x110000 (all codes 0) */
 
 // Rule code (runtime rule tables): the split code with NUM added in bit 6 for non-symbols, so that all 12 base
 // features can be decoded from the byte (tools/gen_unicode_tables.py:rule_code, lane_math.h:lk_feature_planes).

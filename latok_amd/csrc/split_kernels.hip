@@ -62,6 +62,13 @@ __device__ __forceinline__ uint32_t classify1(const uint8_t* t1, const uint8_t* 
     return t2[(blk << kTblShift) | (cp & ((1u << kTblShift) - 1u))];
 }
 
+// byte space: the same through its own table (stage 1 by cp >> 6 as uint16 block offsets; kernels.h: kB6*)
+__device__ __forceinline__ uint32_t classify1_b6(const uint8_t* t1b, const uint8_t* t2b, uint32_t cp) {
+    const uint32_t hi = min(cp >> LK_B6_SHIFT, (uint32_t)(kB6Stage1Len - 1));
+    const uint32_t off = *reinterpret_cast<const uint16_t*>(t1b + 2u * hi);
+    return t2b[off | (cp & 63u)];
+}
+
 __device__ __forceinline__ uint32_t classify4(const uint8_t* t1, const uint8_t* t2, u32x4 v, bool* not_ascii = nullptr) {
     uint32_t c;
     // wave-uniform fast path: all 256 chars of this wave instruction are ASCII -> stage-2 block 0, no stage-1 lookup
@@ -161,6 +168,10 @@ struct TileLds {
     const uint8_t* lut;    // kModeLatin1: slice LUT (kSliceLutBytes) in place of the Unicode tables
     const uint8_t* ctab;   // kModeLatin1: split code of each of the 256 Latin-1 chars (kModeBytes: the stage-2 block of U+0000, for its ASCII tiles)
     const uint8_t* ltab;   // kModeBytes: decode table of the multi-byte lead bytes (kLeadTabBytes, build_lead_table)
+    const uint8_t* t1b;    // kModeBytes: its own class table (kernels.h: kB6*) -- stage 1, uint16 block offsets by cp >> 6 ...
+    const uint8_t* t2b;    //             ... and stage 2, 64-entry blocks (t1 / t2 are unused there; ctab = t2b: ASCII is blocks 0, 1)
+    uint8_t* tables;       // the workgroup's table area (LDS offset 0) and the two counters of the on-demand table load
+    int* ctl;              // (tables_ensure); ctl == nullptr: the kernel reads its tables from global memory
     uint64_t* small_bits;  // k_small_batch: where the tile's boundary / SPACE words go (LDS) in place of P.bits_out /
     uint64_t* small_space; // P.space_out -- the kernel arguments stay where they are (no private copy of the rule tables)
 };
@@ -329,6 +340,27 @@ __device__ __forceinline__ bool units_phase1(const SplitParams& P, const TileLds
     return false;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Class tables on demand (k_tiles_main, byte space).  A workgroup used to copy its tables to LDS before its first tile: 60 KB
+// per CU from L2 with nothing else in flight, ~2 us at the head of every launch -- for tables that a batch of ASCII text never
+// reads beyond the 128 codes of U+0000..U+007F.  Now the launch copies those 128 bytes, and the first wave that meets a
+// multi-byte char brings in the rest: the copy is cut into kLazyGrabs pieces handed out by an LDS counter, so every wave that
+// arrives while it is under way takes a share (text that is not ASCII anywhere: all twelve at once, as fast as before), and a
+// second counter says when the last piece is in place.  Waves that find both counters full pay one LDS read per tile.
+// (Both counters count LANES, 64 per piece: every lane of the wave executes the same atomic -- hipcc folds them into one
+// ds_add of 64 per wave -- so no lane-0 branch surrounds the wave-wide copy instructions.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kLazyPer = 4;                                    // 1 KiB rows (one global_load_lds_dwordx4 of the wave each) per piece
+
+constexpr int kLazyRows = kB6TablesBytes / 1024;                 // byte space: [stage 1 | stage 2], then (computed, the last piece) the byte decode table
+constexpr int kLazyGrabs = (kLazyRows + kLazyPer - 1) / kLazyPer + 1;
+__device__ __attribute__((noinline, cold)) void tables_fetch_bytes(const uint8_t* t1, const uint8_t* t2, uint8_t* tables, int* ctl);
+__device__ __forceinline__ void tables_ensure_bytes(const SplitParams& P, const TileLds& L, int lane) {
+    if (L.ctl == nullptr) return;
+    if (__hip_atomic_load(&L.ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= 64 * kLazyGrabs) return;
+    tables_fetch_bytes(P.t1, P.t2, L.tables, L.ctl);
+}
+
 // kModeBytes, phase 1 (lane = 16 consecutive bytes per 1 KiB row).  What reaches the staging buffer: the split code of
 // its char at every LEAD byte (any non-continuation byte), the marker LK_CODE_CONT at continuation bytes (the continuation
 // plane of a word then falls out of phase 2's bit-slicing).  Nothing is carried from lane to lane: the continuation bytes take their owner's code in phase 2, as
@@ -340,43 +372,42 @@ __device__ __forceinline__ bool units_phase1(const SplitParams& P, const TileLds
 // halo[8..15] = staging bytes of the 8 bytes after the tile.
 // the window of slot (dword Q, lead mask m within the dword): its 4 bytes and where in the dword the lead sits
 // the window of a slot of dword Q: m = lead mask within the dword in "bit 7 of the byte" form; the slot takes its lowest
-// lead: *r_out = which byte of the dword, returns the 4 bytes from there on
+// lead: *r8_out = the bit position of that byte in the dword, returns the 4 bytes from there on
 // ---------------------------------------------------------------------------------------------------------------
-// kModeBytes: class of a multi-byte char straight from its bytes.  What the two-stage class table wants is hi = cp >> 7 and
-// lo = cp & 127; with Z = "the payload bits of every byte but the last" = cp >> 6 they are hi = Z >> 1, lo = (Z & 1) << 6 | last
-// payload.  The code point itself is never assembled: a 16-byte table entry per lead byte (0xC0..0xFF) holds
-//   .x  a v_perm selector that brings the sequence into ONE order whatever its length: R = {last, the byte before it, the one
-//       before that (4-byte sequences; else 0), 0}
-//   .y  what the lead byte itself contributes to hi:  0 | (b0 & 15) << 5 | (b0 & 7) << 11   (2 / 3 / 4 bytes)
-//   .z  the bytes of R that must be continuation bytes (0xC0 per byte)
-// so hi = .y + (R.byte1 & 0x3E) >> 1 + (R.byte2 & 0x3F) << 5 (for a 2-byte sequence R.byte1 is the lead itself: bit 5 of
-// 110xxxxx is 0), lo = R.byte0 & 0x3F | (R.byte1 & 1) << 6.  15 VALU instructions + one ds_read_b128 per char instead of 27
-// through utf8_cp_of (sequence length by compares, variable shifts, validity by variable masks): the byte-space kernel is
-// VALU bound and spends half its instructions here on non-ASCII text.  Same results as utf8_cp_of + classify1: a sequence cut
-// short is U+FFFD, overlong / surrogate forms decode as they are, 0xF8..0xFF are 4-byte leads with 3 payload bits.
+// kModeBytes: class of a multi-byte char straight from its bytes (lane_math.h: lk_lead_index has the scheme).  The code point is
+// never assembled: byte space has its own two-stage class table cut at 6 bits, so stage 1 wants "every byte but the last" and
+// stage 2 the last byte's payload.  Per decode slot: one ds_read_b128 of the 16-byte entry of the window's first byte, v_perm,
+// v_dot4_u32_u8 (the stage-1 offset), a clamp, the "cut short" test (2), ds_read_u16, v_and_or (stage-2 index), ds_read_u8 --
+// 7 VALU instructions where utf8_cp_of + classify1 took 27 and the 7-bit table (hi = cp >> 7, lo = cp & 127 by shifts and masks)
+// 15.  Same results as utf8_cp_of + classify1: a sequence cut short is U+FFFD, overlong / surrogate forms decode as they are,
+// 0xF8..0xFF are 4-byte leads with 3 payload bits.  The table has an entry for EVERY byte value: a slot that holds no lead
+// decodes whatever byte its window starts at, and the entries below 0xC0 yield code 0 (nothing to OR into the staging bytes).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kLeadTabBytes = 64 * 16;
+constexpr int kLeadTabBytes = 256 * 16;
 template <int NT>
 __device__ __forceinline__ void build_lead_table(uint8_t* lds) {
-    for (int i = threadIdx.x; i < 64; i += NT) {
-        const lk_lead_entry e = lk_lead_entry_of(0xC0u + (uint32_t)i);
+    for (int i = threadIdx.x; i < 256; i += NT) {
+        const lk_lead_entry e = lk_lead_entry_of((uint32_t)i);
         reinterpret_cast<uint4*>(lds)[i] = make_uint4(e.sel, e.hi0, e.need, 0u);
     }
 }
-// W = the 4 bytes from a lead byte >= 0xC0 on (memory order); *hi / *lo = the class-table indices of its char, returns whether
-// the sequence is cut short (the char is U+FFFD then; hi / lo are in range but meaningless)
-__device__ __forceinline__ bool lead_hi_lo(const uint8_t* ltab, uint32_t W, uint32_t* hi, uint32_t* lo) {
-    const uint4 q = *reinterpret_cast<const uint4*>(ltab + ((W & 0x3Fu) << 4));
+// W = the 4 bytes from a slot's first byte on (memory order): *off2 = byte offset of the char's stage-1 entry (clamped), *R = the
+// sequence in lk_lead_index's order (low 6 bits = stage-2 index); returns whether the sequence is cut short (U+FFFD then)
+__device__ __forceinline__ bool lead_index(const uint8_t* ltab, uint32_t W, uint32_t* off2, uint32_t* R) {
+    const uint4 q = *reinterpret_cast<const uint4*>(ltab + ((W & 0xFFu) << 4));
     lk_lead_entry e;
     e.sel = q.x; e.hi0 = q.y; e.need = q.z;
-    return lk_lead_hi_lo(e, W, hi, lo);
+    uint32_t o;
+    const bool bad = lk_lead_index(e, W, &o, R);
+    *off2 = min(o, 2u * (uint32_t)(kB6Stage1Len - 1));
+    return bad;
 }
 
 template <int Q>
-__device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], uint32_t m, uint32_t* r_out) {
-    const uint32_t r = ((uint32_t)__builtin_ctz(m | 0x80000000u) >> 3) & 3u;   // m == 0: a dummy decode, dropped by the caller
-    *r_out = r;
-    return __builtin_amdgcn_alignbyte(w[Q + 1], w[Q], r);
+__device__ __forceinline__ uint32_t bytes_slot_window(const uint32_t (&w)[5], uint32_t m, uint32_t* r8_out) {
+    const uint32_t r8 = (uint32_t)__builtin_ctz(m | 0x80000000u) & 24u;   // bit position of the byte; m == 0: byte 3, whatever it is
+    *r8_out = r8;
+    return __builtin_amdgcn_alignbit(w[Q + 1], w[Q], r8);
 }
 
 // byte space: the halo bytes of the tile at t0 -- lane 0: the dword before the tile, lanes 1..11: the 11 bytes after it
@@ -443,11 +474,12 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<uint4*>(L.stage + stage_addr(1024u * i + 16u * lane)) = make_uint4(v[i].x, v[i].y, v[i].z, v[i].w);
-        if (lane == 0 && t0 > 0) L.halo[0] = L.t2[hb >> 24];
-        if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.t2[hb & 0xFFu];
+        if (lane == 0 && t0 > 0) L.halo[0] = L.ctab[hb >> 24];
+        if (lane >= 1 && lane < 9 && t0 + kTile + (lane - 1) < total) L.halo[8 + (lane - 1)] = L.ctab[hb & 0xFFu];
         return true;
     }
 
+    tables_ensure_bytes(P, L, lane);   // from here on the whole class table is read, not just its ASCII part
     // The char that owns byte t0-1: its lead is byte t0-k, k = 1..4 (further back: nobody owns it).  The 8 bytes
     // t0-4 .. t0+3 sit in lane 0's registers; every lane computes (no divergence), lane 0 stores.
     {
@@ -456,17 +488,17 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         const lk_u64 Z = (lk_u64)hb | ((lk_u64)v[0].x << 32);
         const uint32_t W = (uint32_t)(Z >> (8u * (4u - k)));
         const uint32_t b0 = W & 0xFFu;
-        const uint32_t code = classify1(L.t1, L.t2, b0 < 0x80u ? b0 : utf8_cp_of(W));
+        const uint32_t code = classify1_b6(L.t1b, L.t2b, b0 < 0x80u ? b0 : utf8_cp_of(W));
         if (lane == 0 && t0 > 0 && !u8_is_cont(b0)) {
             L.halo[0] = (uint8_t)code;
             L.halo[4] = (uint8_t)(4u - k);
         }
     }
 
-    const uint32_t code_fffd = classify1(L.t1, L.t2, 0xFFFDu);   // a sequence that is cut short
+    const uint32_t code_fffd = classify1_b6(L.t1b, L.t2b, 0xFFFDu);   // a sequence that is cut short
     LATOK_STAMP(12);   // (share of stamp 2: owner of the byte before the tile)
     // R rows (1 KiB each) per round, every stage over all of them: the table lookups of a round -- R x 16 ASCII, then R x 8 per
-    // level of the multi-byte decode (lead table, stage 1, stage 2) -- are in flight together, so a round is four trips to the
+    // level of the multi-byte decode (byte entry, stage 1, stage 2) -- are in flight together, so a round is four trips to the
     // LDS whatever R is.  (Stamped build on C3: the rows were 3.7 K clocks each for ~250 VALU instructions -- the wave sat in the
     // LDS latency of one row at a time.)
     constexpr int R = 1;   // (2 rows per round: 128 B more scratch, 0.505 -> 0.56 ms on C3; 4: 0.78 KB of scratch, 1.4 ms)
@@ -475,15 +507,15 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         uint32_t d[R][4], out[R][4];
 #pragma unroll
         for (int a = 0; a < R; ++a) { d[a][0] = v[i0 + a].x; d[a][1] = v[i0 + a].y; d[a][2] = v[i0 + a].z; d[a][3] = v[i0 + a].w; }
-        // every byte as if it were ASCII: one lookup each in the stage-2 block of U+0000 (t1[0] == 0 by construction of the
-        // tables); the results at non-ASCII positions are cleared below
+        // every byte as if it were ASCII: one lookup each in the stage-2 blocks of U+0000..U+007F (blocks 0 and 1 by construction
+        // of the table); the results at non-ASCII positions are cleared below
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             // all 16 lookups of the row requested before the first one is used: left to itself hipcc keeps two or three in flight
             // (a register each), and the row waits for the LDS eight times instead of once
             uint32_t c[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) c[k] = L.t2[(d[a][k >> 2] >> (8 * (k & 3))) & 0x7Fu];
+            for (int k = 0; k < 16; ++k) c[k] = L.ctab[(d[a][k >> 2] >> (8 * (k & 3))) & 0x7Fu];
             asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                               "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
 #pragma unroll
@@ -526,52 +558,51 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
                 rest[a][q] = m2[a][q] & (m2[a][q] - 1u);                        // leads beyond two per dword (malformed input)
             }
         {
-            // stage by stage over the 8 R slots
-            uint32_t r[R][8], W[R][8], hi[R][8], lo[R][8], blk[R][8], code[R][8];
+            // stage by stage over the 8 R slots (slot s < 4: the first lead of dword s, else the second of dword s - 4)
+            uint32_t r8[R][8], W[R][8], off2[R][8], Rs[R][8], blk[R][8], code[R][8];
             bool bad[R][8];
 #pragma unroll
             for (int a = 0; a < R; ++a) {
-                W[a][0] = bytes_slot_window<0>(w[a], m1[a][0], &r[a][0]);
-                W[a][1] = bytes_slot_window<1>(w[a], m1[a][1], &r[a][1]);
-                W[a][2] = bytes_slot_window<2>(w[a], m1[a][2], &r[a][2]);
-                W[a][3] = bytes_slot_window<3>(w[a], m1[a][3], &r[a][3]);
-                W[a][4] = bytes_slot_window<0>(w[a], m2[a][0], &r[a][4]);
-                W[a][5] = bytes_slot_window<1>(w[a], m2[a][1], &r[a][5]);
-                W[a][6] = bytes_slot_window<2>(w[a], m2[a][2], &r[a][6]);
-                W[a][7] = bytes_slot_window<3>(w[a], m2[a][3], &r[a][7]);
+                W[a][0] = bytes_slot_window<0>(w[a], m1[a][0], &r8[a][0]);
+                W[a][1] = bytes_slot_window<1>(w[a], m1[a][1], &r8[a][1]);
+                W[a][2] = bytes_slot_window<2>(w[a], m1[a][2], &r8[a][2]);
+                W[a][3] = bytes_slot_window<3>(w[a], m1[a][3], &r8[a][3]);
+                W[a][4] = bytes_slot_window<0>(w[a], m2[a][0], &r8[a][4]);
+                W[a][5] = bytes_slot_window<1>(w[a], m2[a][1], &r8[a][5]);
+                W[a][6] = bytes_slot_window<2>(w[a], m2[a][2], &r8[a][6]);
+                W[a][7] = bytes_slot_window<3>(w[a], m2[a][3], &r8[a][7]);
             }
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
-                    bad[a][s] = lead_hi_lo(L.ltab, W[a][s], &hi[a][s], &lo[a][s]);
+                    bad[a][s] = lead_index(L.ltab, W[a][s], &off2[a][s], &Rs[a][s]);
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) blk[a][s] = L.t1[min(hi[a][s], (uint32_t)(kStage1Len - 1))];
+                for (int s = 0; s < 8; ++s) blk[a][s] = *reinterpret_cast<const uint16_t*>(L.t1b + off2[a][s]);
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) code[a][s] = L.t2[(blk[a][s] << kTblShift) | lo[a][s]];
+                for (int s = 0; s < 8; ++s) code[a][s] = L.t2b[blk[a][s] | (Rs[a][s] & 0x3Fu)];
+            // A slot without a lead decoded the dword's last byte: an ASCII or continuation byte gives code 0 (its table entry),
+            // a lead -- then the dword's first or second lead -- its own code once more, at its own place: OR-ing is right either way.
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const uint32_t c = bad[a][s] ? code_fffd : code[a][s];
-                    out[a][s & 3] |= ((s < 4 ? m1[a][s & 3] : m2[a][s & 3]) ? c : 0u) << (8u * r[a][s]);
-                }
+                for (int s = 0; s < 8; ++s) out[a][s & 3] |= (bad[a][s] ? code_fffd : code[a][s]) << r8[a][s];
         }
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             while (__any((rest[a][0] | rest[a][1] | rest[a][2] | rest[a][3]) != 0u)) {   // wave-uniform; never taken on well-formed UTF-8
-                uint32_t r[4], cp[4];
-                cp[0] = utf8_cp_of(bytes_slot_window<0>(w[a], rest[a][0], &r[0]));
-                cp[1] = utf8_cp_of(bytes_slot_window<1>(w[a], rest[a][1], &r[1]));
-                cp[2] = utf8_cp_of(bytes_slot_window<2>(w[a], rest[a][2], &r[2]));
-                cp[3] = utf8_cp_of(bytes_slot_window<3>(w[a], rest[a][3], &r[3]));
+                uint32_t r8[4], cp[4];
+                cp[0] = utf8_cp_of(bytes_slot_window<0>(w[a], rest[a][0], &r8[0]));
+                cp[1] = utf8_cp_of(bytes_slot_window<1>(w[a], rest[a][1], &r8[1]));
+                cp[2] = utf8_cp_of(bytes_slot_window<2>(w[a], rest[a][2], &r8[2]));
+                cp[3] = utf8_cp_of(bytes_slot_window<3>(w[a], rest[a][3], &r8[3]));
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    out[a][q] |= (rest[a][q] ? classify1(L.t1, L.t2, cp[q]) : 0u) << (8u * r[q]);
+                    out[a][q] |= (rest[a][q] ? classify1_b6(L.t1b, L.t2b, cp[q]) : 0u) << r8[q];
                     rest[a][q] &= rest[a][q] - 1u;
                 }
             }
@@ -590,7 +621,7 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         const uint32_t b3 = (uint32_t)dpp_mov<kDppWaveShl1, 0xF>(0, (int)b2) & 0xFFu;
         const uint32_t W = (hb & 0xFFu) | (b1 << 8) | (b2 << 16) | (b3 << 24);
         const uint32_t b0 = W & 0xFFu;
-        const uint32_t my_code = classify1(L.t1, L.t2, b0 < 0x80u ? b0 : utf8_cp_of(W));
+        const uint32_t my_code = classify1_b6(L.t1b, L.t2b, b0 < 0x80u ? b0 : utf8_cp_of(W));
         if (in_win) L.halo[8 + k] = (uint8_t)(u8_is_cont(b0) ? LK_CODE_CONT : my_code);
     }
     return false;
@@ -1210,9 +1241,14 @@ constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSeg
 constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
 constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
 constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
-constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: the lead-byte decode table (kLeadTabBytes); Latin-1 has its [slice LUT | code table] at 0
+constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: the byte decode table (kLeadTabBytes); Latin-1 has its [slice LUT | code table] at 0
+// Byte space's class table is larger than the other modes' ([stage 1, uint16 | stage 2] = kB6TablesBytes at 0: both stages below
+// 64 KiB, so that a lookup's table base fits the 16-bit offset field of its ds_read); everything behind the tables moves up by
+// the difference.  The kernels add lds_shift(MODE) to every offset above but the tables'.
+constexpr int lds_shift(int mode) { return mode_base(mode) == kModeBytes ? kB6TablesBytes - kTablesLdsBytes : 0; }
+static_assert(lds_shift(kModeBytes) % 16 == 0 && kB6TablesBytes < 65536, "alignment / immediate offsets");
 constexpr int kLdsTotalBase = kLdsSlice;
-constexpr int kLdsTotalBytes = kLdsSlice + kLeadTabBytes;
+constexpr int kLdsTotalBytes = kLdsSlice + lds_shift(kModeBytes) + kLeadTabBytes;
 constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
 // Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
 // per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
@@ -1238,7 +1274,37 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
         build_latin1_tables<NT>(lds, P);
         return;
     }
-    if (mode_base(MODE) == kModeBytes) build_lead_table<NT>(lds + kLdsSlice);
+    if (mode_base(MODE) == kModeBytes) {
+        // byte space: its own class table -- stage 1 (uint16 offsets) to 0, stage 2 behind it
+        build_lead_table<NT>(lds + lds_shift(kModeBytes) + kLdsSlice);
+        const uint4* src1 = reinterpret_cast<const uint4*>(P.t1);
+        const uint4* src2 = reinterpret_cast<const uint4*>(P.t2);
+        uint4* dst1 = reinterpret_cast<uint4*>(lds);
+        uint4* dst2 = reinterpret_cast<uint4*>(lds + kB6Stage1Bytes);
+        constexpr int kVec1 = kB6Stage1Bytes / 16, kVecB = kVec1 + kB6Stage2Bytes / 16;   // 2240 + 1600
+        constexpr int kPerB = (kVecB + NT - 1) / NT;                                       // 5 with 768 threads
+        if (kPerB <= 5) {
+            uint4 tmp[kPerB <= 5 ? kPerB : 1];   // all of a thread's loads are issued before its first LDS write
+#pragma unroll
+            for (int j = 0; j < (kPerB <= 5 ? kPerB : 1); ++j) {
+                const int i = threadIdx.x + j * NT;
+                if (i < kVecB) tmp[j] = i < kVec1 ? src1[i] : src2[i - kVec1];
+            }
+#pragma unroll
+            for (int j = 0; j < (kPerB <= 5 ? kPerB : 1); ++j) {
+                const int i = threadIdx.x + j * NT;
+                if (i < kVecB) { if (i < kVec1) dst1[i] = tmp[j]; else dst2[i - kVec1] = tmp[j]; }
+            }
+        } else {
+            for (int i = threadIdx.x; i < kVec1; i += NT) dst1[i] = src1[i];
+            for (int i = threadIdx.x; i < kVecB - kVec1; i += NT) dst2[i] = src2[i];
+        }
+        if (threadIdx.x == 0) {   // (tables_ensure_bytes: nothing left to fetch)
+            int* ctl = reinterpret_cast<int*>(lds + lds_shift(kModeBytes) + kLdsMisc) + 16;
+            ctl[0] = ctl[1] = 64 * kLazyGrabs;
+        }
+        return;
+    }
     constexpr int kVec = kTablesLdsBytes / 16;                    // 2585
     constexpr int kPer = (kVec + NT - 1) / NT;                    // 4 with 768 threads
     const uint4* src = reinterpret_cast<const uint4*>(P.t1);
@@ -1260,18 +1326,65 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
     }
 }
 
+// k_tiles_main in byte space: the ASCII part of the class table now, the rest when a tile asks for it (tables_ensure_bytes)
+__device__ __forceinline__ void load_tables_ascii_bytes(uint8_t* lds, const SplitParams& P) {
+    if (threadIdx.x < 8) reinterpret_cast<uint4*>(lds + kB6Stage1Bytes)[threadIdx.x] = reinterpret_cast<const uint4*>(P.t2)[threadIdx.x];
+    if (threadIdx.x == 8) {
+        int* ctl = reinterpret_cast<int*>(lds + lds_shift(kModeBytes) + kLdsMisc) + 16;
+        ctl[0] = ctl[1] = 0;
+    }
+}
+// the rest of it: pieces of kLazyPer rows of 1 KiB, handed out by ctl[0]; ctl[1] counts the pieces that are in place.  The rows go
+// from global memory straight to LDS (global_load_lds_dwordx4: wave-uniform LDS base + 16 x lane, no registers in between -- the
+// wave that fetches holds its tile's bytes in registers), the last piece is the byte decode table, which is computed.
+__device__ __attribute__((noinline, cold)) void tables_fetch_bytes(const uint8_t* t1, const uint8_t* t2, uint8_t* tables, int* ctl) {
+    const int lane = (int)(threadIdx.x & 63u);
+    struct { const uint8_t* t1; const uint8_t* t2; } P = {t1, t2};
+    struct { uint8_t* tables; int* ctl; } L = {tables, ctl};
+    typedef const void __attribute__((address_space(1))) * gptr_t;
+    typedef void __attribute__((address_space(3))) * lptr_t;
+    for (;;) {
+        const int ticket = __hip_atomic_fetch_add(&L.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int g = __builtin_amdgcn_readfirstlane(ticket) >> 6;                 // wave-uniform: 64 tickets per piece
+        if (g >= kLazyGrabs) break;
+        if (g == kLazyGrabs - 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const lk_lead_entry e = lk_lead_entry_of((uint32_t)(64 * j + lane));
+                reinterpret_cast<uint4*>(L.tables + lds_shift(kModeBytes) + kLdsSlice)[64 * j + lane] = make_uint4(e.sel, e.hi0, e.need, 0u);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLazyPer; ++j) {
+                const int row = g * kLazyPer + j;                                  // wave-uniform
+                if (row < kLazyRows)   // (both stages are back to back, in global memory as in LDS)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(P.t1 + 1024 * row + 16 * lane), (lptr_t)(L.tables + 1024 * row), 16, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the rows have landed
+        }
+        // (the LDS executes one wave's instructions in order: the piece is in place before the count says so)
+        __hip_atomic_fetch_add(&L.ctl[1], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    while (__hip_atomic_load(&L.ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 64 * kLazyGrabs) __builtin_amdgcn_s_sleep(2);
+}
+
 template <int MODE = kModeBits>
 __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     TileLds L;
     L.t1 = lds;
     L.t2 = lds + kStage1Pad;
-    uint8_t* mine = wave < kWPB ? lds + kLdsWaves + wave * kWaveLdsBytes : lds + lds_total(MODE) + (wave - kWPB) * kWaveLdsBytes;
+    uint8_t* const w = lds + lds_shift(MODE);
+    uint8_t* mine = wave < kWPB ? w + kLdsWaves + wave * kWaveLdsBytes : lds + lds_total(MODE) + (wave - kWPB) * kWaveLdsBytes;
     L.stage = mine;
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
     L.lut = lds;                                                     // build_latin1_tables (kModeLatin1: in place of the Unicode tables)
-    L.ctab = mode_base(MODE) == kModeBytes ? L.t2 : L.lut + kSliceLutBytes;   // (byte space reads it for ASCII bytes only: stage-2 block of U+0000)
-    L.ltab = lds + kLdsSlice;
+    L.ltab = w + kLdsSlice;
+    L.tables = lds;
+    L.ctl = reinterpret_cast<int*>(w + kLdsMisc) + 16;
+    L.t1b = lds;
+    L.t2b = lds + kB6Stage1Bytes;
+    L.ctab = mode_base(MODE) == kModeBytes ? L.t2b : L.lut + kSliceLutBytes;   // (byte space reads it for ASCII bytes only: stage-2 blocks 0 and 1)
     L.small_bits = L.small_space = nullptr;
     return L;
 }
@@ -1298,8 +1411,8 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
                                             int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
     const TileLds L = wave_lds<MODE>(lds, wave);
-    int4* sm = reinterpret_cast<int4*>(lds + kLdsSumm);
-    ScanLdsT<WPB>& scan = *reinterpret_cast<ScanLdsT<WPB>*>(lds + kLdsScan);
+    int4* sm = reinterpret_cast<int4*>(lds + lds_shift(MODE) + kLdsSumm);
+    ScanLdsT<WPB>& scan = *reinterpret_cast<ScanLdsT<WPB>*>(lds + lds_shift(MODE) + kLdsScan);
 
     const int64_t T0 = seg * S;
     const int64_t T1 = min(T0 + S, P.n_tiles);
@@ -1379,7 +1492,11 @@ __global__ __launch_bounds__(tile_wpb(MODE) * 64) void k_tiles_main(SplitParams 
     if (blockIdx.x == 0 && tid == 0) *P.fix_count = 0;            // statistics counter of the resolve stage
 
     bool tables = MODE != kModeBlockMask;
-    if (tables) load_tables<WPB * 64, MODE>(lds, P);   // published by the barrier at the top of the workgroup's first segment
+    // (published by the barrier at the top of the workgroup's first segment)
+    if (tables) {
+        if (mode_base(MODE) == kModeBytes) load_tables_ascii_bytes(lds, P);
+        else load_tables<WPB * 64, MODE>(lds, P);
+    }
 #ifdef LATOK_STAMPS
     unsigned long long stamp_acc[16];
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
@@ -1408,10 +1525,10 @@ __global__ __launch_bounds__(tile_wpb(MODE) * 64) void k_tiles_main(SplitParams 
 template <int MODE, int NW, bool ONE>
 __device__ __forceinline__ void resolve_segments(const SplitParams& P, uint8_t* lds, int tid, int lane, int wave) {
     const int S = P.seg_tiles;
-    ScanLdsT<NW>& scan = *reinterpret_cast<ScanLdsT<NW>*>(lds + kLdsScan);
-    int* misc = reinterpret_cast<int*>(lds + kLdsMisc);          // misc[0] = number of tiles to recompute
-    int* fix_t = reinterpret_cast<int*>(lds + kLdsTf);           // tile index inside the segment (tiles to recompute)
-    int2* fix_in = reinterpret_cast<int2*>(lds + kLdsSumm);      // {q_in, tail_zero}
+    ScanLdsT<NW>& scan = *reinterpret_cast<ScanLdsT<NW>*>(lds + lds_shift(MODE) + kLdsScan);
+    int* misc = reinterpret_cast<int*>(lds + lds_shift(MODE) + kLdsMisc);          // misc[0] = number of tiles to recompute
+    int* fix_t = reinterpret_cast<int*>(lds + lds_shift(MODE) + kLdsTf);           // tile index inside the segment (tiles to recompute)
+    int2* fix_in = reinterpret_cast<int2*>(lds + lds_shift(MODE) + kLdsSumm);      // {q_in, tail_zero}
     bool tables_loaded = ONE;
 
     for (int64_t seg = ONE ? 0 : (int64_t)blockIdx.x; seg < (ONE ? 1 : P.n_segs); seg += ONE ? 1 : (int64_t)gridDim.x) {
@@ -2113,7 +2230,7 @@ __global__ __launch_bounds__(kFeatWaves * 64) void k_features_tiles(FeatParams P
     if (!(P.n_tokens_dev && *P.n_tokens_dev > P.cap)) {
         TileLds L;
         L.small_bits = L.small_space = nullptr;
-        L.t1 = L.t2 = L.lut = L.ctab = L.ltab = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
+        L.t1 = L.t2 = L.lut = L.ctab = L.ltab = L.t1b = L.t2b = nullptr; L.tables = nullptr; L.ctl = nullptr;   // nothing is classified here: the tile kernel left the rule codes (P.codes)
         uint8_t* mine = lds + wave * kFeatWaveLds;
         L.stage = mine;
         L.halo = mine + kFeatWinBytes;
@@ -2161,7 +2278,7 @@ __global__ __launch_bounds__(64) void k_small_batch(SmallParams S) {
     TileLds L;
     L.t1 = S.P.t1;          // global memory
     L.t2 = S.P.t2;
-    L.lut = L.ctab = L.ltab = nullptr;
+    L.lut = L.ctab = L.ltab = L.t1b = L.t2b = nullptr; L.tables = nullptr; L.ctl = nullptr;
     L.stage = lds;
     L.halo = lds + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(lds + kStageBytes + 16);
@@ -2373,7 +2490,7 @@ __global__ __launch_bounds__(64) void k_small_block_mask(SmallParams S) {
     __shared__ int s_flags[2];
     const int lane = threadIdx.x;
     TileLds L;
-    L.t1 = L.t2 = L.lut = L.ctab = L.ltab = nullptr;
+    L.t1 = L.t2 = L.lut = L.ctab = L.ltab = L.t1b = L.t2b = nullptr; L.tables = nullptr; L.ctl = nullptr;
     L.small_bits = L.small_space = nullptr;
     L.stage = lds;
     L.halo = lds + kStageBytes;

@@ -432,11 +432,12 @@ extern "C" unsigned long long fused_pext64(unsigned long long x, unsigned long l
     return want;
 }
 
-// test hook: lane_math.h lk_lead_entry_of + lk_lead_hi_lo (the byte-space kernel's table-driven decode of multi-byte chars):
-// W = 4 bytes from a lead byte >= 0xC0 on; returns 1 when the sequence is cut short, else 0 with *cp = (hi << 7) | lo
+// test hook: lane_math.h lk_lead_entry_of + lk_lead_index (the byte-space kernel's table-driven decode of multi-byte chars):
+// W = 4 bytes from byte b0 on; returns 1 when the sequence is cut short, else 0 with *cp = (stage-1 index << 6) | stage-2 index
+// (a byte below 0xC0 starts nothing: stage 1's last entry, index 0)
 extern "C" int fused_lead_decode(uint32_t W, uint32_t* cp) {
-    uint32_t hi = 0, lo = 0;
-    const bool bad = lk_lead_hi_lo(lk_lead_entry_of(W & 0xFFu), W, &hi, &lo);
-    *cp = (hi << 7) | lo;
+    uint32_t off2 = 0, R = 0;
+    const bool bad = lk_lead_index(lk_lead_entry_of(W & 0xFFu), W, &off2, &R);
+    *cp = ((off2 >> 1) << LK_B6_SHIFT) | (R & 0x3Fu);
     return bad ? 1 : 0;
 }

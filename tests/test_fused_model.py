@@ -341,12 +341,17 @@ def test_model_code_point_mask_is_the_byte_space_mask_at_lead_bytes(model):
 
 
 def test_table_driven_lead_decode_is_the_decoder_rule(model):
-    """lane_math.h lk_lead_hi_lo (the byte-space kernel classifies a multi-byte char from cp >> 7 and cp & 127 computed straight
-    from its bytes, one table entry per lead byte) against the decoder's rule (utf8_decode.h): every lead byte 0xC0..0xFF with
-    every second byte, third / fourth bytes over a set that holds both ends of the continuation range and non-continuation bytes."""
+    """lane_math.h lk_lead_index (the byte-space kernel classifies a multi-byte char from cp >> 6 and the last byte's payload,
+    computed straight from its bytes with one table entry per byte value) against the decoder's rule (utf8_decode.h): every lead
+    byte 0xC0..0xFF with every second byte, third / fourth bytes over a set that holds both ends of the continuation range and
+    non-continuation bytes; a byte below 0xC0 starts nothing (stage 1's last entry, never "cut short")."""
     model.fused_lead_decode.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
     tail = [0x00, 0x41, 0x7F, 0x80, 0x81, 0x9F, 0xA0, 0xBE, 0xBF, 0xC0, 0xE3, 0xFF]
     cp = C.c_uint32(0)
+    for b0 in range(0xC0):
+        for rest in (0, 0x808080, 0xBFBFBF, 0xFFFFFF, 0x41E380):
+            assert model.fused_lead_decode(b0 | rest << 8, C.byref(cp)) == 0
+            assert cp.value == 0x110000, (b0, hex(cp.value))
     n = 0
     for b0 in range(0xC0, 0x100):
         k = 1 + (b0 >= 0xE0) + (b0 >= 0xF0)          # continuation bytes the lead asks for

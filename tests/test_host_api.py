@@ -269,6 +269,42 @@ def test_host_decoder_of_small_utf8_batches():
         assert run(bad)[0] == 0, bad
 
 
+def test_byte_space_class_table_is_the_generated_table_cut_at_six_bits():
+    """api.cpp: build_byte_tables -- the byte-space kernel classifies through its own two-stage table (stage 1 by cp >> 6 as
+    uint16 block offsets, stage 2 by the last UTF-8 byte's payload; split_code.h LK_B6_*).  Every code point must get the code the
+    generated 7-bit table (unicode_tables.inc, pinned by tests/golden/unicode_classes.json through the oracle tests) gives it,
+    for split codes and rule codes; ASCII must be the first 128 stage-2 bytes; the last stage-1 entry (cp >= 0x110000, and what
+    a decode slot without a lead points at) must be a block of zeros.  No device needed."""
+    import ctypes as C
+    import re
+    from latok_amd import _lib
+    fn = _lib.load().latok_debug_byte_tables
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_int64]
+    src = open(os.path.join(ROOT, "latok_amd", "csrc", "unicode_tables.inc")).read()
+
+    def arr(name):
+        body = re.search(name + r"\[\d+\] = \{(.*?)\};", src, re.S).group(1)
+        return np.array([int(x, 0) for x in re.findall(r"0x[0-9a-fA-F]+|\d+", body)], np.int64)
+
+    s1, s2 = arr("kStage1"), arr("kStage2")
+    cps = np.arange(0x110000, dtype=np.int64)
+    cls = s2[(s1[cps >> 7] << 7) | (cps & 127)]
+    n1 = (0x110000 >> 6) + 1
+    for rule, name in ((0, "kClassCode"), (1, "kClassRuleCode")):
+        blob = np.zeros(1 << 17, np.uint8)
+        off = fn(rule, blob.ctypes.data, blob.size)
+        assert off == (2 * n1 + 1023) // 1024 * 1024, _lib.load().latok_last_error()
+        t1 = blob[:2 * n1].view("<u2").astype(np.int64)
+        t2 = blob[off:]
+        assert (t1 % 64 == 0).all() and t1.max() + 64 <= 400 * 64
+        want = arr(name)[cls]
+        assert np.array_equal(t2[t1[cps >> 6] | (cps & 63)], want)
+        assert np.array_equal(t2[:128], want[:128])                     # ASCII without stage 1
+        assert not t2[t1[-1]:t1[-1] + 64].any()                         # cp >= 0x110000 / "no lead here"
+        assert fn(rule, blob.ctypes.data, 1000) < 0
+
+
 def _router():
     import ctypes as C
     from latok_amd import _lib

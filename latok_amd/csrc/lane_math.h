@@ -145,17 +145,18 @@ LATOK_HD void lk_pext64_lut(lk_u64* x1, lk_u64* x2, lk_u64 m, const uint8_t* tab
 // Byte space: class-table indices of a char straight from its bytes.  The byte-space kernel has its own two-stage class table,
 // cut where UTF-8 cuts: stage 1 is indexed by cp >> 6 -- everything but the last byte's payload -- and holds the offset of a
 // 64-entry stage-2 block, which the last byte's six payload bits index (LK_B6_*; api.cpp derives both stages from the
-// generated tables).  The code point itself is never assembled.  A 16-byte table entry per byte value b0 holds
+// generated tables).  The code point itself is never assembled.  An 8-byte table entry per byte value b0 holds
 //   .sel   a v_perm selector that brings the sequence into ONE order whatever its length: R = {last byte, the one before it
-//          (3- and 4-byte sequences; else 0), the one before that (4-byte sequences; else 0), 0}
+//          (3- and 4-byte sequences), the one before that (4-byte sequences), -}; every position the sequence does not fill
+//          takes the constant 0x80, an empty continuation byte
 //   .hi0   what the lead byte itself contributes to the stage-1 index, as the BYTE offset of the 16-bit entry (2 x (cp >> 6)),
-//          less what the 10xxxxxx prefixes of the continuation bytes in R add to the sum below
-//   .need  0xC0 in every byte of R that must be a continuation byte
-// so that the stage-1 offset is hi0 + 2 * R.byte1 + 128 * R.byte2 -- ONE v_dot4_u32_u8 with the entry as its addend -- and the
-// stage-2 index is the block offset | R & 0x3F.  lk_lead_entry_of(b0) = the entry of byte b0: 0xC0..0xFF are lead bytes
-// (0xF8..0xFF count as 4-byte leads with 3 payload bits); a byte below 0xC0 starts no multi-byte char: its entry selects
-// nothing (R = 0), is never "cut short" and points at stage 1's last entry, the block of cp >= 0x110000, whose codes are all 0
-// -- a decode slot that holds no lead adds nothing to the staging bytes without a select.
+//          less what the 10xxxxxx prefixes of R.byte1 and R.byte2 add to the sum below (the same for every length)
+// so that the stage-1 offset is hi0 + 2 * R.byte1 + 128 * R.byte2 -- ONE v_dot4_u32_u8 with the entry as its addend --, the
+// stage-2 index is the block offset | R & 0x3F, and the sequence is cut short exactly when some byte of R is not 10xxxxxx.
+// lk_lead_entry_of(b0) = the entry of byte b0: 0xC0..0xFF are lead bytes (0xF8..0xFF count as 4-byte leads with 3 payload
+// bits); a byte below 0xC0 starts no multi-byte char: its entry selects nothing (R = 0x80808080: never "cut short", index 0
+// in its block) and points at stage 1's last entry, the block of cp >= 0x110000, whose codes are all 0 -- a decode slot that
+// holds no lead adds nothing to the staging bytes without a select.
 // lk_lead_index(entry, W) with W = the 4 bytes from b0 on: *off2 = byte offset into stage 1 (clamp it to the last entry:
 // sequences that decode beyond U+10FFFF, and whatever a sequence that is cut short adds up to), *R_out = R (low six bits = the
 // stage-2 index within the block); returns true when the sequence is cut short (the char is U+FFFD then).
@@ -163,38 +164,35 @@ LATOK_HD void lk_pext64_lut(lk_u64* x1, lk_u64* x2, lk_u64 m, const uint8_t* tab
 struct lk_lead_entry {
     uint32_t sel;
     uint32_t hi0;
-    uint32_t need;
 };
 LATOK_HD lk_lead_entry lk_lead_entry_of(uint32_t b0) {
     lk_lead_entry e;
+    const uint32_t prefixes = 0x80u + 64u * 0x80u;   // of R.byte1 / R.byte2 in the sum (a position without a byte holds 0x80 too)
     if (b0 < 0xC0u) {
-        e.sel = 0x0C0C0C0Cu;
-        e.hi0 = 2u * (uint32_t)(LK_B6_STAGE1_LEN - 1);
-        e.need = 0u;
+        e.sel = 0x04040404u;
+        e.hi0 = 2u * ((uint32_t)(LK_B6_STAGE1_LEN - 1) - prefixes);
         return e;
     }
     const int n = 2 + (b0 >= 0xE0u) + (b0 >= 0xF0u);
-    e.sel = n == 2 ? 0x0C0C0C01u : (n == 3 ? 0x0C0C0102u : 0x0C010203u);
+    e.sel = n == 2 ? 0x04040401u : (n == 3 ? 0x04040102u : 0x04010203u);   // (0..3: byte of W, 4: the constant)
     const uint32_t own = n == 2 ? (b0 & 31u) : (n == 3 ? (b0 & 15u) << 6 : (b0 & 7u) << 12);   // the lead's part of cp >> 6
-    const uint32_t prefixes = n == 2 ? 0u : (n == 3 ? 0x80u : 0x80u + 64u * 0x80u);             // of R.byte1 / R.byte2 in the sum
     e.hi0 = 2u * (own - prefixes);                                                               // (mod 2^32: the sum is exact again)
-    e.need = n == 2 ? 0x000000C0u : (n == 3 ? 0x0000C0C0u : 0x00C0C0C0u);
     return e;
 }
 LATOK_HD bool lk_lead_index(lk_lead_entry e, uint32_t W, uint32_t* off2, uint32_t* R_out) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t R = __builtin_amdgcn_perm(W, W, e.sel);
+    const uint32_t R = __builtin_amdgcn_perm(0x80808080u, W, e.sel);
     *off2 = __builtin_amdgcn_udot4(R, 0x00800200u, e.hi0, false);
 #else
     uint32_t R = 0;
     for (int k = 0; k < 4; ++k) {
         const uint32_t s = (e.sel >> (8 * k)) & 0xFFu;
-        if (s < 4u) R |= ((W >> (8 * s)) & 0xFFu) << (8 * k);
+        R |= (s < 4u ? (W >> (8 * s)) & 0xFFu : 0x80u) << (8 * k);
     }
     *off2 = e.hi0 + 2u * ((R >> 8) & 0xFFu) + 128u * ((R >> 16) & 0xFFu);
 #endif
     *R_out = R;
-    return ((R ^ 0x80808080u) & e.need) != 0u;
+    return ((R ^ 0x80808080u) & 0xC0C0C0C0u) != 0u;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

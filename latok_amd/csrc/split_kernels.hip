@@ -376,27 +376,30 @@ __device__ __forceinline__ void tables_ensure_bytes(const SplitParams& P, const 
 // ---------------------------------------------------------------------------------------------------------------
 // kModeBytes: class of a multi-byte char straight from its bytes (lane_math.h: lk_lead_index has the scheme).  The code point is
 // never assembled: byte space has its own two-stage class table cut at 6 bits, so stage 1 wants "every byte but the last" and
-// stage 2 the last byte's payload.  Per decode slot: one ds_read_b128 of the 16-byte entry of the window's first byte, v_perm,
+// stage 2 the last byte's payload.  Per decode slot: one ds_read_b64 of the 8-byte entry of the window's first byte, v_perm,
 // v_dot4_u32_u8 (the stage-1 offset), a clamp, the "cut short" test (2), ds_read_u16, v_and_or (stage-2 index), ds_read_u8 --
 // 7 VALU instructions where utf8_cp_of + classify1 took 27 and the 7-bit table (hi = cp >> 7, lo = cp & 127 by shifts and masks)
 // 15.  Same results as utf8_cp_of + classify1: a sequence cut short is U+FFFD, overlong / surrogate forms decode as they are,
 // 0xF8..0xFF are 4-byte leads with 3 payload bits.  The table has an entry for EVERY byte value: a slot that holds no lead
 // decodes whatever byte its window starts at, and the entries below 0xC0 yield code 0 (nothing to OR into the staging bytes).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kLeadTabBytes = 256 * 16;
+constexpr int kLeadTabBytes = 256 * 8;
 template <int NT>
 __device__ __forceinline__ void build_lead_table(uint8_t* lds) {
     for (int i = threadIdx.x; i < 256; i += NT) {
         const lk_lead_entry e = lk_lead_entry_of((uint32_t)i);
-        reinterpret_cast<uint4*>(lds)[i] = make_uint4(e.sel, e.hi0, e.need, 0u);
+        reinterpret_cast<uint2*>(lds)[i] = make_uint2(e.sel, e.hi0);
     }
 }
-// W = the 4 bytes from a slot's first byte on (memory order): *off2 = byte offset of the char's stage-1 entry (clamped), *R = the
-// sequence in lk_lead_index's order (low 6 bits = stage-2 index); returns whether the sequence is cut short (U+FFFD then)
-__device__ __forceinline__ bool lead_index(const uint8_t* ltab, uint32_t W, uint32_t* off2, uint32_t* R) {
-    const uint4 q = *reinterpret_cast<const uint4*>(ltab + ((W & 0xFFu) << 4));
+// the entry of the byte a slot's window W starts with
+__device__ __forceinline__ uint2 lead_entry(const uint8_t* ltab, uint32_t W) {
+    return *reinterpret_cast<const uint2*>(ltab + ((W & 0xFFu) << 3));
+}
+// W = the 4 bytes from a slot's first byte on (memory order), q = its entry: *off2 = byte offset of the char's stage-1 entry
+// (clamped), *R = the sequence in lk_lead_index's order (low 6 bits = stage-2 index); returns whether the sequence is cut short
+__device__ __forceinline__ bool lead_index(uint2 q, uint32_t W, uint32_t* off2, uint32_t* R) {
     lk_lead_entry e;
-    e.sel = q.x; e.hi0 = q.y; e.need = q.z;
+    e.sel = q.x; e.hi0 = q.y;
     uint32_t o;
     const bool bad = lk_lead_index(e, W, &o, R);
     *off2 = min(o, 2u * (uint32_t)(kB6Stage1Len - 1));
@@ -572,11 +575,21 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
                 W[a][6] = bytes_slot_window<2>(w[a], m2[a][2], &r8[a][6]);
                 W[a][7] = bytes_slot_window<3>(w[a], m2[a][3], &r8[a][7]);
             }
+            // (the eight entries requested together, like the ASCII lookups above: left alone hipcc reads, waits and decodes slot by slot)
+            static_assert(R == 1, "the pin below names the entries of one row");
+            uint2 ent[R][8];
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) ent[a][s] = lead_entry(L.ltab, W[a][s]);
+            asm volatile("" : "+v"(ent[0][0].x), "+v"(ent[0][0].y), "+v"(ent[0][1].x), "+v"(ent[0][1].y), "+v"(ent[0][2].x), "+v"(ent[0][2].y),
+                              "+v"(ent[0][3].x), "+v"(ent[0][3].y), "+v"(ent[0][4].x), "+v"(ent[0][4].y), "+v"(ent[0][5].x), "+v"(ent[0][5].y),
+                              "+v"(ent[0][6].x), "+v"(ent[0][6].y), "+v"(ent[0][7].x), "+v"(ent[0][7].y));
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
-                    bad[a][s] = lead_index(L.ltab, W[a][s], &off2[a][s], &Rs[a][s]);
+                    bad[a][s] = lead_index(ent[a][s], W[a][s], &off2[a][s], &Rs[a][s]);
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
@@ -1241,14 +1254,15 @@ constexpr int kLdsTf = kLdsWaves + kWPB * kWaveLdsBytes;           // int32[kSeg
 constexpr int kLdsSumm = kLdsTf + kSegMax * 4;                     // int4[kSegMax]: tile summaries of the segment
 constexpr int kLdsScan = kLdsSumm + kSegMax * 16;                  // ScanLds
 constexpr int kLdsMisc = kLdsScan + 512;                           // 64 ints of scratch
-constexpr int kLdsSlice = kLdsMisc + 256;                          // kModeBytes: the byte decode table (kLeadTabBytes); Latin-1 has its [slice LUT | code table] at 0
-// Byte space's class table is larger than the other modes' ([stage 1, uint16 | stage 2] = kB6TablesBytes at 0: both stages below
+constexpr int kLdsSlice = kLdsMisc + 256;                          // end of the map (Latin-1 has its [slice LUT | code table] at 0)
+// Byte space's tables are larger than the other modes' ([stage 1, uint16 | stage 2 | byte decode table] at 0, all of it below
 // 64 KiB, so that a lookup's table base fits the 16-bit offset field of its ds_read); everything behind the tables moves up by
 // the difference.  The kernels add lds_shift(MODE) to every offset above but the tables'.
-constexpr int lds_shift(int mode) { return mode_base(mode) == kModeBytes ? kB6TablesBytes - kTablesLdsBytes : 0; }
-static_assert(lds_shift(kModeBytes) % 16 == 0 && kB6TablesBytes < 65536, "alignment / immediate offsets");
+constexpr int kLdsLeadTab = kB6TablesBytes;                       // kModeBytes: the byte decode table, behind the class table
+constexpr int lds_shift(int mode) { return mode_base(mode) == kModeBytes ? kLdsLeadTab + kLeadTabBytes - kTablesLdsBytes : 0; }
+static_assert(lds_shift(kModeBytes) % 16 == 0 && kLdsLeadTab + kLeadTabBytes < 65536, "alignment / immediate offsets");
 constexpr int kLdsTotalBase = kLdsSlice;
-constexpr int kLdsTotalBytes = kLdsSlice + lds_shift(kModeBytes) + kLeadTabBytes;
+constexpr int kLdsTotalBytes = kLdsSlice + lds_shift(kModeBytes);
 constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
 // Waves per workgroup of the TILE kernel.  The Latin-1 kernel needs <= 128 VGPRs and its LDS map has room, so it runs 16 waves
 // per CU (4 per SIMD): its waves spend half their life in s_waitcnt, a fourth wave per SIMD fills part of that.  The
@@ -1276,7 +1290,7 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
     }
     if (mode_base(MODE) == kModeBytes) {
         // byte space: its own class table -- stage 1 (uint16 offsets) to 0, stage 2 behind it
-        build_lead_table<NT>(lds + lds_shift(kModeBytes) + kLdsSlice);
+        build_lead_table<NT>(lds + kLdsLeadTab);
         const uint4* src1 = reinterpret_cast<const uint4*>(P.t1);
         const uint4* src2 = reinterpret_cast<const uint4*>(P.t2);
         uint4* dst1 = reinterpret_cast<uint4*>(lds);
@@ -1351,7 +1365,7 @@ __device__ __attribute__((noinline, cold)) void tables_fetch_bytes(const uint8_t
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const lk_lead_entry e = lk_lead_entry_of((uint32_t)(64 * j + lane));
-                reinterpret_cast<uint4*>(L.tables + lds_shift(kModeBytes) + kLdsSlice)[64 * j + lane] = make_uint4(e.sel, e.hi0, e.need, 0u);
+                reinterpret_cast<uint2*>(L.tables + kLdsLeadTab)[64 * j + lane] = make_uint2(e.sel, e.hi0);
             }
         } else {
 #pragma unroll
@@ -1379,7 +1393,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.halo = mine + kStageBytes;
     L.bw = reinterpret_cast<lk_u64*>(mine + kStageBytes + 16);
     L.lut = lds;                                                     // build_latin1_tables (kModeLatin1: in place of the Unicode tables)
-    L.ltab = w + kLdsSlice;
+    L.ltab = lds + kLdsLeadTab;
     L.tables = lds;
     L.ctl = reinterpret_cast<int*>(w + kLdsMisc) + 16;
     L.t1b = lds;

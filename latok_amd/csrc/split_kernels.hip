@@ -70,17 +70,26 @@ __device__ __forceinline__ uint32_t classify1_b6(const uint8_t* t1b, const uint8
 }
 
 __device__ __forceinline__ uint32_t classify4(const uint8_t* t1, const uint8_t* t2, u32x4 v, bool* not_ascii = nullptr) {
-    uint32_t c;
-    // wave-uniform fast path: all 256 chars of this wave instruction are ASCII -> stage-2 block 0, no stage-1 lookup
+    // wave-uniform fast path: all 256 chars of this wave instruction are ASCII -> stage-2 block 0, no stage-1 lookup.
+    // Either way the four lookups of a table level are requested together (the empty asm pins them): left alone hipcc shares the
+    // fourth lookup between the two branches and strings the others along -- two LDS round trips per ASCII row instead of one,
+    // five per non-ASCII row instead of two.
     const bool ascii = __all((v.x | v.y | v.z | v.w) < 128u);
     if (not_ascii && !ascii) *not_ascii = true;
+    uint32_t c0, c1, c2, c3;
     if (ascii) {
-        c = (uint32_t)t2[v.x] | ((uint32_t)t2[v.y] << 8) | ((uint32_t)t2[v.z] << 16) | ((uint32_t)t2[v.w] << 24);
+        c0 = t2[v.x]; c1 = t2[v.y]; c2 = t2[v.z]; c3 = t2[v.w];
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     } else {
-        c = classify1(t1, t2, v.x) | (classify1(t1, t2, v.y) << 8) | (classify1(t1, t2, v.z) << 16) |
-            (classify1(t1, t2, v.w) << 24);
+        const uint32_t last = (uint32_t)(kStage1Len - 1), low = (1u << kTblShift) - 1u;
+        uint32_t b0 = t1[min(v.x >> kTblShift, last)], b1 = t1[min(v.y >> kTblShift, last)],
+                 b2 = t1[min(v.z >> kTblShift, last)], b3 = t1[min(v.w >> kTblShift, last)];
+        asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+        c0 = t2[(b0 << kTblShift) | (v.x & low)]; c1 = t2[(b1 << kTblShift) | (v.y & low)];
+        c2 = t2[(b2 << kTblShift) | (v.z & low)]; c3 = t2[(b3 << kTblShift) | (v.w & low)];
+        asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     }
-    return c;
+    return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
 }
 
 __device__ __forceinline__ void wave_lds_sync() {

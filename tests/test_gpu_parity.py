@@ -1057,6 +1057,45 @@ def test_utf8_byte_space(gpu, oracle):
             assert g == want, (t[:60], g[:8], want[:8])
 
 
+def test_utf8_byte_space_tables_arrive_when_the_first_multibyte_char_does(gpu, oracle):
+    """Byte space copies its class table to LDS on demand (split_kernels.hip: tables_ensure_bytes): the launch brings in the 128
+    ASCII codes, the first wave of a workgroup that meets a multi-byte char fetches the rest, waves that arrive meanwhile take a
+    share or wait.  Large ASCII batches (hundreds of tiles per workgroup) whose ONLY multi-byte chars sit at chosen places -- the
+    very first tile, the very last, one tile somewhere in the middle, the last byte of a tile, every 50th tile -- so that one wave
+    fetches alone, early or late in its workgroup's life, or many workgroups do at once; results against the oracle, mapped to
+    byte positions; the same call repeated (every launch starts without the table)."""
+    from latok_amd import batch
+    rng = random.Random(77)
+    words = ALPHABETS["words"]
+    base = random_strings(rng, 9000, 100, 300, words)                    # ~1.8 MB of ASCII: ~440 tiles
+    variants = []
+    v = list(base); v[0] = "é" + v[0]; variants.append(v)                                   # first tile
+    v = list(base); v[-1] = v[-1] + " 日本語"; variants.append(v)                            # last tile
+    v = list(base); v[len(v) // 2] = v[len(v) // 2][:50] + "🤓 ü" + v[len(v) // 2][50:]; variants.append(v)   # the middle
+    v = list(base)
+    head = sum(len(t) for t in v[:20])
+    pad = (4096 - (head % 4096) - 1) % 4096                              # a 2-byte char whose lead is a tile's last byte
+    v[20] = "x" * pad + "é" + v[20]
+    variants.append(v)
+    v = list(base)
+    for i in range(0, len(v), 1000): v[i] = v[i] + " Привет ①"
+    variants.append(v)
+    variants.append(list(base))                                          # and none at all
+    for texts in variants:
+        blobs, boff, flags, per_string = _byte_expect(oracle, texts)
+        utf8 = np.frombuffer(b"".join(blobs), np.uint8)
+        total = int(boff[-1])
+        for _ in range(2):
+            got = bits_to_bool(batch.split_mask_utf8_bytes_csr(utf8, boff), total)
+            if not np.array_equal(got, flags):
+                bad = int(np.nonzero(got != flags)[0][0])
+                s_ = int(np.searchsorted(boff, bad, side="right") - 1)
+                raise AssertionError(f"byte mask differs at byte {bad} (string {s_}, byte {bad - boff[s_]} of {boff[s_ + 1] - boff[s_]})")
+        counts, offs = batch.split_offsets_utf8_bytes_csr(utf8, boff)
+        assert np.array_equal(counts, [len(x) for x in per_string])
+        assert np.array_equal(offs, np.concatenate(per_string))
+
+
 def test_utf8_byte_space_malformed_bytes_against_the_cpu_model(gpu):
     """Byte space on bytes that are NOT well-formed UTF-8: stray continuation bytes (also right behind '#' '@' ':' '/' '.',
     which sends the tile through the general rule form), runs of more than three of them, truncated sequences, lone leads,

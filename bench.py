@@ -397,7 +397,7 @@ def pmc_traffic(workload: str, total_chars: int, in_flight: int, distinct: bool)
     passes, gfx950 corrections); a counter pass cannot run inside this process, so the figure is null for a workload / size that
     has none.  The pass of the line's own command (batches in flight, one or two input copies) is preferred; any other is named
     as what it is."""
-    best, best_score = None, -1
+    best, best_score = None, (-1, -1)
     for path in PMC_SUMMARIES:
         try:
             with open(path) as f:
@@ -410,7 +410,8 @@ def pmc_traffic(workload: str, total_chars: int, in_flight: int, distinct: bool)
                 continue
             same_flow = int(rec.get("in_flight", 1)) == in_flight
             same_inputs = in_flight < 2 or bool(rec.get("distinct_inputs", 0)) == bool(distinct)
-            score = 2 * same_flow + (same_flow and same_inputs)
+            # (a flow pass holds two instantiations of the kernel: its own and the one-batch warm-up passes'; the one launched more wins)
+            score = (2 * same_flow + (same_flow and same_inputs), int(rec.get("launches") or 0))
             if score > best_score:
                 best_score = score
                 best = (rec.get("hbm_bytes_per_launch"),

@@ -377,7 +377,7 @@ int run_pipeline(Ctx& g, const uint32_t* d_cps, const int64_t* d_row, int64_t n_
     }
     if (stages & 1) HIP_TRY(latok::launch_tile_index(P, st));   // (the kernel-timing loop of latok_bench_split_mask launches stage 1 alone)
     if (tiles_begin) HIP_TRY(hipEventRecord(tiles_begin, st));
-    if (stages & 2) HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st));   // (the plan may leave CUs free; the grid never exceeds the chip)
+    if (stages & 2) HIP_TRY(latok::launch_split_tiles(P, mode, g.n_cu, st, slot != nullptr));   // (the plan may leave CUs free; the grid never exceeds the chip)
     if (tiles_end) HIP_TRY(hipEventRecord(tiles_end, st));
     if (stages & 4) HIP_TRY(latok::launch_resolve_fix(P, mode, g.n_cu, st));
     return LATOK_OK;

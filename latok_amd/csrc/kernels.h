@@ -149,7 +149,7 @@ hipError_t launch_features_tiles(const FeatParams& P, int n_cu, hipStream_t st);
 
 void plan_segments(int64_t n_tiles, int n_cu, int* seg_tiles, int64_t* n_segs);
 hipError_t launch_tile_index(const SplitParams& P, hipStream_t st);   // stage 0: P.tile_first (must be set)
-hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st);
+hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st, bool in_flow = false);   // in_flow: a batch of a flow (deeper prefetch)
 hipError_t launch_resolve_fix(const SplitParams& P, int mode, int n_cu, hipStream_t st);
 // the three stages in one launch of one workgroup: batches of at most kOneSegTiles tiles planned as ONE segment
 // (P.n_segs = 1, P.seg_tiles >= P.n_tiles), UTF-32 bitmask modes (kModeBits / kModeRules)

@@ -435,8 +435,14 @@ __device__ __forceinline__ uint32_t bytes_halo_load(const uint8_t* __restrict__ 
 }
 
 constexpr int kCpsPrefetchRows = 2;   // rows (1 KiB) of the wave's next UTF-32 tile requested before phase 2 of the current one
+// ... and in the tile kernel of a FLOW batch (two batches in flight, each planned for 7/8 of the CUs): six.  Same box, R = 2 / 4 / 5 / 6:
+// C2 through the flow 1 424 / 1 434 / 1 439 / 1 448 GB/s (sustained 1 472 / 1 487 / 1 489 / 1 500), C3 2 450 -> 2 585 (+5 %) -- but
+// one batch at a time 1 213 -> 1 205 on C2, 2 306 -> 2 266 on C3, the isolated kernel 94.5 -> 95.2 us: the depth that pays while another
+// kernel shares the memory system costs a little when the kernel is alone, so the launch scheme picks the instantiation.
+constexpr int kCpsPrefetchRowsFlow = 6;
+constexpr int kCpsPrefetchMax = kCpsPrefetchRowsFlow;
 struct CpsPrefetch {
-    u32x4 v[kCpsPrefetchRows];
+    u32x4 v[kCpsPrefetchMax];
     bool valid;
 };
 
@@ -962,7 +968,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
 // 94.4-94.5 us with R = 2 (R = 1: 93.9-94.1, R = 4: 95-99), step 106.6-107.3 -> 105.0-105.1; C3 / C4 / C5 within their noise
 // (profiles/r03_ab_headline_prefetch.txt).
 
-template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false>
+template <int MODE, bool DEFER = false, bool SMALL = false, bool FAST_TAIL = false, int PF = kCpsPrefetchRows>
 __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileLds& L, int64_t t, int64_t idx0, int q_in,
                                              int tail_zero, bool write_summary, int4* summ_l, int lane
 #ifdef LATOK_STAMPS
@@ -1055,7 +1061,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
     } else if (t0 + kTile <= total) {
         u32x4 v[16];
         const u32x4* src = reinterpret_cast<const u32x4*>(P.cps + t0) + lane;
-        constexpr int R = kCpsPrefetchRows;
+        constexpr int R = PF;
         const bool pre = R > 0 && pf && pf->valid;      // wave-uniform
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -1110,7 +1116,7 @@ __device__ __forceinline__ lk_u64 process_tile(const SplitParams& P, const TileL
         if (want && t_next >= 0 && (t_next + 1) * kTile <= total) {
             const u32x4* nsrc = reinterpret_cast<const u32x4*>(P.cps + t_next * kTile) + lane;
 #pragma unroll
-            for (int i = 0; i < kCpsPrefetchRows; ++i) pf->v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
+            for (int i = 0; i < PF; ++i) pf->v[i] = __builtin_nontemporal_load(nsrc + 64 * i);
             pf->valid = true;
         }
     }
@@ -1429,7 +1435,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
 #define LATOK_STAMP_NULL
 #endif
 
-template <int MODE, bool FAST_TAIL = false, int WPB = kWPB>
+template <int MODE, bool FAST_TAIL = false, int WPB = kWPB, int PF = kCpsPrefetchRows>
 __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, int64_t seg, int tid, int lane,
                                             int wave, bool tables LATOK_STAMP_PARAM) {
     const int S = P.seg_tiles;
@@ -1475,7 +1481,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
     CpsPrefetch pf;
     pf.valid = false;
     for (int k = wave, j = 0; k < n_seg; k += WPB, ++j) {
-        const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG
+        const lk_u64 w = process_tile<MODE, kDefer, false, FAST_TAIL, PF>(P, L, T0 + k, lane_read64(tfv, j), 0, -1, true, &sm[k], lane LATOK_STAMP_ARG
                                                                       , MODE == kModeBits && !FAST_TAIL ? &pf : nullptr, k + WPB < n_seg ? T0 + k + WPB : (int64_t)-1
                                                                       );
         if (kDefer) put(w, k);
@@ -1505,7 +1511,7 @@ __device__ __forceinline__ void run_segment(const SplitParams& P, uint8_t* lds, 
 // FAST_TAIL: the batch's last, partial tile requests all its rows before the first lookup (process_tile).  Chosen for small
 // batches, where that tile's latency is a visible share of the call (a 4-tile batch in pinned host memory: 31 -> 16 us);
 // the large-batch instantiation keeps the serial tail: the unified form costs its full-tile loop 16 VGPRs and 4 % on C2.
-template <int MODE, bool FAST_TAIL = false>
+template <int MODE, bool FAST_TAIL = false, int PF = kCpsPrefetchRows>
 __global__ __launch_bounds__(tile_wpb(MODE) * 64) void k_tiles_main(SplitParams P) {
     constexpr int WPB = tile_wpb(MODE);
     __shared__ __attribute__((aligned(16))) uint8_t lds[lds_total_tiles(MODE)];
@@ -1525,7 +1531,7 @@ __global__ __launch_bounds__(tile_wpb(MODE) * 64) void k_tiles_main(SplitParams 
     for (int i = 0; i < 16; ++i) stamp_acc[i] = 0;
 #endif
     for (int64_t seg = blockIdx.x; seg < P.n_segs; seg += gridDim.x) {
-        run_segment<MODE, FAST_TAIL, WPB>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
+        run_segment<MODE, FAST_TAIL, WPB, PF>(P, lds, seg, tid, lane, wave, tables LATOK_STAMP_ARG);
         tables = false;
     }
 #ifdef LATOK_STAMPS
@@ -2595,10 +2601,11 @@ static inline int grid_for(const SplitParams& P, int n_cu) {
     return (int)(P.n_segs < n_cu ? (P.n_segs < 1 ? 1 : P.n_segs) : n_cu);
 }
 
-hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st) {
+hipError_t launch_split_tiles(const SplitParams& P, int mode, int n_cu, hipStream_t st, bool in_flow) {
     const dim3 grid(grid_for(P, n_cu)), block(kWPB * 64);
     const bool fast_tail = P.n_tiles <= kFastTailTiles;
-    if (mode == kModeBits && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeBits, true>), grid, block, 0, st, P);
+    if (mode == kModeBits && in_flow && !fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeBits, false, kCpsPrefetchRowsFlow>), grid, block, 0, st, P);
+    else if (mode == kModeBits && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeBits, true>), grid, block, 0, st, P);
     else if (mode == kModeRules && fast_tail) hipLaunchKernelGGL((k_tiles_main<kModeRules, true>), grid, block, 0, st, P);
     else if (mode == kModeBits) hipLaunchKernelGGL((k_tiles_main<kModeBits>), grid, block, 0, st, P);
     else if (mode == kModeValues) hipLaunchKernelGGL((k_tiles_main<kModeValues>), grid, block, 0, st, P);

@@ -690,7 +690,8 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
     lk_rule_counts counts;    // kModeValuesRules only: rows of C_SPLIT / C_SYM that hold at each char
     lk_u64 space_plane = 0;   // SPACE plane for the token-span passes (byte mode: smeared over continuation bytes)
     lk_u64 cont_plane = 0;    // byte mode: continuation bytes of my word (P.lead_out)
-    int no_patch = 0;         // byte mode: the tile holds multi-byte chars, the resolve stage must recompute, not patch
+    int no_patch = 0;         // byte mode: the tile holds multi-byte chars: the one bit a patch of the resolve stage keeps (the C_SYM
+                              // bit of a block's last char) sits at that char's LEAD byte, which the stage finds in the bytes
     if (MODE == kModeBlockMask) {
         // a1 -> start plane, a2 -> space plane; 64 bytes each, non-zero = set (PyArray_Nonzero, latok.c:178,198)
         lk_u64 st = 0, sp = 0;
@@ -854,9 +855,20 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             p_rel = lane_read(64 * lane + top + s_top, last_lane);
             tail_keep = lane_read(1 - s_top, last_lane);
         }
-        const int hs_pos = c_rel > 0 ? c_rel - 1 : 0;
-        const int head_sym = c_rel > 0 ? lane_read((int)((loc.sym >> (hs_pos & 63)) & 1ull), hs_pos >> 6) : 0;
-        const int tail_sym = lane_read((int)(loc.sym >> 63), 63);
+        int head_sym, tail_sym;
+        if (mode_base(MODE) == kModeBytes) {
+            // A block holds no closing event, and C_SYM = SYMBOL & NEXT_SPACE is set only in front of one: the only C_SYM bit a block
+            // can hold is its last char's, wherever that char's lead byte is -- "any C_SYM bit in the block" is the flag.
+            const int64_t lo_w = 64 * (int64_t)lane;
+            const lk_u64 in_head = c_rel >= lo_w + 64 ? ~0ull : (c_rel <= lo_w ? 0ull : ((1ull << (c_rel - lo_w)) - 1ull));
+            const lk_u64 in_tail = p_rel <= lo_w ? ~0ull : (p_rel >= lo_w + 64 ? 0ull : (~0ull << (p_rel - lo_w)));
+            head_sym = __ballot((loc.sym & in_head) != 0ull) != 0ull;
+            tail_sym = __ballot((loc.sym & in_tail) != 0ull) != 0ull;
+        } else {
+            const int hs_pos = c_rel > 0 ? c_rel - 1 : 0;
+            head_sym = c_rel > 0 ? lane_read((int)((loc.sym >> (hs_pos & 63)) & 1ull), hs_pos >> 6) : 0;
+            tail_sym = lane_read((int)(loc.sym >> 63), 63);
+        }
         if (lane == 0) {
             const int geom = (closing_lanes != 0) | (c_rel << 1) | (p_rel << 14) | (head_sym << 27) | (tail_keep << 28) |
                              (tail_sym << 29) | (no_patch << 30);
@@ -1222,10 +1234,12 @@ __device__ __forceinline__ void block_scan(Fn64 f, Hd64 h, ScanLdsT<NW>& L, Fn64
 
 
 // clear mask bits [lo, hi) (clamped to limit); afterwards re-set the first / last bit of the range on request
+// (last_back: the kept last bit sits that many positions before hi - 1 -- byte space: the lead byte of the block's last char)
 __device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t hi, int64_t limit, int keep_first,
-                                            int keep_last) {
+                                            int keep_last, int last_back = 0) {
     if (hi > limit) hi = limit;
     if (lo >= hi) return;
+    const int64_t last = hi - 1 - last_back;
     for (int64_t w = lo >> 6; w <= (hi - 1) >> 6; ++w) {
         const int64_t base = w << 6;
         uint64_t m = ~0ull;
@@ -1233,7 +1247,7 @@ __device__ __forceinline__ void clear_range(uint64_t* bits, int64_t lo, int64_t 
         if (hi < base + 64) m &= (1ull << (hi - base)) - 1ull;
         uint64_t v = bits[w] & ~m;
         if (keep_first && (lo >> 6) == w) v |= 1ull << (lo & 63);
-        if (keep_last && ((hi - 1) >> 6) == w) v |= 1ull << ((hi - 1) & 63);
+        if (keep_last && last >= lo && (last >> 6) == w) v |= 1ull << (last & 63);
         bits[w] = v;
     }
 }
@@ -1604,17 +1618,33 @@ __device__ __forceinline__ void resolve_segments(const SplitParams& P, uint8_t* 
             const int tz0 = s.y > 0;
             if (q_in != 0 || tz != tz0) {
                 const int geom = s.w;
-                // (byte mode: only tiles without multi-byte chars, where "last char of a block" = "last position")
-                if (!mode_rules(MODE) && (MODE == kModeBits || mode_is_bytes(MODE)) && !((geom >> 30) & 1) && (geom & 1) && q_in <= 1 &&
+                if (!mode_rules(MODE) && (MODE == kModeBits || mode_is_bytes(MODE)) && (geom & 1) && q_in <= 1 &&
                     (q_in == 0 || s.z == 0)) {
                     // Patch in place: one pending start entering a tile whose head block has no start of its own
                     // zeroes that head block; a tail block that turns out to be zeroed is cleared.  What stays in a
                     // cleared block: the C_SYM bit of its last char and the bit of a string start.
+                    // (byte space, tiles with multi-byte chars: the last char's bit is at its lead byte, up to 3 bytes before the
+                    // block's last position -- found in the bytes themselves)
                     const int64_t t0 = t * kTile;
                     const int64_t t_end = min(t0 + kTile, P.total);
-                    if (q_in == 1) clear_range(P.bits_out, t0, t0 + ((geom >> 1) & 0x1FFF), t_end, 0, (geom >> 27) & 1);
-                    if (tz != tz0)
-                        clear_range(P.bits_out, t0 + ((geom >> 14) & 0x1FFF), t_end, t_end, (geom >> 28) & 1, (geom >> 29) & 1);
+                    auto lead_back = [&](int64_t lo, int64_t hi) -> int {
+                        int back = 0;
+                        if (mode_base(MODE) == kModeBytes && ((geom >> 30) & 1)) {
+                            if (hi > t_end) hi = t_end;
+                            while (back < 3 && hi - 1 - back > lo && (P.u8[hi - 1 - back] & 0xC0u) == 0x80u) ++back;
+                        }
+                        return back;
+                    };
+                    if (q_in == 1) {
+                        const int64_t hi = t0 + ((geom >> 1) & 0x1FFF);
+                        const int keep = (geom >> 27) & 1;
+                        clear_range(P.bits_out, t0, hi, t_end, 0, keep, keep ? lead_back(t0, hi) : 0);
+                    }
+                    if (tz != tz0) {
+                        const int64_t lo = t0 + ((geom >> 14) & 0x1FFF);
+                        const int keep = (geom >> 29) & 1;
+                        clear_range(P.bits_out, lo, t_end, t_end, (geom >> 28) & 1, keep, keep ? lead_back(lo, t_end) : 0);
+                    }
                 } else {
                     const int slot = atomicAdd(&misc[0], 1);
                     fix_t[slot] = tid;

@@ -1096,6 +1096,38 @@ def test_utf8_byte_space_tables_arrive_when_the_first_multibyte_char_does(gpu, o
         assert np.array_equal(offs, np.concatenate(per_string))
 
 
+def test_utf8_byte_space_blocks_that_end_in_a_multibyte_symbol_near_tile_edges(gpu, oracle):
+    """The resolve stage patches a tile in place when one pending start enters it or its open tail block turns out to be masked;
+    what stays of a cleared block is the C_SYM bit of its LAST char (default_tokenizer.py:128-131: splits = raw * mask + sym).  In
+    byte space that bit sits at the char's lead byte, up to 3 bytes before the block's last position, also when the tile holds
+    multi-byte chars (the stage finds the lead in the bytes).  URLs (a masked block from 'http://' to the next space) made of
+    2-, 3- and 4-byte chars, closed by a multi-byte SYMBOL + space, with the closing char at every byte offset around a tile edge
+    -- in the tile's head block, in its tail block, straddling the edge."""
+    from latok_amd import batch
+    fillers = ["日", "é", "🤓", "aé日"]
+    closers = ["。", "、", "🤓", "¡", "."]
+    for fill in fillers:
+        fb = len(fill.encode())
+        for closer in closers:
+            texts = []
+            for shift in range(0, 7):
+                n = (2 * 4096 - 7 - shift) // fb
+                for dn in (-2, -1, 0, 1):
+                    texts.append("x" * shift)                                   # moves the URL's bytes against the tile grid
+                    texts.append("http://" + fill * (n + dn) + closer + " tail " + fill + closer)
+                    texts.append("a " + "http://" + fill * (n + dn) + closer)  # ... and the block that ends with the string
+            blobs, boff, flags, per_string = _byte_expect(oracle, texts)
+            utf8 = np.frombuffer(b"".join(blobs), np.uint8)
+            total = int(boff[-1])
+            got = bits_to_bool(batch.split_mask_utf8_bytes_csr(utf8, boff), total)
+            if not np.array_equal(got, flags):
+                bad = int(np.nonzero(got != flags)[0][0])
+                s_ = int(np.searchsorted(boff, bad, side="right") - 1)
+                raise AssertionError(f"{fill!r} {closer!r}: byte mask differs at byte {bad} (string {s_}, byte {bad - boff[s_]} of {boff[s_ + 1] - boff[s_]}; tile offset {bad % 4096})")
+            counts, offs = batch.split_offsets_utf8_bytes_csr(utf8, boff)
+            assert np.array_equal(offs, np.concatenate(per_string))
+
+
 def test_utf8_byte_space_malformed_bytes_against_the_cpu_model(gpu):
     """Byte space on bytes that are NOT well-formed UTF-8: stray continuation bytes (also right behind '#' '@' ':' '/' '.',
     which sends the tile through the general rule form), runs of more than three of them, truncated sequences, lone leads,

@@ -525,15 +525,15 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
         uint32_t d[R][4], out[R][4];
 #pragma unroll
         for (int a = 0; a < R; ++a) { d[a][0] = v[i0 + a].x; d[a][1] = v[i0 + a].y; d[a][2] = v[i0 + a].z; d[a][3] = v[i0 + a].w; }
-        // every byte as if it were ASCII: one lookup each in the stage-2 blocks of U+0000..U+007F (blocks 0 and 1 by construction
-        // of the table); the results at non-ASCII positions are cleared below
+        // every byte as if it were a char of its own: one lookup each in code[256] (the ASCII codes; 0 from 0x80 on, so the
+        // positions of multi-byte chars come back empty)
 #pragma unroll
         for (int a = 0; a < R; ++a) {
             // all 16 lookups of the row requested before the first one is used: left to itself hipcc keeps two or three in flight
             // (a register each), and the row waits for the LDS eight times instead of once
             uint32_t c[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) c[k] = L.ctab[(d[a][k >> 2] >> (8 * (k & 3))) & 0x7Fu];
+            for (int k = 0; k < 16; ++k) c[k] = L.ctab[(d[a][k >> 2] >> (8 * (k & 3))) & 0xFFu];
             asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                               "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15]));
 #pragma unroll
@@ -569,8 +569,7 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
             for (int q = 0; q < 4; ++q) {
                 const uint32_t hi = d[a][q] & 0x80808080u;
                 const uint32_t cont = hi & ~(d[a][q] << 1);
-                const uint32_t ff = hi | (hi - (hi >> 7));                      // 0xFF at the non-ASCII bytes
-                out[a][q] = (out[a][q] & ~ff) | cont;                           // ASCII codes | LK_CODE_CONT at continuation bytes
+                out[a][q] |= cont;                                              // ASCII codes | LK_CODE_CONT at continuation bytes
                 m1[a][q] = hi ^ cont;
                 m2[a][q] = m1[a][q] & (m1[a][q] - 1u);
                 rest[a][q] = m2[a][q] & (m2[a][q] - 1u);                        // leads beyond two per dword (malformed input)
@@ -618,7 +617,21 @@ __device__ __forceinline__ bool bytes_phase1(const SplitParams& P, const TileLds
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) out[a][s & 3] |= (bad[a][s] ? code_fffd : code[a][s]) << r8[a][s];
+                for (int s = 0; s < 8; ++s) out[a][s & 3] |= code[a][s] << r8[a][s];
+            // Sequences that are cut short (malformed input) are U+FFFD: looked for once per row, wave-wide, instead of a compare
+            // and a select per slot; the rare row that holds one puts U+FFFD's code in place of what the slot looked up.
+            bool any_bad = false;
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) any_bad = any_bad || bad[a][s];
+            if (__any(any_bad)) {
+#pragma unroll
+                for (int a = 0; a < R; ++a)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        if (bad[a][s]) out[a][s & 3] = (out[a][s & 3] & ~(0xFFu << r8[a][s])) | (code_fffd << r8[a][s]);
+            }
         }
 #pragma unroll
         for (int a = 0; a < R; ++a) {
@@ -1287,9 +1300,11 @@ constexpr int kLdsSlice = kLdsMisc + 256;                          // end of the
 // Byte space's tables are larger than the other modes' ([stage 1, uint16 | stage 2 | byte decode table] at 0, all of it below
 // 64 KiB, so that a lookup's table base fits the 16-bit offset field of its ds_read); everything behind the tables moves up by
 // the difference.  The kernels add lds_shift(MODE) to every offset above but the tables'.
-constexpr int kLdsLeadTab = kB6TablesBytes;                       // kModeBytes: the byte decode table, behind the class table
-constexpr int lds_shift(int mode) { return mode_base(mode) == kModeBytes ? kLdsLeadTab + kLeadTabBytes - kTablesLdsBytes : 0; }
-static_assert(lds_shift(kModeBytes) % 16 == 0 && kLdsLeadTab + kLeadTabBytes < 65536, "alignment / immediate offsets");
+constexpr int kLdsLeadTab = kB6TablesBytes;                       // kModeBytes: the byte decode table, behind the class table,
+constexpr int kLdsByteCodes = kLdsLeadTab + kLeadTabBytes;        //   then code[256] of a byte taken as a char of its own: the ASCII codes, 0 from 0x80 on
+constexpr int kByteCodesBytes = 256;
+constexpr int lds_shift(int mode) { return mode_base(mode) == kModeBytes ? kLdsByteCodes + kByteCodesBytes - kTablesLdsBytes : 0; }
+static_assert(lds_shift(kModeBytes) % 16 == 0 && kLdsByteCodes + kByteCodesBytes < 65536, "alignment / immediate offsets");
 constexpr int kLdsTotalBase = kLdsSlice;
 constexpr int kLdsTotalBytes = kLdsSlice + lds_shift(kModeBytes);
 constexpr int lds_total(int mode) { return mode_base(mode) == kModeBytes ? kLdsTotalBytes : kLdsTotalBase; }
@@ -1309,6 +1324,13 @@ static_assert(kSegMax == kWPB * 64, "one tile per thread in the block-wide scans
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget of one CU");
 static_assert(kLdsSumm % 16 == 0 && kLdsScan % 16 == 0 && kLdsSlice % 16 == 0, "alignment");
 
+// byte space: code[256] of a byte taken as a char of its own -- the 128 ASCII codes (stage-2 blocks 0 and 1), 0 from 0x80 on: the
+// lookups of phase 1 then need no masking of the non-ASCII positions (threads 0..15)
+__device__ __forceinline__ void load_byte_codes(uint8_t* lds, const SplitParams& P) {
+    if (threadIdx.x < 8) reinterpret_cast<uint4*>(lds + kLdsByteCodes)[threadIdx.x] = reinterpret_cast<const uint4*>(P.t2)[threadIdx.x];
+    else if (threadIdx.x < 16) reinterpret_cast<uint4*>(lds + kLdsByteCodes)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Both tables are contiguous in LDS ([stage1 | stage2]) and in global memory (api.cpp uploads them back to back), so the
 // copy is one stream of kTablesLdsBytes / 16 vectors; all of a thread's loads are issued before its first LDS write.
 template <int NT = kWPB * 64, int MODE = kModeBits>
@@ -1320,6 +1342,7 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
     if (mode_base(MODE) == kModeBytes) {
         // byte space: its own class table -- stage 1 (uint16 offsets) to 0, stage 2 behind it
         build_lead_table<NT>(lds + kLdsLeadTab);
+        load_byte_codes(lds, P);
         const uint4* src1 = reinterpret_cast<const uint4*>(P.t1);
         const uint4* src2 = reinterpret_cast<const uint4*>(P.t2);
         uint4* dst1 = reinterpret_cast<uint4*>(lds);
@@ -1371,8 +1394,8 @@ __device__ __forceinline__ void load_tables(uint8_t* lds, const SplitParams& P) 
 
 // k_tiles_main in byte space: the ASCII part of the class table now, the rest when a tile asks for it (tables_ensure_bytes)
 __device__ __forceinline__ void load_tables_ascii_bytes(uint8_t* lds, const SplitParams& P) {
-    if (threadIdx.x < 8) reinterpret_cast<uint4*>(lds + kB6Stage1Bytes)[threadIdx.x] = reinterpret_cast<const uint4*>(P.t2)[threadIdx.x];
-    if (threadIdx.x == 8) {
+    load_byte_codes(lds, P);
+    if (threadIdx.x == 16) {
         int* ctl = reinterpret_cast<int*>(lds + lds_shift(kModeBytes) + kLdsMisc) + 16;
         ctl[0] = ctl[1] = 0;
     }
@@ -1427,7 +1450,7 @@ __device__ __forceinline__ TileLds wave_lds(uint8_t* lds, int wave) {
     L.ctl = reinterpret_cast<int*>(w + kLdsMisc) + 16;
     L.t1b = lds;
     L.t2b = lds + kB6Stage1Bytes;
-    L.ctab = mode_base(MODE) == kModeBytes ? L.t2b : L.lut + kSliceLutBytes;   // (byte space reads it for ASCII bytes only: stage-2 blocks 0 and 1)
+    L.ctab = mode_base(MODE) == kModeBytes ? lds + kLdsByteCodes : L.lut + kSliceLutBytes;   // (byte space: code of a byte taken as a char, 0 from 0x80 on)
     L.small_bits = L.small_space = nullptr;
     return L;
 }

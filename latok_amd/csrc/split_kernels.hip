@@ -869,7 +869,7 @@ __device__ __forceinline__ lk_u64 tile_phase2(const SplitParams& P, const TileLd
             tail_keep = lane_read(1 - s_top, last_lane);
         }
         int head_sym, tail_sym;
-        if (mode_base(MODE) == kModeBytes) {
+        if (mode_base(MODE) == kModeBytes && no_patch) {   // (wave-uniform; tiles without multi-byte chars take the char form below)
             // A block holds no closing event, and C_SYM = SYMBOL & NEXT_SPACE is set only in front of one: the only C_SYM bit a block
             // can hold is its last char's, wherever that char's lead byte is -- "any C_SYM bit in the block" is the flag.
             const int64_t lo_w = 64 * (int64_t)lane;

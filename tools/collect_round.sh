@@ -31,3 +31,4 @@ python3 $R/tools/pmc_traffic_summary.py $P/${TAG}_pmc_summary.json \
   "paths:C3:255924408:1000000:$F/pmc_paths_c3_FETCH_SIZE.csv:$F/pmc_paths_c3_WRITE_SIZE.csv:rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/path_bench.py --workload C3 --iters 3 --paths bytes_mask,utf8_mask,kind_mask"
 sed -i "s/\"round\": 2/\"round\": \"$TAG\"/" $P/${TAG}_pmc_summary.json
 fi
+[ -f $R/gpurun_out/${TAG}_bytes_C3_pmc_summary.txt ] && python3 $R/tools/pmc_narrow_profile.py $TAG

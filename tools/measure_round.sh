@@ -1,7 +1,7 @@
 #!/bin/bash
 # A round's measurement batch (run on the GPU box through gpurun).  Everything lands under gpurun_out/measure_<tag>/ ; what is to
 # be judged is copied into profiles/ afterwards (tools/collect_round.sh <tag>).  A step killed at its limit ends the batch.
-#   tools/measure_round.sh <tag> [part]     tag = r04 ...; part = bench | paths | pathstats | pmc | all (default all)
+#   tools/measure_round.sh <tag> [part]     tag = r04 ...; part = bench | paths | pathstats | pmc | narrow | all (default all)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:?round tag, e.g. r04}; shift
@@ -90,5 +90,12 @@ pmc c3_flow 300 $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline
 pmc paths 300 $R/tools/path_bench.py --workload C2 --iters 3 --paths bytes_mask,kind_mask,offsets32,spans32,features32
 pmc paths_c3 300 $R/tools/path_bench.py --workload C3 --iters 3 --paths bytes_mask,utf8_mask,kind_mask
 cd $R
+fi
+if [ "$PART" = "narrow" ]; then
+# instruction / LDS counters of the narrow-input tile kernels (-> profiles/<tag>_pmc_narrow_kernels.txt by tools/pmc_narrow_profile.py <tag>)
+for wl in C3 C2; do
+bash $R/tools/pmc_pass.sh ${TAG}_bytes_$wl "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE" -- tools/path_bench.py --workload $wl --iters 3 --paths bytes_mask,kind_mask,utf8_mask > $O/narrow_$wl.log 2>&1
+echo "narrow $wl rc=$?" | tee -a $LOG
+done
 fi
 echo "=== done $PART" | tee -a $LOG

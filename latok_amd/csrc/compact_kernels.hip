@@ -555,6 +555,18 @@ __global__ __launch_bounds__(kCompressWaves * 64) void k_lead_compress(
     // words the workgroup owns: those whose last bit is its own, + the batch's final partial word if its last lead is
     const int64_t own_end = end == total_cps ? (end + 63) >> 6 : end >> 6;
     if (end == pos0 || own_end <= ow0) return;                     // no lead at all / all bits lie in a word a later one owns (uniform)
+    // Every byte of the workgroup's tiles is a lead (ASCII text) and its first code point opens an output word: code point k of the
+    // range IS byte k, the packed words are the input words (uniform; nothing to pack, nothing shared with a neighbour).
+    {
+        const int64_t b0 = T0 * kTile, b1 = min((T1 + 1) * (int64_t)kTile, total_bytes);
+        if ((pos0 & 63) == 0 && end - pos0 == b1 - b0) {
+            if (in) {
+                out_mask[ow0 + tid] = x;
+                if (TWO) out_mask2[ow0 + tid] = x2;
+            }
+            return;
+        }
+    }
     __syncthreads();
     {
         const int64_t pos = my_pos0 + pref;
